@@ -1,0 +1,196 @@
+/*
+ * matchy_amd.h — C ABI of the MI355X-native `matchy match` engine (libmatchy_amd.so).
+ *
+ * Drop-in boundary: every `matchy_*` function declared in PART 1 keeps the name, argument meaning, ownership and
+ * error convention of the reference's C API (reference = matchylabs/matchy @ 2025-12-12,
+ * crates/matchy/include/matchy/matchy.h, implemented in crates/matchy/src/c_api/matchy.rs). The citation after
+ * each declaration names the reference interface it replaces. PART 2 is additive (`matchy_scanner_*`): the bulk
+ * entry point behind which the HIP pipeline sits; it is called exactly where the reference calls
+ * Worker::process_batch (crates/matchy/src/processing/parallel.rs:411-439 -> processing/mod.rs:353-448).
+ *
+ * All lookups and extractions run on the GPU. There is no CPU fallback: without a usable HIP device
+ * matchy_open()/matchy_extractor_create() return NULL and scanner calls return MATCHY_ERROR_IO.
+ */
+#ifndef MATCHY_AMD_H
+#define MATCHY_AMD_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (matchy.h:46-86) */
+#define MATCHY_SUCCESS 0
+#define MATCHY_ERROR_FILE_NOT_FOUND -1
+#define MATCHY_ERROR_INVALID_FORMAT -2
+#define MATCHY_ERROR_CORRUPT_DATA -3
+#define MATCHY_ERROR_OUT_OF_MEMORY -4
+#define MATCHY_ERROR_INVALID_PARAM -5
+#define MATCHY_ERROR_IO -6
+
+/* ---- extractor flags and item types (matchy.h:188-288) */
+#define MATCHY_EXTRACT_DOMAINS (1 << 0)
+#define MATCHY_EXTRACT_EMAILS (1 << 1)
+#define MATCHY_EXTRACT_IPV4 (1 << 2)
+#define MATCHY_EXTRACT_IPV6 (1 << 3)
+#define MATCHY_EXTRACT_HASHES (1 << 4)
+#define MATCHY_EXTRACT_BITCOIN (1 << 5)
+#define MATCHY_EXTRACT_ETHEREUM (1 << 6)
+#define MATCHY_EXTRACT_MONERO (1 << 7)
+#define MATCHY_EXTRACT_ALL 255
+
+#define MATCHY_ITEM_TYPE_DOMAIN 0
+#define MATCHY_ITEM_TYPE_EMAIL 1
+#define MATCHY_ITEM_TYPE_IPV4 2
+#define MATCHY_ITEM_TYPE_IPV6 3
+#define MATCHY_ITEM_TYPE_MD5 4
+#define MATCHY_ITEM_TYPE_SHA1 5
+#define MATCHY_ITEM_TYPE_SHA256 6
+#define MATCHY_ITEM_TYPE_SHA384 7
+#define MATCHY_ITEM_TYPE_SHA512 8
+#define MATCHY_ITEM_TYPE_BITCOIN 9
+#define MATCHY_ITEM_TYPE_ETHEREUM 10
+#define MATCHY_ITEM_TYPE_MONERO 11
+
+/* ================================================================================================
+ * PART 1 — reference-compatible surface
+ * ================================================================================================ */
+
+typedef struct matchy_builder_t matchy_builder_t; /* opaque (matchy.h:293-295) */
+typedef struct matchy_t matchy_t;                 /* opaque (matchy.h:396-398) */
+typedef struct matchy_extractor_t matchy_extractor_t; /* opaque (matchy.h:513-515) */
+
+/* matchy.h:361-391. auto_reload / reload_callback are accepted and ignored (watching is out of scope);
+ * cache_capacity is accepted and ignored (no per-thread LRU: every query is answered by the device tables). */
+typedef struct matchy_open_options_t {
+  uint32_t cache_capacity;
+  bool auto_reload;
+  void (*reload_callback)(const void *event, void *user_data);
+  void *reload_callback_user_data;
+} matchy_open_options_t;
+
+/* matchy.h:437-454 */
+typedef struct matchy_result_t {
+  bool found;
+  uint8_t prefix_len;
+  void *_data_cache;
+  const matchy_t *_db_ref;
+} matchy_result_t;
+
+/* matchy.h:520-556 */
+typedef struct matchy_match_t {
+  uint8_t item_type;
+  const char *value;
+  uintptr_t start;
+  uintptr_t end;
+} matchy_match_t;
+typedef struct matchy_matches_t {
+  const matchy_match_t *items;
+  uintptr_t count;
+  void *_internal;
+} matchy_matches_t;
+
+/* ---- builder (replaces c_api/matchy.rs:300-600; matchy.h:578-753) */
+matchy_builder_t *matchy_builder_new(void);                                            /* matchy.h:578 */
+int32_t matchy_builder_set_case_insensitive(matchy_builder_t *b, bool case_insensitive); /* matchy.h:605 (true is rejected at build: f2) */
+int32_t matchy_builder_add(matchy_builder_t *b, const char *key, const char *json_data); /* matchy.h:670, c_api/matchy.rs:401-455 */
+int32_t matchy_builder_set_description(matchy_builder_t *b, const char *description);   /* matchy.h:687 */
+int32_t matchy_builder_save(matchy_builder_t *b, const char *filename);                 /* matchy.h:711 */
+int32_t matchy_builder_build(matchy_builder_t *b, uint8_t **buffer, uintptr_t *size);   /* matchy.h:740 (buffer is malloc'ed; caller frees with free()) */
+void matchy_builder_free(matchy_builder_t *b);                                          /* matchy.h:753 */
+
+/* ---- open / close (c_api/matchy.rs:781-939, 1055-1059; matchy.h:777-938) */
+void matchy_init_open_options(matchy_open_options_t *options);                                   /* matchy.h:777 */
+matchy_t *matchy_open_with_options(const char *filename, const matchy_open_options_t *options);  /* matchy.h:815 (NULL options -> NULL) */
+matchy_t *matchy_open(const char *filename);                                                     /* matchy.h:844 */
+matchy_t *matchy_open_buffer(const uint8_t *buffer, uintptr_t size);                             /* matchy.h:863 (copies the buffer) */
+void matchy_close(matchy_t *db);                                                                 /* matchy.h:938 (NULL-safe) */
+
+/* ---- query (c_api/matchy.rs:1100-1239; matchy.h:980-1034). One query = one device lookup. */
+matchy_result_t matchy_query(const matchy_t *db, const char *query);                    /* matchy.h:980 */
+void matchy_query_into(const matchy_t *db, const char *query, matchy_result_t *result); /* matchy.h:1008 */
+void matchy_free_result(matchy_result_t *result);                                       /* matchy.h:1022 */
+void matchy_free_string(char *string);                                                  /* matchy.h:1034 */
+char *matchy_result_to_json(const matchy_result_t *result);                             /* matchy.h:1323 */
+
+/* ---- introspection (matchy.h:1043-1190) */
+const char *matchy_version(void);                                  /* matchy.h:1043 */
+const char *matchy_format(const matchy_t *db);                     /* matchy.h:1059 */
+bool matchy_has_ip_data(const matchy_t *db);                       /* matchy.h:1074 */
+bool matchy_has_string_data(const matchy_t *db);                   /* matchy.h:1089 */
+bool matchy_has_literal_data(const matchy_t *db);                  /* matchy.h:1104 */
+bool matchy_has_glob_data(const matchy_t *db);                     /* matchy.h:1119 */
+char *matchy_metadata(const matchy_t *db);                         /* matchy.h:1154 (JSON; free with matchy_free_string) */
+char *matchy_get_pattern_string(const matchy_t *db, uint32_t id);  /* matchy.h:1173 */
+uintptr_t matchy_pattern_count(const matchy_t *db);                /* matchy.h:1190 */
+
+/* ---- extractor (c_api/matchy.rs:2270-2395; matchy.h:1380-1460). Items come back in the reference's chunk-path
+ * order (IPv6, IPv4, e-mail, domain, hashes, Bitcoin, Ethereum, Monero; by position inside each class). */
+matchy_extractor_t *matchy_extractor_create(uint32_t flags);                                  /* matchy.h:1380 */
+int32_t matchy_extractor_extract_chunk(const matchy_extractor_t *extractor, const uint8_t *data, uintptr_t len,
+                                       matchy_matches_t *matches);                             /* matchy.h:1423 */
+void matchy_matches_free(matchy_matches_t *matches);                                          /* matchy.h:1434 */
+void matchy_extractor_free(matchy_extractor_t *extractor);                                    /* matchy.h:1445 */
+const char *matchy_item_type_name(uint8_t item_type);                                         /* matchy.h:1460 */
+
+/* ================================================================================================
+ * PART 2 — additive bulk-scan surface (not in the reference)
+ * ================================================================================================ */
+
+typedef struct matchy_scanner_t matchy_scanner_t;
+
+/* One match of Worker::process_bytes (processing/mod.rs:423-443): candidate span + lookup result. */
+typedef struct matchy_scan_hit_t {
+  uint64_t start;        /* byte offset of the matched text in the scanned buffer */
+  uint64_t end;          /* exclusive */
+  uint8_t item_type;     /* MATCHY_ITEM_TYPE_* */
+  uint8_t kind;          /* 2 = IP result, 3 = pattern result */
+  uint8_t prefix_len;    /* IP results */
+  uint8_t _pad;
+  uint32_t data_offset;  /* IP results: offset of the entry data in the MMDB data section */
+  uint32_t n_ids;        /* pattern results: number of pattern ids (literal id first, then glob ids ascending) */
+  uint32_t ids_index;    /* pattern results: index of the first id in pattern_ids / data_offsets */
+} matchy_scan_hit_t;
+
+typedef struct matchy_scan_result_t {
+  const matchy_scan_hit_t *hits;  /* canonical order: by start, then chunk-path class order */
+  size_t n_hits;
+  const uint32_t *pattern_ids;
+  const int64_t *data_offsets;    /* per pattern id: data-section offset or -1 */
+  size_t n_ids;
+  uint64_t lines;                 /* number of '\n' bytes (WorkerStats::lines_processed) */
+  uint64_t candidates;            /* WorkerStats::candidates_tested */
+  uint64_t bytes;
+  void *_internal;
+} matchy_scan_result_t;
+
+/* extract_flags 0 = derive from the database like `matchy match` does (match_cmd.rs:276-303).
+ * device = HIP device ordinal. Returns NULL on failure. One scanner per thread. */
+matchy_scanner_t *matchy_scanner_create(const matchy_t *db, uint32_t extract_flags, int32_t device);
+void matchy_scanner_free(matchy_scanner_t *scanner);
+/* Scan a host buffer (copied to the device in newline-aligned pieces of < 1 GiB). */
+int32_t matchy_scanner_scan(matchy_scanner_t *scanner, const uint8_t *data, size_t len, matchy_scan_result_t *out);
+/* Scan bytes that are already resident in device memory (16-byte aligned, len < 2^31) on `hip_stream`
+ * (a hipStream_t, NULL = default stream). With fetch_hits=false only counters are read back. */
+int32_t matchy_scanner_scan_device(matchy_scanner_t *scanner, const void *device_ptr, size_t len, void *hip_stream,
+                                   bool fetch_hits, matchy_scan_result_t *out);
+void matchy_scan_result_free(matchy_scan_result_t *result);
+/* The NDJSON record `matchy match` prints for hit i (match_processor/parallel.rs:297-369). `text` points at the
+ * scanned bytes on the host. Returned string: matchy_free_string(). */
+char *matchy_scan_hit_to_json(const matchy_scanner_t *scanner, const matchy_scan_result_t *result, size_t i,
+                              const uint8_t *text, const char *source);
+/* Per-kernel HIP-event timing of the last scan: out[0..3] = tokenize, rare, lookup, total (milliseconds). */
+void matchy_scanner_set_profile(matchy_scanner_t *scanner, bool enabled);
+void matchy_scanner_get_timing(const matchy_scanner_t *scanner, float out_ms[4]);
+/* Last error message of the calling thread ("" if none). */
+const char *matchy_amd_last_error(void);
+/* Deterministic builds for tests: fixes the build_epoch metadata value. */
+int32_t matchy_builder_set_build_epoch(matchy_builder_t *b, uint64_t epoch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MATCHY_AMD_H */

@@ -1,0 +1,357 @@
+"""matchy_amd — MI355X-native `matchy match` engine (host mirror over the C ABI in include/matchy_amd.h).
+
+The classes mirror the reference's operator interface for this path:
+  DatabaseBuilder  ~ matchy::DatabaseBuilder   (crates/matchy-format/src/mmdb_builder.rs)
+  Database         ~ matchy::Database          (crates/matchy/src/database.rs)         — lookups run on the GPU
+  Extractor        ~ matchy::extractor::Extractor (crates/matchy-extractor/src/lib.rs) — extraction runs on the GPU
+  Scanner          ~ processing::Worker        (crates/matchy/src/processing/mod.rs:318-448), the bulk scan entry
+
+There is no CPU fallback anywhere in this package: if libmatchy_amd.so is missing the import of the native
+layer raises, and without a HIP device Database()/Extractor() raise RuntimeError.
+"""
+import ctypes as C
+import json
+from pathlib import Path
+
+from . import build as _build
+
+__all__ = ["DatabaseBuilder", "Database", "Extractor", "Scanner", "lib", "ITEM_TYPE_NAMES", "EXTRACT_ALL", "last_error"]
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "lib" / "libmatchy_amd.so"
+
+ITEM_TYPE_NAMES = ["Domain", "Email", "IPv4", "IPv6", "MD5", "SHA1", "SHA256", "SHA384", "SHA512", "Bitcoin", "Ethereum", "Monero"]
+EXTRACT_DOMAINS, EXTRACT_EMAILS, EXTRACT_IPV4, EXTRACT_IPV6 = 1, 2, 4, 8
+EXTRACT_HASHES, EXTRACT_BITCOIN, EXTRACT_ETHEREUM, EXTRACT_MONERO = 16, 32, 64, 128
+EXTRACT_ALL = 255
+
+# every symbol include/matchy_amd.h declares
+EXPORTED_SYMBOLS = [
+    "matchy_builder_new", "matchy_builder_set_case_insensitive", "matchy_builder_add", "matchy_builder_set_description",
+    "matchy_builder_save", "matchy_builder_build", "matchy_builder_free", "matchy_init_open_options",
+    "matchy_open_with_options", "matchy_open", "matchy_open_buffer", "matchy_close", "matchy_query", "matchy_query_into",
+    "matchy_free_result", "matchy_free_string", "matchy_result_to_json", "matchy_version", "matchy_format",
+    "matchy_has_ip_data", "matchy_has_string_data", "matchy_has_literal_data", "matchy_has_glob_data", "matchy_metadata",
+    "matchy_get_pattern_string", "matchy_pattern_count", "matchy_extractor_create", "matchy_extractor_extract_chunk",
+    "matchy_matches_free", "matchy_extractor_free", "matchy_item_type_name", "matchy_scanner_create", "matchy_scanner_free",
+    "matchy_scanner_scan", "matchy_scanner_scan_device", "matchy_scan_result_free", "matchy_scan_hit_to_json",
+    "matchy_scanner_set_profile", "matchy_scanner_get_timing", "matchy_amd_last_error", "matchy_builder_set_build_epoch",
+]
+
+
+class _Result(C.Structure):
+    _fields_ = [("found", C.c_bool), ("prefix_len", C.c_uint8), ("_data_cache", C.c_void_p), ("_db_ref", C.c_void_p)]
+
+
+class _Match(C.Structure):
+    _fields_ = [("item_type", C.c_uint8), ("value", C.c_char_p), ("start", C.c_size_t), ("end", C.c_size_t)]
+
+
+class _Matches(C.Structure):
+    _fields_ = [("items", C.POINTER(_Match)), ("count", C.c_size_t), ("_internal", C.c_void_p)]
+
+
+class _ScanHit(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("end", C.c_uint64), ("item_type", C.c_uint8), ("kind", C.c_uint8),
+                ("prefix_len", C.c_uint8), ("_pad", C.c_uint8), ("data_offset", C.c_uint32), ("n_ids", C.c_uint32),
+                ("ids_index", C.c_uint32)]
+
+
+class _ScanResult(C.Structure):
+    _fields_ = [("hits", C.POINTER(_ScanHit)), ("n_hits", C.c_size_t), ("pattern_ids", C.POINTER(C.c_uint32)),
+                ("data_offsets", C.POINTER(C.c_int64)), ("n_ids", C.c_size_t), ("lines", C.c_uint64),
+                ("candidates", C.c_uint64), ("bytes", C.c_uint64), ("_internal", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libmatchy_amd.so (built in-tree by matchy_amd.build). Raises if it is missing — no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is missing: run `python -m matchy_amd.build` (hipcc, gfx950) first")
+    L = C.CDLL(str(LIB_PATH))
+    vp, cp, u8p = C.c_void_p, C.c_char_p, C.POINTER(C.c_uint8)
+    sig = {
+        "matchy_builder_new": (vp, []),
+        "matchy_builder_set_case_insensitive": (C.c_int32, [vp, C.c_bool]),
+        "matchy_builder_add": (C.c_int32, [vp, cp, cp]),
+        "matchy_builder_set_description": (C.c_int32, [vp, cp]),
+        "matchy_builder_save": (C.c_int32, [vp, cp]),
+        "matchy_builder_build": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "matchy_builder_free": (None, [vp]),
+        "matchy_builder_set_build_epoch": (C.c_int32, [vp, C.c_uint64]),
+        "matchy_open": (vp, [cp]),
+        "matchy_open_with_options": (vp, [cp, vp]),
+        "matchy_open_buffer": (vp, [cp, C.c_size_t]),
+        "matchy_close": (None, [vp]),
+        "matchy_query": (_Result, [vp, cp]),
+        "matchy_query_into": (None, [vp, cp, C.POINTER(_Result)]),
+        "matchy_free_result": (None, [C.POINTER(_Result)]),
+        "matchy_free_string": (None, [vp]),
+        "matchy_result_to_json": (vp, [C.POINTER(_Result)]),
+        "matchy_version": (cp, []),
+        "matchy_format": (cp, [vp]),
+        "matchy_has_ip_data": (C.c_bool, [vp]),
+        "matchy_has_string_data": (C.c_bool, [vp]),
+        "matchy_has_literal_data": (C.c_bool, [vp]),
+        "matchy_has_glob_data": (C.c_bool, [vp]),
+        "matchy_metadata": (vp, [vp]),
+        "matchy_get_pattern_string": (vp, [vp, C.c_uint32]),
+        "matchy_pattern_count": (C.c_size_t, [vp]),
+        "matchy_extractor_create": (vp, [C.c_uint32]),
+        "matchy_extractor_extract_chunk": (C.c_int32, [vp, cp, C.c_size_t, C.POINTER(_Matches)]),
+        "matchy_matches_free": (None, [C.POINTER(_Matches)]),
+        "matchy_extractor_free": (None, [vp]),
+        "matchy_item_type_name": (cp, [C.c_uint8]),
+        "matchy_scanner_create": (vp, [vp, C.c_uint32, C.c_int32]),
+        "matchy_scanner_free": (None, [vp]),
+        "matchy_scanner_scan": (C.c_int32, [vp, cp, C.c_size_t, C.POINTER(_ScanResult)]),
+        "matchy_scanner_scan_device": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_bool, C.POINTER(_ScanResult)]),
+        "matchy_scan_result_free": (None, [C.POINTER(_ScanResult)]),
+        "matchy_scan_hit_to_json": (vp, [vp, C.POINTER(_ScanResult), C.c_size_t, cp, cp]),
+        "matchy_scanner_set_profile": (None, [vp, C.c_bool]),
+        "matchy_scanner_get_timing": (None, [vp, C.POINTER(C.c_float)]),
+        "matchy_amd_last_error": (cp, []),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().matchy_amd_last_error().decode("utf-8", "replace")
+
+
+def _take_string(ptr) -> str:
+    if not ptr:
+        return None
+    s = C.string_at(ptr).decode("utf-8", "replace")
+    lib().matchy_free_string(ptr)
+    return s
+
+
+class DatabaseBuilder:
+    """Mirror of the reference builder behind matchy_builder_* (host-side, no GPU needed)."""
+
+    def __init__(self, build_epoch=None):
+        self._h = lib().matchy_builder_new()
+        if build_epoch is not None:
+            lib().matchy_builder_set_build_epoch(self._h, build_epoch)
+
+    def add_entry(self, key: str, data: dict):
+        rc = lib().matchy_builder_add(self._h, key.encode("utf-8"), json.dumps(data).encode("utf-8"))
+        if rc != 0:
+            raise ValueError(f"matchy_builder_add({key!r}) failed: rc={rc} {last_error()}")
+
+    def set_description(self, text: str):
+        lib().matchy_builder_set_description(self._h, text.encode("utf-8"))
+
+    def build(self) -> bytes:
+        buf = C.c_void_p()
+        size = C.c_size_t()
+        rc = lib().matchy_builder_build(self._h, C.byref(buf), C.byref(size))
+        if rc != 0:
+            raise ValueError(f"matchy_builder_build failed: rc={rc} {last_error()}")
+        try:
+            return C.string_at(buf, size.value)
+        finally:
+            C.CDLL(None).free(buf)
+
+    def save(self, path: str):
+        rc = lib().matchy_builder_save(self._h, str(path).encode())
+        if rc != 0:
+            raise OSError(f"matchy_builder_save failed: rc={rc} {last_error()}")
+
+    def close(self):
+        if self._h:
+            lib().matchy_builder_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Database:
+    """An opened .mxy database, uploaded once to device memory (matchy_open / matchy_open_buffer)."""
+
+    def __init__(self, source):
+        L = lib()
+        if isinstance(source, (bytes, bytearray, memoryview)):
+            b = bytes(source)
+            self._h = L.matchy_open_buffer(b, len(b))
+        else:
+            self._h = L.matchy_open(str(source).encode())
+        if not self._h:
+            raise RuntimeError("matchy_open failed: " + last_error())
+
+    def close(self):
+        if self._h:
+            lib().matchy_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def lookup(self, query: str):
+        """Database::lookup → None | {'found': True, 'prefix_len': n, 'data': {...}} (matchy_query semantics)."""
+        L = lib()
+        r = L.matchy_query(self._h, query.encode("utf-8") if isinstance(query, str) else bytes(query))
+        try:
+            if not r.found:
+                return None
+            js = _take_string(L.matchy_result_to_json(C.byref(r)))
+            return {"found": True, "prefix_len": r.prefix_len, "data": json.loads(js) if js else None}
+        finally:
+            L.matchy_free_result(C.byref(r))
+
+    def has_ip_data(self):
+        return bool(lib().matchy_has_ip_data(self._h))
+
+    def has_literal_data(self):
+        return bool(lib().matchy_has_literal_data(self._h))
+
+    def has_glob_data(self):
+        return bool(lib().matchy_has_glob_data(self._h))
+
+    def format(self):
+        return lib().matchy_format(self._h).decode()
+
+    def metadata(self):
+        return json.loads(_take_string(lib().matchy_metadata(self._h)))
+
+    def pattern_count(self):
+        return lib().matchy_pattern_count(self._h)
+
+    def pattern_string(self, pid):
+        return _take_string(lib().matchy_get_pattern_string(self._h, pid))
+
+
+class Extractor:
+    """Extractor::extract_from_chunk on the GPU (matchy_extractor_*). Returns (type_name, start, end, value)."""
+
+    def __init__(self, flags=EXTRACT_ALL):
+        self._h = lib().matchy_extractor_create(flags)
+        if not self._h:
+            raise RuntimeError("matchy_extractor_create failed: " + last_error())
+
+    def extract_from_chunk(self, data: bytes):
+        L = lib()
+        m = _Matches()
+        rc = L.matchy_extractor_extract_chunk(self._h, bytes(data), len(data), C.byref(m))
+        if rc != 0:
+            raise RuntimeError(f"matchy_extractor_extract_chunk failed: rc={rc} {last_error()}")
+        try:
+            return [(ITEM_TYPE_NAMES[m.items[i].item_type], m.items[i].start, m.items[i].end, m.items[i].value.decode("utf-8"))
+                    for i in range(m.count)]
+        finally:
+            L.matchy_matches_free(C.byref(m))
+
+    def close(self):
+        if self._h:
+            lib().matchy_extractor_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ScanResult:
+    def __init__(self, scanner, raw):
+        self._scanner = scanner
+        self._raw = raw
+        self.lines = raw.lines
+        self.candidates = raw.candidates
+        self.bytes = raw.bytes
+        self.n_hits = raw.n_hits
+
+    def hits(self):
+        """list of dict(start,end,type,kind,prefix_len,ip_data_offset,ids,offs) in canonical order."""
+        r = self._raw
+        out = []
+        if not r.hits:
+            return out
+        for i in range(r.n_hits):
+            h = r.hits[i]
+            ids = [r.pattern_ids[h.ids_index + k] for k in range(h.n_ids)] if h.kind == 3 else []
+            offs = [r.data_offsets[h.ids_index + k] for k in range(h.n_ids)] if h.kind == 3 else []
+            out.append(dict(start=h.start, end=h.end, type=ITEM_TYPE_NAMES[h.item_type], kind="ip" if h.kind == 2 else "pattern",
+                            prefix_len=h.prefix_len, ip_data_offset=h.data_offset if h.kind == 2 else 0, ids=ids, offs=offs))
+        return out
+
+    def ndjson(self, text: bytes, source="-"):
+        L = lib()
+        return [_take_string(L.matchy_scan_hit_to_json(self._scanner._h, C.byref(self._raw), i, text, source.encode()))
+                for i in range(self._raw.n_hits)] if self._raw.hits else []
+
+    def close(self):
+        if self._raw is not None:
+            lib().matchy_scan_result_free(C.byref(self._raw))
+            self._raw = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scanner:
+    """Bulk scan session (the device-side Worker). One per thread / stream."""
+
+    def __init__(self, db: Database, extract_flags=0, device=0, profile=False):
+        self._db = db
+        self._h = lib().matchy_scanner_create(db.handle, extract_flags, device)
+        if not self._h:
+            raise RuntimeError("matchy_scanner_create failed: " + last_error())
+        if profile:
+            lib().matchy_scanner_set_profile(self._h, True)
+
+    def scan(self, data: bytes) -> ScanResult:
+        raw = _ScanResult()
+        rc = lib().matchy_scanner_scan(self._h, bytes(data), len(data), C.byref(raw))
+        if rc != 0:
+            raise RuntimeError(f"matchy_scanner_scan failed: rc={rc} {last_error()}")
+        return ScanResult(self, raw)
+
+    def scan_device(self, device_ptr: int, nbytes: int, stream: int = 0, fetch_hits=True) -> ScanResult:
+        raw = _ScanResult()
+        rc = lib().matchy_scanner_scan_device(self._h, device_ptr, nbytes, stream, fetch_hits, C.byref(raw))
+        if rc != 0:
+            raise RuntimeError(f"matchy_scanner_scan_device failed: rc={rc} {last_error()}")
+        return ScanResult(self, raw)
+
+    def timing_ms(self):
+        out = (C.c_float * 4)()
+        lib().matchy_scanner_get_timing(self._h, out)
+        return dict(tokenize=out[0], rare=out[1], lookup=out[2], total=out[3])
+
+    def close(self):
+        if self._h:
+            lib().matchy_scanner_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,54 @@
+"""Build libmatchy_amd.so (HIP kernels + host pipeline + C ABI) for gfx950 with hipcc, in-tree."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIBDIR = PKG / "lib"
+LIB = LIBDIR / "libmatchy_amd.so"
+SOURCES = ["scan_kernels.hip", "engine.cpp", "db_image.cpp", "db_builder.cpp", "data_codec.cpp", "capi.cpp"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def needs_build():
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "matchy_amd.h", Path(__file__)]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    LIBDIR.mkdir(exist_ok=True)
+    objs = []
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+             "-Wno-unused-result", "-DNDEBUG"]
+    procs = []
+    for src in SOURCES:
+        obj = LIBDIR / (src.rsplit(".", 1)[0] + ".o")
+        cmd = [HIPCC, *flags, "-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(str(obj))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- hipcc {src} failed ---\n{out.decode(errors='replace')}\n")
+        elif verbose and out:
+            sys.stderr.write(out.decode(errors="replace"))
+    if failed:
+        raise RuntimeError("hipcc compilation failed")
+    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs, "-ldl", "-lpthread"]
+    subprocess.run(link, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,518 @@
+// extern "C" surface of libmatchy_amd.so — see include/matchy_amd.h for the per-function reference citations.
+#include "../../include/matchy_amd.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "db_builder.h"
+#include "db_image.h"
+#include "engine.h"
+#include "netaddr.h"
+
+using namespace mxy;
+
+namespace {
+
+thread_local std::string g_last_error;
+void set_error(const std::string& e) { g_last_error = e; }
+
+struct Builder {
+    DatabaseBuilder b;
+};
+
+struct Db {
+    std::shared_ptr<DbImage> img;
+    std::mutex mu;                                   // guards dev + query scanner (single queries are serialised)
+    std::vector<std::shared_ptr<DeviceDb>> dev;      // per device ordinal, uploaded on first use
+    std::unique_ptr<Scanner> query_scanner;
+    DevBuf<uint8_t> qbuf;
+    DevBuf<Candidate> qcand;
+    std::string format;
+
+    std::shared_ptr<DeviceDb> device_db(int device) {
+        if ((int)dev.size() <= device) dev.resize(device + 1);
+        if (!dev[device]) {
+            auto d = std::make_shared<DeviceDb>();
+            d->upload(*img, device);
+            dev[device] = d;
+        }
+        return dev[device];
+    }
+};
+
+struct ExtractorH {
+    std::shared_ptr<DbImage> img;  // empty image: only the PSL tables are needed
+    std::shared_ptr<DeviceDb> ddb;
+    std::unique_ptr<Scanner> scanner;
+    std::mutex mu;
+    uint32_t flags;
+};
+
+struct MatchesInternal {
+    std::vector<matchy_match_t> items;
+    std::vector<std::string> values;
+};
+
+struct ScannerH {
+    const Db* db;
+    std::unique_ptr<Scanner> sc;
+};
+
+struct ScanResultInternal {
+    std::vector<matchy_scan_hit_t> hits;
+    std::vector<uint32_t> ids;
+    std::vector<int64_t> offs;
+};
+
+int type_rank(uint32_t t) {  // chunk-path extractor order (matchy-extractor/src/lib.rs:449-485)
+    switch (t) {
+        case IT_IPV6: return 0; case IT_IPV4: return 1; case IT_EMAIL: return 2; case IT_DOMAIN: return 3;
+        case IT_MD5: case IT_SHA1: case IT_SHA256: case IT_SHA384: case IT_SHA512: return 4;
+        case IT_BITCOIN: return 5; case IT_ETHEREUM: return 6; case IT_MONERO: return 7;
+    }
+    return 8;
+}
+
+bool valid_utf8_host(const uint8_t* s, size_t n) {
+    size_t i = 0;
+    while (i < n) {
+        uint8_t c = s[i];
+        if (c < 0x80) { ++i; continue; }
+        size_t l = (c >= 0xC2 && c <= 0xDF) ? 2 : (c >= 0xE0 && c <= 0xEF) ? 3 : (c >= 0xF0 && c <= 0xF4) ? 4 : 0;
+        if (l == 0 || i + l > n) return false;
+        uint8_t lo = 0x80, hi = 0xBF;
+        if (c == 0xE0) lo = 0xA0;
+        if (c == 0xED) hi = 0x9F;
+        if (c == 0xF0) lo = 0x90;
+        if (c == 0xF4) hi = 0x8F;
+        if (s[i + 1] < lo || s[i + 1] > hi) return false;
+        for (size_t k = 2; k < l; ++k) if ((s[i + k] & 0xC0) != 0x80) return false;
+        i += l;
+    }
+    return true;
+}
+
+const char* item_type_name(uint8_t t) {
+    static const char* N[] = {"Domain", "Email", "IPv4", "IPv6", "MD5", "SHA1", "SHA256", "SHA384", "SHA512", "Bitcoin", "Ethereum", "Monero"};
+    return t < 12 ? N[t] : "Unknown";
+}
+
+bool read_file(const char* path, std::vector<uint8_t>& out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    uint8_t tmp[1 << 16];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) out.insert(out.end(), tmp, tmp + n);
+    fclose(f);
+    return true;
+}
+
+matchy_t* open_bytes(std::vector<uint8_t>&& bytes) {
+    try {
+        auto db = std::make_unique<Db>();
+        db->img = std::make_shared<DbImage>();
+        std::string err;
+        if (!db->img->open(std::move(bytes), err)) { set_error(err); return nullptr; }
+        db->format = db->img->format_name();
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+            set_error("matchy_amd: no HIP device available (this build has no CPU lookup path)");
+            return nullptr;
+        }
+        db->device_db(0);  // "uploaded once to device memory" at open
+        return reinterpret_cast<matchy_t*>(db.release());
+    } catch (const HipError& e) { set_error(e.what); return nullptr; }
+    catch (const std::exception& e) { set_error(e.what()); return nullptr; }
+}
+
+// Fill matchy_scan_result_t from a ScanOutput. `bases[i]` = absolute offset of the piece hit i came from.
+void fill_result(const DbImage& img, const ScanOutput& so, const std::vector<uint64_t>* bases, uint64_t bytes, matchy_scan_result_t* out) {
+    auto* in = new ScanResultInternal();
+    std::vector<uint32_t> order(so.hits.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+    auto abs_start = [&](uint32_t i) { return (uint64_t)so.hits[i].start + (bases ? (*bases)[i] : 0); };
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        uint64_t sa = abs_start(a), sb = abs_start(b);
+        if (sa != sb) return sa < sb;
+        int ra = type_rank(so.hits[a].len_type >> 24), rb = type_rank(so.hits[b].len_type >> 24);
+        if (ra != rb) return ra < rb;
+        return (so.hits[a].len_type & 0xFFFFFF) < (so.hits[b].len_type & 0xFFFFFF);
+    });
+    for (uint32_t oi : order) {
+        const Hit& h = so.hits[oi];
+        matchy_scan_hit_t m{};
+        m.start = abs_start(oi);
+        m.end = m.start + (h.len_type & 0xFFFFFF);
+        m.item_type = (uint8_t)(h.len_type >> 24);
+        m.kind = h.kind;
+        m.prefix_len = h.prefix_len;
+        if (h.kind == 2) {
+            m.data_offset = h.a;
+        } else {
+            // Database::lookup_string_uncached (database.rs:911-981): literal id (only if it has a data offset), then globs
+            m.ids_index = (uint32_t)in->ids.size();
+            if (h.a != 0xFFFFFFFFu) {
+                uint32_t off;
+                if (img.lit_data_offset(h.a, off)) { in->ids.push_back(h.a); in->offs.push_back(off); }
+            }
+            for (uint32_t k = 0; k < h.n_globs; ++k) {
+                uint32_t pid = so.ids[h.ids_off + k], off;
+                in->ids.push_back(pid);
+                in->offs.push_back(img.glob_data_offset(pid, off) ? (int64_t)off : -1);
+            }
+            m.n_ids = (uint32_t)in->ids.size() - m.ids_index;
+            if (m.n_ids == 0) continue;  // literal without mapping and no glob: NotFound in the reference
+        }
+        in->hits.push_back(m);
+    }
+    out->hits = in->hits.data(); out->n_hits = in->hits.size();
+    out->pattern_ids = in->ids.data(); out->data_offsets = in->offs.data(); out->n_ids = in->ids.size();
+    out->lines = so.lines; out->candidates = so.n_cand; out->bytes = bytes;
+    out->_internal = in;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* matchy_amd_last_error(void) { return g_last_error.c_str(); }
+const char* matchy_version(void) { return "matchy-amd 0.1.0 (reference matchy 1.2.2 surface)"; }
+
+// ------------------------------------------------------------------------------------------------ builder
+matchy_builder_t* matchy_builder_new(void) { return reinterpret_cast<matchy_builder_t*>(new Builder()); }
+void matchy_builder_free(matchy_builder_t* b) { delete reinterpret_cast<Builder*>(b); }
+int32_t matchy_builder_set_case_insensitive(matchy_builder_t* b, bool ci) {
+    if (!b) return MATCHY_ERROR_INVALID_PARAM;
+    reinterpret_cast<Builder*>(b)->b.set_case_insensitive(ci);
+    return MATCHY_SUCCESS;
+}
+int32_t matchy_builder_set_build_epoch(matchy_builder_t* b, uint64_t epoch) {
+    if (!b) return MATCHY_ERROR_INVALID_PARAM;
+    reinterpret_cast<Builder*>(b)->b.set_build_epoch(epoch);
+    return MATCHY_SUCCESS;
+}
+int32_t matchy_builder_add(matchy_builder_t* b, const char* key, const char* json_data) {
+    if (!b || !key || !json_data) return MATCHY_ERROR_INVALID_PARAM;
+    DataValue v;
+    std::string err;
+    if (!parse_json(json_data, strlen(json_data), NumberTyping::SERDE, v, err)) { set_error(err); return MATCHY_ERROR_INVALID_FORMAT; }
+    if (v.type != DataValue::MAP) {  // single value: wrapped as {"value": v} (c_api/matchy.rs:427-435)
+        DataValue m = DataValue::Map();
+        m.map["value"] = std::move(v);
+        v = std::move(m);
+    }
+    Builder* bb = reinterpret_cast<Builder*>(b);
+    if (!bb->b.add_entry(key, v)) { set_error(bb->b.error()); return MATCHY_ERROR_INVALID_FORMAT; }
+    return MATCHY_SUCCESS;
+}
+int32_t matchy_builder_set_description(matchy_builder_t* b, const char* description) {
+    if (!b || !description) return MATCHY_ERROR_INVALID_PARAM;
+    reinterpret_cast<Builder*>(b)->b.set_description("en", description);
+    return MATCHY_SUCCESS;
+}
+int32_t matchy_builder_build(matchy_builder_t* b, uint8_t** buffer, uintptr_t* size) {
+    if (!b || !buffer || !size) return MATCHY_ERROR_INVALID_PARAM;
+    Builder* bb = reinterpret_cast<Builder*>(b);
+    std::vector<uint8_t> out;
+    if (!bb->b.build(out)) { set_error(bb->b.error()); return MATCHY_ERROR_INVALID_FORMAT; }
+    uint8_t* p = (uint8_t*)malloc(out.size() ? out.size() : 1);
+    if (!p) return MATCHY_ERROR_OUT_OF_MEMORY;
+    memcpy(p, out.data(), out.size());
+    *buffer = p;
+    *size = out.size();
+    return MATCHY_SUCCESS;
+}
+int32_t matchy_builder_save(matchy_builder_t* b, const char* filename) {
+    if (!b || !filename) return MATCHY_ERROR_INVALID_PARAM;
+    Builder* bb = reinterpret_cast<Builder*>(b);
+    std::vector<uint8_t> out;
+    if (!bb->b.build(out)) { set_error(bb->b.error()); return MATCHY_ERROR_INVALID_FORMAT; }
+    FILE* f = fopen(filename, "wb");
+    if (!f) return MATCHY_ERROR_IO;
+    bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    ok = fclose(f) == 0 && ok;
+    return ok ? MATCHY_SUCCESS : MATCHY_ERROR_IO;
+}
+
+// ------------------------------------------------------------------------------------------------ open / close
+void matchy_init_open_options(matchy_open_options_t* o) {
+    if (!o) return;
+    o->cache_capacity = 10000; o->auto_reload = false; o->reload_callback = nullptr; o->reload_callback_user_data = nullptr;
+}
+matchy_t* matchy_open(const char* filename) {
+    if (!filename) return nullptr;
+    std::vector<uint8_t> bytes;
+    if (!read_file(filename, bytes)) { set_error(std::string("Failed to open ") + filename); return nullptr; }
+    return open_bytes(std::move(bytes));
+}
+matchy_t* matchy_open_with_options(const char* filename, const matchy_open_options_t* options) {
+    if (!filename || !options) return nullptr;
+    return matchy_open(filename);
+}
+matchy_t* matchy_open_buffer(const uint8_t* buffer, uintptr_t size) {
+    if (!buffer || size == 0) return nullptr;
+    return open_bytes(std::vector<uint8_t>(buffer, buffer + size));
+}
+void matchy_close(matchy_t* db) { delete reinterpret_cast<Db*>(db); }
+
+const char* matchy_format(const matchy_t* db) { return db ? reinterpret_cast<const Db*>(db)->format.c_str() : nullptr; }
+bool matchy_has_ip_data(const matchy_t* db) { return db && reinterpret_cast<const Db*>(db)->img->has_ip; }
+bool matchy_has_literal_data(const matchy_t* db) { return db && reinterpret_cast<const Db*>(db)->img->has_literal; }
+bool matchy_has_glob_data(const matchy_t* db) { return db && reinterpret_cast<const Db*>(db)->img->has_glob; }
+bool matchy_has_string_data(const matchy_t* db) { return matchy_has_literal_data(db) || matchy_has_glob_data(db); }
+uintptr_t matchy_pattern_count(const matchy_t* db) { return db ? reinterpret_cast<const Db*>(db)->img->pattern_count : 0; }
+char* matchy_metadata(const matchy_t* db) {
+    if (!db) return nullptr;
+    std::string s;
+    to_json(reinterpret_cast<const Db*>(db)->img->metadata, s);
+    return strdup(s.c_str());
+}
+char* matchy_get_pattern_string(const matchy_t* db, uint32_t id) {
+    if (!db) return nullptr;
+    const DbImage& img = *reinterpret_cast<const Db*>(db)->img;
+    if (!img.has_glob || id >= img.pattern_count) return nullptr;
+    return strdup(img.pattern_string(id).c_str());
+}
+void matchy_free_string(char* s) { free(s); }
+
+// ------------------------------------------------------------------------------------------------ single query
+void matchy_query_into(const matchy_t* dbc, const char* query, matchy_result_t* result) {
+    if (!result) return;
+    *result = matchy_result_t{false, 0, nullptr, nullptr};
+    if (!dbc || !query) return;
+    Db* db = const_cast<Db*>(reinterpret_cast<const Db*>(dbc));
+    size_t qn = strlen(query);
+    if (!valid_utf8_host((const uint8_t*)query, qn)) return;  // CStr::to_str failure -> found=false
+    try {
+        std::lock_guard<std::mutex> lk(db->mu);
+        if (!db->query_scanner) db->query_scanner = std::make_unique<Scanner>(db->img, db->device_db(0), EX_ALL, 2);
+        // Database::lookup (database.rs:725-804): try IpAddr first, otherwise the string path
+        IpAddr ip;
+        std::string text(query, qn);
+        Candidate c{0, 0, 0, 0};
+        if (parse_ip(query, qn, ip)) {
+            if (!ip.v6) { c.v4 = ((uint32_t)ip.b[0] << 24) | ((uint32_t)ip.b[1] << 16) | ((uint32_t)ip.b[2] << 8) | ip.b[3]; c.len_type = (uint32_t)qn | ((uint32_t)IT_IPV4 << 24); }
+            else {
+                char buf[64];
+                snprintf(buf, sizeof(buf), "%x:%x:%x:%x:%x:%x:%x:%x", (ip.b[0] << 8) | ip.b[1], (ip.b[2] << 8) | ip.b[3], (ip.b[4] << 8) | ip.b[5],
+                         (ip.b[6] << 8) | ip.b[7], (ip.b[8] << 8) | ip.b[9], (ip.b[10] << 8) | ip.b[11], (ip.b[12] << 8) | ip.b[13], (ip.b[14] << 8) | ip.b[15]);
+                text = buf;
+                c.len_type = (uint32_t)text.size() | ((uint32_t)IT_IPV6 << 24);
+            }
+        } else {
+            if (qn >= (1u << 24)) return;
+            c.len_type = (uint32_t)qn | ((uint32_t)IT_DOMAIN << 24);
+        }
+        ScanOutput so;
+        db->query_scanner->lookup_one(text, c, so);
+        if (so.hits.empty()) return;
+        const Hit& h = so.hits[0];
+        DataValue* dv = new DataValue();
+        bool ok = false;
+        if (h.kind == 2) { ok = db->img->decode_data(h.a, *dv); result->prefix_len = h.prefix_len; }
+        else {
+            // first pattern's data only (c_api/matchy.rs:1143-1154)
+            uint32_t off;
+            bool have = false;
+            if (h.a != 0xFFFFFFFFu && db->img->lit_data_offset(h.a, off)) have = true;
+            else if ((h.a == 0xFFFFFFFFu || !db->img->lit_data_offset(h.a, off)) && h.n_globs > 0) have = db->img->glob_data_offset(so.ids[h.ids_off], off);
+            ok = have && db->img->decode_data(off, *dv);
+        }
+        if (!ok) { delete dv; result->prefix_len = 0; return; }
+        result->found = true;
+        result->_data_cache = dv;
+        result->_db_ref = dbc;
+    } catch (const HipError& e) { set_error(e.what); }
+    catch (const std::exception& e) { set_error(e.what()); }
+}
+matchy_result_t matchy_query(const matchy_t* db, const char* query) {
+    matchy_result_t r;
+    matchy_query_into(db, query, &r);
+    return r;
+}
+void matchy_free_result(matchy_result_t* r) {
+    if (!r) return;
+    delete reinterpret_cast<DataValue*>(r->_data_cache);
+    r->_data_cache = nullptr;
+}
+char* matchy_result_to_json(const matchy_result_t* r) {
+    if (!r || !r->found || !r->_data_cache) return nullptr;
+    std::string s;
+    to_json(*reinterpret_cast<const DataValue*>(r->_data_cache), s);
+    return strdup(s.c_str());
+}
+
+// ------------------------------------------------------------------------------------------------ extractor
+matchy_extractor_t* matchy_extractor_create(uint32_t flags) {
+    try {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("matchy_amd: no HIP device available"); return nullptr; }
+        auto e = std::make_unique<ExtractorH>();
+        e->flags = flags;
+        e->img = std::make_shared<DbImage>();  // no sections: has_ip/has_literal/has_glob all false
+        e->img->node_count = 0;
+        e->ddb = std::make_shared<DeviceDb>();
+        e->ddb->upload(*e->img, 0);
+        e->scanner = std::make_unique<Scanner>(e->img, e->ddb, flags, 2);
+        return reinterpret_cast<matchy_extractor_t*>(e.release());
+    } catch (const HipError& e) { set_error(e.what); return nullptr; }
+    catch (const std::exception& e) { set_error(e.what()); return nullptr; }
+}
+void matchy_extractor_free(matchy_extractor_t* e) { delete reinterpret_cast<ExtractorH*>(e); }
+const char* matchy_item_type_name(uint8_t t) { return item_type_name(t); }
+
+int32_t matchy_extractor_extract_chunk(const matchy_extractor_t* ec, const uint8_t* data, uintptr_t len, matchy_matches_t* out) {
+    if (!ec || !out || (!data && len)) return MATCHY_ERROR_INVALID_PARAM;
+    ExtractorH* e = const_cast<ExtractorH*>(reinterpret_cast<const ExtractorH*>(ec));
+    try {
+        std::lock_guard<std::mutex> lk(e->mu);
+        ScanOutput so;
+        std::vector<uint64_t> bases;
+        e->scanner->scan_host(data, len, false, true, so, &bases);
+        size_t nc = so.cands.size();
+        std::vector<uint32_t> order(nc);
+        for (uint32_t i = 0; i < nc; ++i) order[i] = i;
+        auto abs_start = [&](uint32_t i) { return (uint64_t)so.cands[i].start + bases[so.hits.size() + i]; };
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            int ra = type_rank(so.cands[a].len_type >> 24), rb = type_rank(so.cands[b].len_type >> 24);
+            if (ra != rb) return ra < rb;
+            uint64_t sa = abs_start(a), sb = abs_start(b);
+            if (sa != sb) return sa < sb;
+            return (so.cands[a].len_type >> 24) < (so.cands[b].len_type >> 24);
+        });
+        auto* in = new MatchesInternal();
+        in->values.reserve(nc);
+        in->items.reserve(nc);
+        for (uint32_t oi : order) {
+            const Candidate& c = so.cands[oi];
+            uint64_t s = abs_start(oi), n = c.len_type & 0xFFFFFF;
+            uint8_t ty = (uint8_t)(c.len_type >> 24);
+            std::string val;
+            if (ty == IT_IPV4) {  // as_value(): canonical Display (matchy-extractor/src/lib.rs:300-311)
+                uint8_t b[4] = {(uint8_t)(c.v4 >> 24), (uint8_t)(c.v4 >> 16), (uint8_t)(c.v4 >> 8), (uint8_t)c.v4};
+                val = format_ipv4(b);
+            } else if (ty == IT_IPV6) {
+                uint8_t b[16];
+                if (parse_ipv6((const char*)data + s, n, b)) val = format_ipv6(b);
+            } else val.assign((const char*)data + s, n);
+            in->values.push_back(std::move(val));
+            in->items.push_back(matchy_match_t{ty, nullptr, (uintptr_t)s, (uintptr_t)(s + n)});
+        }
+        for (size_t i = 0; i < in->items.size(); ++i) in->items[i].value = in->values[i].c_str();
+        out->items = in->items.data(); out->count = in->items.size(); out->_internal = in;
+        return MATCHY_SUCCESS;
+    } catch (const HipError& ex) { set_error(ex.what); return MATCHY_ERROR_IO; }
+    catch (const std::exception& ex) { set_error(ex.what()); return MATCHY_ERROR_IO; }
+}
+void matchy_matches_free(matchy_matches_t* m) {
+    if (!m) return;
+    delete reinterpret_cast<MatchesInternal*>(m->_internal);
+    m->items = nullptr; m->count = 0; m->_internal = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ bulk scan
+matchy_scanner_t* matchy_scanner_create(const matchy_t* dbc, uint32_t extract_flags, int32_t device) {
+    if (!dbc || device < 0) return nullptr;
+    Db* db = const_cast<Db*>(reinterpret_cast<const Db*>(dbc));
+    try {
+        if (extract_flags == 0) {  // match_cmd.rs:276-303
+            if (db->img->has_ip) extract_flags |= EX_IPV4 | EX_IPV6;
+            if (db->img->has_literal || db->img->has_glob) extract_flags |= EX_DOMAINS | EX_EMAILS | EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO;
+        }
+        std::shared_ptr<DeviceDb> ddb;
+        { std::lock_guard<std::mutex> lk(db->mu); ddb = db->device_db(device); }
+        auto s = std::make_unique<ScannerH>();
+        s->db = db;
+        s->sc = std::make_unique<Scanner>(db->img, ddb, extract_flags, 2);
+        return reinterpret_cast<matchy_scanner_t*>(s.release());
+    } catch (const HipError& e) { set_error(e.what); return nullptr; }
+    catch (const std::exception& e) { set_error(e.what()); return nullptr; }
+}
+void matchy_scanner_free(matchy_scanner_t* s) { delete reinterpret_cast<ScannerH*>(s); }
+void matchy_scanner_set_profile(matchy_scanner_t* s, bool on) { if (s) reinterpret_cast<ScannerH*>(s)->sc->set_profile(on); }
+void matchy_scanner_get_timing(const matchy_scanner_t* s, float out[4]) {
+    if (!s || !out) return;
+    const ScanTiming& t = reinterpret_cast<const ScannerH*>(s)->sc->timing();
+    out[0] = t.tokenize_ms; out[1] = t.rare_ms; out[2] = t.lookup_ms; out[3] = t.total_ms;
+}
+
+int32_t matchy_scanner_scan(matchy_scanner_t* s, const uint8_t* data, size_t len, matchy_scan_result_t* out) {
+    if (!s || !out || (!data && len)) return MATCHY_ERROR_INVALID_PARAM;
+    ScannerH* h = reinterpret_cast<ScannerH*>(s);
+    try {
+        ScanOutput so;
+        std::vector<uint64_t> bases;
+        h->sc->scan_host(data, len, true, false, so, &bases);
+        bases.resize(so.hits.size());
+        fill_result(h->sc->image(), so, &bases, len, out);
+        return MATCHY_SUCCESS;
+    } catch (const HipError& e) { set_error(e.what); return MATCHY_ERROR_IO; }
+    catch (const std::exception& e) { set_error(e.what()); return MATCHY_ERROR_IO; }
+}
+
+int32_t matchy_scanner_scan_device(matchy_scanner_t* s, const void* dptr, size_t len, void* stream, bool fetch_hits, matchy_scan_result_t* out) {
+    if (!s || !out || !dptr) return MATCHY_ERROR_INVALID_PARAM;
+    if (len >= 0x7FFF0000ull) return MATCHY_ERROR_INVALID_PARAM;
+    ScannerH* h = reinterpret_cast<ScannerH*>(s);
+    try {
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st);
+        ScanOutput so;
+        h->sc->fetch(so, false, st, fetch_hits);
+        fill_result(h->sc->image(), so, nullptr, len, out);
+        if (!fetch_hits) out->n_hits = so.n_hits;  // count only; `hits` stays empty
+        return MATCHY_SUCCESS;
+    } catch (const HipError& e) { set_error(e.what); return MATCHY_ERROR_IO; }
+    catch (const std::exception& e) { set_error(e.what()); return MATCHY_ERROR_IO; }
+}
+
+void matchy_scan_result_free(matchy_scan_result_t* r) {
+    if (!r) return;
+    delete reinterpret_cast<ScanResultInternal*>(r->_internal);
+    memset(r, 0, sizeof(*r));
+}
+
+char* matchy_scan_hit_to_json(const matchy_scanner_t* s, const matchy_scan_result_t* r, size_t i, const uint8_t* text, const char* source) {
+    if (!s || !r || !text || i >= r->n_hits || !r->hits) return nullptr;
+    const DbImage& img = reinterpret_cast<const ScannerH*>(s)->sc->image();
+    const matchy_scan_hit_t& h = r->hits[i];
+    std::string matched((const char*)text + h.start, h.end - h.start), o = "{";
+    if (h.kind == 2) {
+        IpAddr ip;
+        std::string cidr;
+        // format_cidr_into parses matched_text again (cli_utils.rs:113); it always parses for extracted IPs
+        if (parse_ip(matched.data(), matched.size(), ip)) cidr = format_cidr(ip, h.prefix_len);
+        else cidr = matched + "/" + std::to_string((unsigned)h.prefix_len);
+        o += "\"cidr\":"; json_escape(cidr, o);
+        o += ",\"data\":";
+        DataValue dv;
+        if (img.decode_data(h.data_offset, dv)) to_json(dv, o); else o += "null";
+        o += ",\"match_type\":\"ip\",\"matched_text\":"; json_escape(matched, o);
+        o += ",\"prefix_len\":" + std::to_string((unsigned)h.prefix_len);
+    } else {
+        std::string arr;
+        bool any = false;
+        for (uint32_t k = 0; k < h.n_ids; ++k) {
+            int64_t off = r->data_offsets[h.ids_index + k];
+            if (off < 0) continue;
+            if (any) arr.push_back(',');
+            DataValue dv;
+            if (img.decode_data((uint32_t)off, dv)) to_json(dv, arr); else arr += "null";
+            any = true;
+        }
+        if (any) o += "\"data\":[" + arr + "],";
+        o += "\"match_type\":\"pattern\",\"matched_text\":"; json_escape(matched, o);
+        o += ",\"pattern_count\":" + std::to_string(h.n_ids);
+    }
+    o += ",\"source\":"; json_escape(source ? source : "-", o);
+    o += ",\"timestamp\":\"0.000\"}";
+    return strdup(o.c_str());
+}
+
+}  // extern "C"

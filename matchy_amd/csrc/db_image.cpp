@@ -1,0 +1,219 @@
+#include "db_image.h"
+
+#include <cstring>
+
+namespace mxy {
+
+namespace {
+inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+long find_metadata_marker(const uint8_t* d, size_t n) {  // mmdb/format.rs:126-150: last occurrence in the final 128 KiB
+    static const uint8_t M[14] = {0xAB, 0xCD, 0xEF, 'M', 'a', 'x', 'M', 'i', 'n', 'd', '.', 'c', 'o', 'm'};
+    if (n < 14) return -1;
+    size_t start = n > 128 * 1024 ? n - 128 * 1024 : 0;
+    long last = -1;
+    for (size_t i = start; i + 14 <= n; ++i)
+        if (memcmp(d + i, M, 14) == 0) last = (long)i;
+    return last;
+}
+bool meta_uint(const DataValue& m, const char* key, uint64_t& out) {
+    auto it = m.map.find(key);
+    if (it == m.map.end()) return false;
+    const DataValue& v = it->second;
+    if (v.type != DataValue::UINT16 && v.type != DataValue::UINT32 && v.type != DataValue::UINT64) return false;
+    out = v.u;
+    return true;
+}
+}  // namespace
+
+bool DbImage::open(std::vector<uint8_t>&& data, std::string& err) {
+    bytes = std::move(data);
+    const uint8_t* d = bytes.data();
+    size_t n = bytes.size();
+    if (n >= 8 && memcmp(d, "PARAGLOB", 8) == 0) { err = "pattern-only (.pgb) databases are not supported"; return false; }
+    long marker = find_metadata_marker(d, n);
+    if (marker < 0) { err = "Unknown database format (no MMDB or PARAGLOB marker)"; return false; }
+    if (!decode_value(d + marker + 14, n - marker - 14, 0, metadata) || metadata.type != DataValue::MAP) { err = "Failed to decode metadata"; return false; }
+    uint64_t nc, rs, ipv;
+    if (!meta_uint(metadata, "node_count", nc) || !meta_uint(metadata, "record_size", rs) || !meta_uint(metadata, "ip_version", ipv)) {
+        err = "Required metadata field missing"; return false;
+    }
+    if (rs != 24 && rs != 28 && rs != 32) { err = "Invalid record size"; return false; }
+    if (ipv != 4 && ipv != 6) { err = "Invalid IP version"; return false; }
+    node_count = (uint32_t)nc; record_size = (int)rs; ip_version = (int)ipv;
+    tree_size = (size_t)node_count * (size_t)(record_size * 2 / 8);
+    if (node_count == 0 || tree_size + 16 > n) { err = "Search tree extends beyond file"; return false; }
+    has_ip = true;
+    auto mm = metadata.map.find("match_mode");
+    if (mm != metadata.map.end() && mm->second.type == DataValue::UINT16) match_mode = mm->second.u == 1 ? 1 : 0;
+    if (match_mode == 1) { err = "case-insensitive databases are not supported yet"; return false; }
+
+    auto po = metadata.map.find("pattern_section_offset");
+    auto lo = metadata.map.find("literal_section_offset");
+    if (po == metadata.map.end() || po->second.type != DataValue::UINT32 || lo == metadata.map.end() || lo->second.type != DataValue::UINT32) {
+        err = "legacy databases without section-offset metadata are not supported"; return false;
+    }
+    size_t pat_off = (size_t)po->second.u, lit_off = (size_t)lo->second.u;
+
+    if (pat_off) {
+        if (pat_off + 8 > n) { err = "Pattern section header truncated"; return false; }
+        size_t pg_size = rd32(d + pat_off + 4);
+        pg_off = pat_off + 8;
+        pg_len = pg_size;
+        if (pg_off + pg_len > n || pg_len < 112) { err = "Paraglob section extends beyond file"; return false; }
+        const uint8_t* pg = d + pg_off;
+        if (memcmp(pg, "PARAGLOB", 8) != 0 || rd32(pg + 8) != 5) { err = "Unsupported paraglob header/version"; return false; }
+        if (rd32(pg + 12) != 0) { err = "case-insensitive paraglob sections are not supported yet"; return false; }
+        pattern_count = rd32(pg + 32);
+        uint32_t ac_start = rd32(pg + 20), ac_size = rd32(pg + 24), patterns_off = rd32(pg + 36), gso = rd32(pg + 104);
+        if ((size_t)ac_start + ac_size > pg_len || (ac_start & 3)) { err = "AC section out of bounds"; return false; }
+        if ((size_t)patterns_off + (size_t)pattern_count * 16 > pg_len) { err = "Pattern entries out of bounds"; return false; }
+        if ((size_t)gso + (size_t)pattern_count * 8 > pg_len) { err = "Glob segment index out of bounds"; return false; }
+        size_t ms = pg_off + pg_len;
+        if (ms + 4 > n) { err = "Pattern mappings section truncated"; return false; }
+        pdm_count = rd32(d + ms);
+        pdm_off = ms + 4;
+        if (pdm_off + pdm_count * 4 > n) { err = "Pattern mappings section out of bounds"; return false; }
+        has_glob = true;
+    }
+    if (lit_off) {
+        if (lit_off + 32 > n) { err = "Literal section truncated"; return false; }
+        lh_off = lit_off;
+        lh_len = n - lit_off;
+        const uint8_t* lh = d + lh_off;
+        if (memcmp(lh, "LHSH", 4) != 0 || rd32(lh + 4) != 1) { err = "Invalid literal hash header"; return false; }
+        lh_table_size = rd32(lh + 12); lh_strings_offset = rd32(lh + 16); lh_strings_size = rd32(lh + 20); lh_num_shards = rd32(lh + 24);
+        lh_table_start = 32 + ((size_t)lh_num_shards + 1) * 4;
+        if (lh_table_start + (size_t)lh_table_size * 16 > lh_len || (size_t)lh_strings_offset + lh_strings_size + 4 > lh_len) {
+            err = "Literal hash table out of bounds"; return false;
+        }
+        size_t mstart = (size_t)lh_strings_offset + lh_strings_size;
+        uint32_t cnt = rd32(lh + mstart);
+        if (mstart + 4 + (size_t)cnt * 8 > lh_len) { err = "Literal mappings out of bounds"; return false; }
+        bool dense = true;
+        for (uint32_t i = 0; i < cnt; ++i) if (rd32(lh + mstart + 4 + (size_t)i * 8) != i) { dense = false; break; }
+        if (dense) {
+            lit_data_offsets.resize(cnt);
+            for (uint32_t i = 0; i < cnt; ++i) lit_data_offsets[i] = rd32(lh + mstart + 8 + (size_t)i * 8);
+        } else {
+            for (uint32_t i = 0; i < cnt; ++i) lit_data_map.emplace(rd32(lh + mstart + 4 + (size_t)i * 8), rd32(lh + mstart + 8 + (size_t)i * 8));
+        }
+        has_literal = true;
+    }
+    return true;
+}
+
+bool DbImage::lit_data_offset(uint32_t pid, uint32_t& off) const {
+    if (!lit_data_offsets.empty()) { if (pid >= lit_data_offsets.size()) return false; off = lit_data_offsets[pid]; return true; }
+    auto it = lit_data_map.find(pid);
+    if (it == lit_data_map.end()) return false;
+    off = it->second;
+    return true;
+}
+bool DbImage::glob_data_offset(uint32_t pid, uint32_t& off) const {
+    if (pid >= pdm_count) return false;
+    off = rd32(bytes.data() + pdm_off + (size_t)pid * 4);
+    return true;
+}
+std::string DbImage::format_name() const {  // Database::format (database.rs:1072-1078)
+    return (has_glob || has_literal) ? "Combined IP+Pattern database" : "IP database";
+}
+std::string DbImage::pattern_string(uint32_t pid) const {
+    if (!has_glob || pid >= pattern_count) return {};
+    const uint8_t* pg = bytes.data() + pg_off;
+    size_t eo = (size_t)rd32(pg + 36) + (size_t)pid * 16;
+    uint32_t so = rd32(pg + eo + 8), sl = rd32(pg + eo + 12);
+    if ((size_t)so + sl > pg_len) return {};
+    return std::string((const char*)pg + so, sl);
+}
+
+void DbImage::build_ip_nodes(std::vector<uint2>& out, uint32_t& v4_start) const {
+    out.resize(node_count);
+    const uint8_t* t = bytes.data();
+    for (uint32_t i = 0; i < node_count; ++i) {
+        uint32_t l, r;
+        if (record_size == 24) {
+            const uint8_t* b = t + (size_t)i * 6;
+            l = ((uint32_t)b[0] << 16) | ((uint32_t)b[1] << 8) | b[2];
+            r = ((uint32_t)b[3] << 16) | ((uint32_t)b[4] << 8) | b[5];
+        } else if (record_size == 28) {
+            const uint8_t* b = t + (size_t)i * 7;
+            l = ((uint32_t)(b[3] >> 4) << 24) | ((uint32_t)b[0] << 16) | ((uint32_t)b[1] << 8) | b[2];
+            r = ((uint32_t)(b[3] & 0xF) << 24) | ((uint32_t)b[4] << 16) | ((uint32_t)b[5] << 8) | b[6];
+        } else {
+            const uint8_t* b = t + (size_t)i * 8;
+            l = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+            r = ((uint32_t)b[4] << 24) | ((uint32_t)b[5] << 16) | ((uint32_t)b[6] << 8) | b[7];
+        }
+        out[i] = make_uint2(l, r);
+    }
+    // find_ipv4_start_node (tree.rs:258-277): follow 96 left links, stop where the walk leaves the node range
+    v4_start = 0;
+    if (ip_version == 6) {
+        uint32_t node = 0;
+        for (int k = 0; k < 96; ++k) {
+            uint32_t rec = out[node].x;
+            if (rec < node_count) node = rec;
+            else break;
+        }
+        v4_start = node;
+    }
+}
+
+void DbImage::build_lit_table(std::vector<LitSlot>& slots, uint32_t& mask) const {
+    const uint8_t* lh = bytes.data() + lh_off;
+    size_t live = 0;
+    for (uint32_t i = 0; i < lh_table_size; ++i) live += rd32(lh + lh_table_start + (size_t)i * 16 + 8) != 0xFFFFFFFFu;
+    size_t cap = 16;
+    while (cap < live * 2) cap <<= 1;
+    mask = (uint32_t)(cap - 1);
+    slots.assign(cap, LitSlot{0, 0xFFFFFFFFu, 0});
+    for (uint32_t i = 0; i < lh_table_size; ++i) {
+        const uint8_t* e = lh + lh_table_start + (size_t)i * 16;
+        uint32_t so = rd32(e + 8);
+        if (so == 0xFFFFFFFFu) continue;
+        if ((size_t)so + 2 > lh_strings_size) continue;  // unreachable string: the reference's read_string would fail too
+        uint64_t h = rd64(e);
+        uint32_t s = (uint32_t)(h ^ (h >> 32)) & mask;
+        while (slots[s].str_off != 0xFFFFFFFFu) s = (s + 1) & mask;
+        slots[s] = LitSlot{h, so, rd32(e + 12)};
+    }
+}
+
+void DbImage::build_lit2pat(std::vector<uint32_t>& off, std::vector<uint32_t>& ids) const {
+    off.assign(1, 0);
+    ids.clear();
+    if (!has_glob) return;
+    const uint8_t* pg = bytes.data() + pg_off;
+    uint32_t map_off = rd32(pg + 96), map_cnt = rd32(pg + 100);
+    if (map_cnt == 0 || map_off == 0 || (size_t)map_off + 24 > pg_len) return;
+    const uint8_t* a = pg + map_off;
+    size_t alen = pg_len - map_off;
+    if (memcmp(a, "ACLH", 4) != 0) return;
+    uint32_t table_size = rd32(a + 12), pstart = rd32(a + 16);
+    if (24 + (size_t)table_size * 16 > alen) return;
+    // enumerate every slot (no dependence on the slot hash function), then densify by literal id
+    std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> ents;  // lit -> (offset, count)
+    uint32_t max_lit = 0;
+    for (uint32_t s = 0; s < table_size; ++s) {
+        const uint8_t* e = a + 24 + (size_t)s * 16;
+        uint32_t lit = rd32(e);
+        if (lit == 0xFFFFFFFFu) continue;
+        uint32_t po = rd32(e + 4), pc = rd32(e + 8);
+        if ((size_t)pstart + po + (size_t)pc * 4 > alen) continue;
+        ents.push_back({lit, {po, pc}});
+        if (lit + 1 > max_lit) max_lit = lit + 1;
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> by_lit(max_lit, {0, 0});
+    std::vector<bool> seen(max_lit, false);
+    for (auto& en : ents) if (!seen[en.first]) { by_lit[en.first] = en.second; seen[en.first] = true; }
+    off.assign(max_lit + 1, 0);
+    for (uint32_t l = 0; l < max_lit; ++l) {
+        off[l] = (uint32_t)ids.size();
+        for (uint32_t k = 0; k < by_lit[l].second; ++k) ids.push_back(rd32(a + pstart + by_lit[l].first + (size_t)k * 4));
+    }
+    off[max_lit] = (uint32_t)ids.size();
+}
+
+}  // namespace mxy

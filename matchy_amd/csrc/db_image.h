@@ -1,0 +1,56 @@
+// Host view of an opened .mxy image: section discovery with bounds validation at open (instead of the
+// reference's per-access checks), plus the derived tables the device upload needs.
+// Follows Database::from_storage (crates/matchy/src/database.rs:649-713, 1023-1069, 1218-1415).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "data_codec.h"
+#include "scan_types.h"
+
+namespace mxy {
+
+struct DbImage {
+    std::vector<uint8_t> bytes;
+
+    uint32_t node_count = 0;
+    int record_size = 24;
+    int ip_version = 4;
+    size_t tree_size = 0;
+    bool has_ip = false;
+    int match_mode = 0;
+    DataValue metadata;
+
+    // literal hash section (relative to lh)
+    bool has_literal = false;
+    size_t lh_off = 0, lh_len = 0;
+    uint32_t lh_table_size = 0, lh_strings_offset = 0, lh_strings_size = 0, lh_num_shards = 0;
+    size_t lh_table_start = 0;
+    std::vector<uint32_t> lit_data_offsets;               // dense by pattern id when ids are 0..n-1
+    std::unordered_map<uint32_t, uint32_t> lit_data_map;  // general fallback (first mapping wins, lh:560-572)
+
+    // paraglob section
+    bool has_glob = false;
+    size_t pg_off = 0, pg_len = 0;
+    size_t pdm_off = 0, pdm_count = 0;  // PatternDataMappings (database.rs:203-229)
+    uint32_t pattern_count = 0;
+
+    bool open(std::vector<uint8_t>&& data, std::string& err);
+
+    const uint8_t* data_section() const { return bytes.data() + tree_size + 16; }
+    size_t data_section_len() const { return bytes.size() - (tree_size + 16); }
+    bool decode_data(uint32_t offset, DataValue& out) const { return decode_value(data_section(), data_section_len(), offset, out); }
+    bool lit_data_offset(uint32_t pid, uint32_t& off) const;
+    bool glob_data_offset(uint32_t pid, uint32_t& off) const;
+    std::string format_name() const;
+    std::string pattern_string(uint32_t pid) const;
+
+    // derived host-side tables for the device image
+    void build_ip_nodes(std::vector<uint2>& out, uint32_t& v4_start) const;
+    void build_lit_table(std::vector<LitSlot>& slots, uint32_t& mask) const;
+    void build_lit2pat(std::vector<uint32_t>& off, std::vector<uint32_t>& ids) const;
+};
+
+}  // namespace mxy

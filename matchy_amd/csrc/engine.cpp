@@ -1,0 +1,321 @@
+#include "engine.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+#include "hashes.h"
+
+namespace mxy {
+
+// ------------------------------------------------------------------------------------------------ PSL
+namespace {
+
+std::string lib_dir() {
+    Dl_info info;
+    if (dladdr((void*)&lib_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t s = p.rfind('/');
+        if (s != std::string::npos) return p.substr(0, s);
+    }
+    return ".";
+}
+
+bool read_file(const std::string& path, std::vector<uint8_t>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint8_t tmp[65536];
+    size_t n;
+    out.clear();
+    while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) out.insert(out.end(), tmp, tmp + n);
+    fclose(f);
+    return true;
+}
+
+uint32_t tld_hash(const uint8_t* s, size_t n) {  // must match tld_hash_step/tld_hash_bit in scan_kernels.hip
+    uint32_t h = 2166136261u;
+    for (size_t i = 0; i < n; ++i) h = (h ^ s[i]) * 16777619u;
+    return (h ^ (h >> 15)) & (TLD_BLOOM_BITS - 1);
+}
+
+PslHost* load_psl() {
+    std::vector<std::string> candidates;
+    if (const char* env = getenv("MATCHY_AMD_PSL")) candidates.push_back(env);
+    std::string d = lib_dir();
+    candidates.push_back(d + "/../data/psl.bin");
+    candidates.push_back(d + "/data/psl.bin");
+    candidates.push_back(d + "/psl.bin");
+    std::vector<uint8_t> buf;
+    bool ok = false;
+    for (auto& c : candidates) if (read_file(c, buf)) { ok = true; break; }
+    if (!ok) throw std::runtime_error("matchy_amd: cannot find the public-suffix container psl.bin (set MATCHY_AMD_PSL)");
+    if (buf.size() < 16 || memcmp(buf.data(), "PSLB", 4) != 0) throw std::runtime_error("matchy_amd: bad psl.bin header");
+    uint32_t count, bytes;
+    memcpy(&count, &buf[8], 4);
+    memcpy(&bytes, &buf[12], 4);
+    auto* h = new PslHost();
+    std::string prev;
+    size_t p = 16;
+    for (uint32_t i = 0; i < count; ++i) {
+        if (p + 2 > buf.size()) throw std::runtime_error("matchy_amd: truncated psl.bin");
+        uint8_t shared = buf[p], rest = buf[p + 1];
+        p += 2;
+        if (shared > prev.size() || p + rest > buf.size()) throw std::runtime_error("matchy_amd: corrupt psl.bin");
+        std::string s = prev.substr(0, shared) + std::string((const char*)&buf[p], rest);
+        p += rest;
+        h->suffixes.push_back(s);
+        prev.swap(s);
+    }
+    size_t cap = 16;
+    while (cap < h->suffixes.size() * 3) cap <<= 1;
+    h->mask = (uint32_t)(cap - 1);
+    h->slots.assign(cap, PslSlot{0, 0, 0});
+    h->bloom.assign(TLD_BLOOM_WORDS, 0);
+    for (const std::string& s : h->suffixes) {
+        if (s.empty()) continue;
+        uint64_t rh = psl_hash_init();
+        for (size_t k = s.size(); k-- > 0;) rh = psl_hash_step(rh, (uint8_t)s[k]);
+        uint64_t hh = psl_hash_finish(rh);
+        uint32_t slot = (uint32_t)hh & h->mask;
+        while (h->slots[slot].len != 0) slot = (slot + 1) & h->mask;
+        h->slots[slot] = PslSlot{hh, (uint32_t)h->pool.size(), (uint32_t)s.size()};
+        h->pool.insert(h->pool.end(), s.begin(), s.end());
+        size_t dot = s.rfind('.');
+        const uint8_t* last = (const uint8_t*)s.data() + (dot == std::string::npos ? 0 : dot + 1);
+        size_t ll = s.size() - (dot == std::string::npos ? 0 : dot + 1);
+        uint32_t bit = tld_hash(last, ll);
+        h->bloom[bit >> 5] |= 1u << (bit & 31);
+        h->max_tld_len = std::max<uint32_t>(h->max_tld_len, (uint32_t)ll);
+    }
+    return h;
+}
+
+}  // namespace
+
+const PslHost& PslHost::get() {
+    static PslHost* inst = load_psl();
+    return *inst;
+}
+
+// ------------------------------------------------------------------------------------------------ device image
+void DeviceDb::upload(const DbImage& img, int dev) {
+    device = dev;
+    MXY_HIP(hipSetDevice(dev));
+    const PslHost& psl = PslHost::get();
+    std::vector<uint2> nodes;
+    uint32_t v4_start;
+    img.build_ip_nodes(nodes, v4_start);
+    ip_nodes.upload(nodes);
+    view.ip_nodes = ip_nodes.p;
+    view.node_count = img.node_count;
+    view.ip_version = (uint32_t)img.ip_version;
+    view.v4_start_node = v4_start;
+    view.has_ip = img.has_ip;
+    bytes_uploaded = nodes.size() * sizeof(uint2);
+    if (img.has_literal) {
+        std::vector<LitSlot> slots;
+        uint32_t mask;
+        img.build_lit_table(slots, mask);
+        lit_slots.upload(slots);
+        const uint8_t* pool = img.bytes.data() + img.lh_off + img.lh_strings_offset;
+        std::vector<uint8_t> pv(pool, pool + img.lh_strings_size);
+        lit_pool.upload(pv);
+        view.lit_slots = lit_slots.p; view.lit_mask = mask; view.has_literal = 1;
+        view.lit_pool = lit_pool.p; view.lit_pool_size = img.lh_strings_size;
+        bytes_uploaded += slots.size() * sizeof(LitSlot) + pv.size();
+    }
+    if (img.has_glob) {
+        const uint8_t* pgp = img.bytes.data() + img.pg_off;
+        std::vector<uint8_t> pv(pgp, pgp + img.pg_len);
+        pv.resize((pv.size() + 3) & ~(size_t)3, 0);
+        pg.upload(pv);
+        std::vector<uint32_t> off, ids;
+        img.build_lit2pat(off, ids);
+        if (ids.empty()) ids.push_back(0);
+        lit2pat_off.upload(off);
+        lit2pat.upload(ids);
+        uint32_t rd[8];
+        auto r32 = [&](size_t o) { uint32_t v; memcpy(&v, pgp + o, 4); return v; };
+        (void)rd;
+        view.pg = pg.p; view.pg_len = (uint32_t)img.pg_len; view.has_glob = 1;
+        view.ac_start = r32(20); view.ac_size = r32(24);
+        view.patterns_off = r32(36); view.pattern_count = r32(32);
+        uint32_t unaligned = r32(40) + r32(44);
+        view.wild_off = unaligned + (8 - unaligned % 8) % 8;  // recomputed like the reader (pg:1089-1093)
+        view.wild_count = r32(60);
+        view.glob_seg_off = r32(104);
+        view.lit2pat_off = lit2pat_off.p; view.lit2pat = lit2pat.p; view.n_ac_lits = (uint32_t)off.size() - 1;
+        bytes_uploaded += pv.size() + (off.size() + ids.size()) * 4;
+    }
+    psl_slots.upload(psl.slots);
+    psl_pool.upload(psl.pool);
+    bloom.upload(psl.bloom);
+    view.psl_slots = psl_slots.p; view.psl_mask = psl.mask; view.psl_pool = psl_pool.p; view.tld_bloom = bloom.p;
+    view.max_tld_len = psl.max_tld_len;
+    bytes_uploaded += psl.slots.size() * sizeof(PslSlot) + psl.pool.size() + psl.bloom.size() * 4;
+}
+
+// ------------------------------------------------------------------------------------------------ scanner
+Scanner::Scanner(std::shared_ptr<const DbImage> img, std::shared_ptr<DeviceDb> ddb, uint32_t extract_flags, uint32_t min_labels)
+    : img_(std::move(img)), ddb_(std::move(ddb)), flags_(extract_flags), min_labels_(min_labels ? min_labels : 2) {
+    MXY_HIP(hipSetDevice(ddb_->device));
+    hipDeviceProp_t prop;
+    MXY_HIP(hipGetDeviceProperties(&prop, ddb_->device));
+    n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    counters_.alloc(1);
+    for (auto& e : ev_) MXY_HIP(hipEventCreate(&e));
+}
+
+Scanner::~Scanner() {
+    for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+}
+
+void Scanner::ensure_capacity(uint32_t len) {
+    size_t want_c = std::max<size_t>(4096, (size_t)len / 24);
+    size_t want_r = std::max<size_t>(1024, (size_t)len / 256);
+    if (cands_.n < want_c) { cands_.alloc(want_c); hits_.alloc(std::max<size_t>(1024, want_c / 4)); ids_.alloc(std::max<size_t>(1024, want_c / 4)); }
+    if (rare_.n < want_r) rare_.alloc(want_r);
+}
+
+void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream) {
+    if (len >= 0x7FFF0000u) throw HipError{"scan_device: chunk too large (must be < 2^31 bytes)"};
+    if (((uintptr_t)dptr & 15) != 0) throw HipError{"scan_device: device pointer must be 16-byte aligned"};
+    MXY_HIP(hipSetDevice(ddb_->device));
+    ensure_capacity(len);
+    last_ptr_ = dptr; last_len_ = len; last_lookup_ = lookup;
+    MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters), stream));
+    TokParams tp{};
+    tp.log = dptr; tp.len = len; tp.flags = flags_; tp.min_labels = min_labels_;
+    tp.n_segs = (uint32_t)(((uint64_t)len + 1 + SEG_BYTES - 1) / SEG_BYTES);
+    tp.cands = cands_.p; tp.cand_cap = (uint32_t)cands_.n;
+    tp.rare = rare_.p; tp.rare_cap = (uint32_t)rare_.n;
+    tp.counters = counters_.p;
+    int grid_tok = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * 4);
+    if (grid_tok < 1) grid_tok = 1;
+    if (profile_) MXY_HIP(hipEventRecord(ev_[0], stream));
+    launch_tokenize(tp, ddb_->view, grid_tok, stream);
+    if (profile_) MXY_HIP(hipEventRecord(ev_[1], stream));
+    bool rare_possible = (flags_ & (EX_IPV6 | EX_EMAILS | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
+    if (rare_possible) launch_rare(tp, ddb_->view, std::min(n_cu_, 256), stream);
+    if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
+    if (lookup) {
+        LookupParams lp{};
+        lp.log = dptr; lp.len = len; lp.cands = cands_.p; lp.cand_cap = (uint32_t)cands_.n;
+        lp.hits = hits_.p; lp.hit_cap = (uint32_t)hits_.n; lp.ids = ids_.p; lp.ids_cap = (uint32_t)ids_.n;
+        lp.counters = counters_.p;
+        launch_lookup(lp, ddb_->view, n_cu_ * 4, stream);
+    }
+    if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
+}
+
+void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, bool want_hits) {
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
+        MXY_HIP(hipStreamSynchronize(stream));
+        const ScanCounters& c = host_counters_;
+        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_hits > hits_.n || c.n_ids > ids_.n;
+        if (!over) break;
+        if (single_) throw HipError{"lookup_one: work buffers overflow"};
+        // grow and run again: the kernels count past the capacity without writing, so the counts are exact demands
+        if (c.n_cand > cands_.n) cands_.alloc((size_t)c.n_cand + c.n_cand / 4 + 1024);
+        if (c.n_rare > rare_.n) rare_.alloc((size_t)c.n_rare + c.n_rare / 4 + 1024);
+        if (c.n_hits > hits_.n || hits_.n < cands_.n / 4) hits_.alloc(std::max<size_t>((size_t)c.n_hits + c.n_hits / 4 + 1024, cands_.n / 4));
+        if (c.n_ids > ids_.n) ids_.alloc((size_t)c.n_ids + c.n_ids / 4 + 1024);
+        scan_device(last_ptr_, last_len_, last_lookup_, stream);
+        if (attempt == 5) throw HipError{"scan: work buffers still overflow after regrowing"};
+    }
+    const ScanCounters& c = host_counters_;
+    if (c.error & 1) throw HipError{"scan: a candidate matched more than MAX_GLOB_RESULTS glob patterns"};
+    if (c.error & 2) throw HipError{"scan: a glob pattern nests more than MAX_GLOB_STARS '*' segments"};
+    out.lines = c.lines; out.n_cand = c.n_cand; out.n_hits = last_lookup_ ? c.n_hits : 0;
+    if (profile_) {
+        MXY_HIP(hipEventElapsedTime(&timing_.tokenize_ms, ev_[0], ev_[1]));
+        MXY_HIP(hipEventElapsedTime(&timing_.rare_ms, ev_[1], ev_[2]));
+        MXY_HIP(hipEventElapsedTime(&timing_.lookup_ms, ev_[2], ev_[3]));
+        MXY_HIP(hipEventElapsedTime(&timing_.total_ms, ev_[0], ev_[3]));
+    }
+    out.hits.clear(); out.ids.clear(); out.cands.clear();
+    if (last_lookup_ && want_hits && c.n_hits) {
+        out.hits.resize(c.n_hits);
+        MXY_HIP(hipMemcpyAsync(out.hits.data(), hits_.p, (size_t)c.n_hits * sizeof(Hit), hipMemcpyDeviceToHost, stream));
+        if (c.n_ids) {
+            out.ids.resize(c.n_ids);
+            MXY_HIP(hipMemcpyAsync(out.ids.data(), ids_.p, (size_t)c.n_ids * 4, hipMemcpyDeviceToHost, stream));
+        }
+    }
+    if (want_cands && c.n_cand) {
+        out.cands.resize(c.n_cand);
+        MXY_HIP(hipMemcpyAsync(out.cands.data(), cands_.p, (size_t)c.n_cand * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
+    }
+    MXY_HIP(hipStreamSynchronize(stream));
+    for (auto& t : out.by_type) t = 0;
+    if (want_cands) for (const Candidate& cd : out.cands) { uint32_t ty = cd.len_type >> 24; if (ty < IT_COUNT) out.by_type[ty]++; }
+}
+
+void Scanner::lookup_one(const std::string& text, Candidate c, ScanOutput& out) {
+    MXY_HIP(hipSetDevice(ddb_->device));
+    ensure_capacity(4096);
+    if (staging_.n < text.size() + 16) staging_.alloc(text.size() + 4096);
+    if (!text.empty()) MXY_HIP(hipMemcpy(staging_.p, text.data(), text.size(), hipMemcpyHostToDevice));
+    c.start = 0;
+    MXY_HIP(hipMemcpy(cands_.p, &c, sizeof(c), hipMemcpyHostToDevice));
+    ScanCounters z{};
+    z.n_cand = 1;
+    MXY_HIP(hipMemcpy(counters_.p, &z, sizeof(z), hipMemcpyHostToDevice));
+    LookupParams lp{};
+    lp.log = staging_.p; lp.len = (uint32_t)text.size(); lp.cands = cands_.p; lp.cand_cap = (uint32_t)cands_.n;
+    lp.hits = hits_.p; lp.hit_cap = (uint32_t)hits_.n; lp.ids = ids_.p; lp.ids_cap = (uint32_t)ids_.n;
+    lp.counters = counters_.p;
+    launch_lookup(lp, ddb_->view, 1, nullptr);
+    last_lookup_ = true; last_ptr_ = staging_.p; last_len_ = (uint32_t)text.size();
+    bool prof = profile_;
+    profile_ = false;
+    single_ = true;
+    try { fetch(out, false, nullptr); } catch (...) { single_ = false; profile_ = prof; throw; }
+    single_ = false;
+    profile_ = prof;
+}
+
+void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_cands, ScanOutput& out, std::vector<uint64_t>* chunk_bases) {
+    // Cut into < 2^30-byte pieces at newlines (N4 in SURVEY §8a: no candidate class admits '\n').
+    const size_t MAXC = (size_t)1 << 30;
+    out = ScanOutput();
+    size_t pos = 0;
+    std::vector<Hit> all_hits;
+    std::vector<uint32_t> all_ids;
+    std::vector<Candidate> all_cands;
+    if (chunk_bases) chunk_bases->clear();
+    std::vector<uint64_t> hit_base, cand_base;
+    do {
+        size_t n = std::min(MAXC, len - pos);
+        if (pos + n < len) {
+            const void* nl = memrchr(data + pos, '\n', n);
+            if (!nl) throw HipError{"scan_host: a single line exceeds 1 GiB"};
+            n = (const uint8_t*)nl - (data + pos) + 1;
+        }
+        if (staging_.n < n + 16) staging_.alloc(n + 16 + n / 8);
+        if (n) MXY_HIP(hipMemcpy(staging_.p, data + pos, n, hipMemcpyHostToDevice));
+        scan_device(staging_.p, (uint32_t)n, lookup, nullptr);
+        ScanOutput part;
+        fetch(part, want_cands, nullptr);
+        out.lines += part.lines; out.n_cand += part.n_cand; out.n_hits += part.n_hits;
+        for (int t = 0; t < IT_COUNT; ++t) out.by_type[t] += part.by_type[t];
+        uint32_t id_shift = (uint32_t)all_ids.size(), cand_shift = (uint32_t)all_cands.size();
+        for (Hit h : part.hits) { h.ids_off += id_shift; h.cand += cand_shift; all_hits.push_back(h); hit_base.push_back(pos); }
+        all_ids.insert(all_ids.end(), part.ids.begin(), part.ids.end());
+        for (const Candidate& c : part.cands) { all_cands.push_back(c); cand_base.push_back(pos); }
+        pos += n;
+    } while (pos < len);
+    out.hits.swap(all_hits); out.ids.swap(all_ids); out.cands.swap(all_cands);
+    if (chunk_bases) {
+        // bases for hits first, then for candidates (callers index by position in the respective vector)
+        chunk_bases->assign(hit_base.begin(), hit_base.end());
+        chunk_bases->insert(chunk_bases->end(), cand_base.begin(), cand_base.end());
+    }
+}
+
+}  // namespace mxy

@@ -1,0 +1,120 @@
+// Host pipeline around the HIP kernels: PSL table, device-resident database image, scan sessions.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "db_image.h"
+#include "scan_types.h"
+
+namespace mxy {
+
+// kernel launch wrappers (scan_kernels.hip)
+void launch_tokenize(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
+void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
+void launch_lookup(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream);
+
+struct HipError { std::string what; };
+#define MXY_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) throw ::mxy::HipError{std::string(#expr) + ": " + hipGetErrorString(_e)}; \
+    } while (0)
+
+// Public-suffix set loaded from the PSLB container (tools/gen_psl.py), shared by all handles.
+struct PslHost {
+    std::vector<std::string> suffixes;
+    std::vector<PslSlot> slots;
+    std::vector<uint8_t> pool;
+    std::vector<uint32_t> bloom;
+    uint32_t mask = 0, max_tld_len = 0;
+    static const PslHost& get();  // throws std::runtime_error if the container cannot be found
+};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        free();
+        if (count) MXY_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+    }
+    void upload(const std::vector<T>& v) { alloc(v.size()); if (!v.empty()) MXY_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); }
+    void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    ~DevBuf() { free(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// Device-resident image of one database on one GPU (uploaded once, at first use).
+struct DeviceDb {
+    int device = 0;
+    DevDb view{};
+    DevBuf<uint2> ip_nodes;
+    DevBuf<LitSlot> lit_slots;
+    DevBuf<uint8_t> lit_pool, pg, psl_pool;
+    DevBuf<uint32_t> lit2pat_off, lit2pat, bloom;
+    DevBuf<PslSlot> psl_slots;
+    size_t bytes_uploaded = 0;
+    void upload(const DbImage& img, int dev);
+};
+
+struct ScanTiming { float tokenize_ms = 0, rare_ms = 0, lookup_ms = 0, total_ms = 0; };
+
+struct ScanOutput {
+    std::vector<Candidate> cands;  // filled only when requested
+    std::vector<Hit> hits;
+    std::vector<uint32_t> ids;
+    uint64_t lines = 0;
+    uint32_t n_cand = 0, n_hits = 0;
+    uint64_t by_type[IT_COUNT] = {0};
+};
+
+// A scan session: owns the per-launch work buffers on one device. Not thread-safe; create one per thread/stream.
+class Scanner {
+public:
+    Scanner(std::shared_ptr<const DbImage> img, std::shared_ptr<DeviceDb> ddb, uint32_t extract_flags, uint32_t min_labels);
+    ~Scanner();
+    // Scan `len` bytes already resident in device memory (16-byte aligned). len < 2^31.
+    // lookup=false stops after extraction. Results stay on the device until fetch().
+    void scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream);
+    // Copies counters (and hits / candidates) back. Call after scan_device; synchronises the stream.
+    void fetch(ScanOutput& out, bool want_cands, hipStream_t stream, bool want_hits = true);
+    // One synthetic candidate (single-query API): `text` is uploaded, only the lookup kernel runs.
+    void lookup_one(const std::string& text, Candidate c, ScanOutput& out);
+    // Convenience: host buffer -> internal device buffer -> scan -> fetch (chunks of < 2^31 bytes).
+    void scan_host(const uint8_t* data, size_t len, bool lookup, bool want_cands, ScanOutput& out, std::vector<uint64_t>* chunk_bases);
+    void set_profile(bool on) { profile_ = on; }
+    const ScanTiming& timing() const { return timing_; }
+    uint32_t flags() const { return flags_; }
+    int device() const { return ddb_->device; }
+    const DbImage& image() const { return *img_; }
+
+private:
+    void ensure_capacity(uint32_t len);
+    std::shared_ptr<const DbImage> img_;
+    std::shared_ptr<DeviceDb> ddb_;
+    uint32_t flags_, min_labels_;
+    DevBuf<Candidate> cands_;
+    DevBuf<RareAnchor> rare_;
+    DevBuf<Hit> hits_;
+    DevBuf<uint32_t> ids_;
+    DevBuf<ScanCounters> counters_;
+    DevBuf<uint8_t> staging_;  // scan_host only
+    ScanCounters host_counters_{};
+    uint32_t last_len_ = 0;
+    const uint8_t* last_ptr_ = nullptr;
+    bool last_lookup_ = false;
+    bool single_ = false;
+    bool profile_ = false;
+    hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    ScanTiming timing_;
+    int n_cu_ = 256;
+};
+
+}  // namespace mxy

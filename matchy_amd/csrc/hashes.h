@@ -1,0 +1,72 @@
+// Hash functions shared by host code and HIP kernels.
+//   xxh64        XXH64 (seed 0 in all call sites) — literal-hash keys (crates/matchy-literal-hash/src/lib.rs:666-671)
+//   fx_u32       rustc-hash 2.x FxHasher over one u32 — ACLH slot placement (matchy-paraglob/src/literal_hash.rs:95-99)
+//   psl_hash     our own 64-bit hash for the device PSL table (any good hash works: membership is verified bytewise)
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MXY_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define MXY_HD inline
+#endif
+
+namespace mxy {
+
+MXY_HD uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+// Byte-fetch functor based XXH64 so the same code runs over host pointers and over device "log + offset" views.
+template <class Fetch>
+MXY_HD uint64_t xxh64_fetch(Fetch f, size_t len, uint64_t seed) {
+    const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL,
+                   P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
+    auto rd64 = [&](size_t o) {
+        uint64_t v = 0;
+        for (int k = 7; k >= 0; --k) v = (v << 8) | (uint64_t)f(o + k);
+        return v;
+    };
+    auto rd32 = [&](size_t o) {
+        uint64_t v = 0;
+        for (int k = 3; k >= 0; --k) v = (v << 8) | (uint64_t)f(o + k);
+        return v;
+    };
+    auto round = [&](uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl64(acc, 31); return acc * P1; };
+    auto merge = [&](uint64_t acc, uint64_t val) { val = round(0, val); acc ^= val; return acc * P1 + P4; };
+    size_t p = 0;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        size_t limit = len - 32;
+        do {
+            v1 = round(v1, rd64(p)); v2 = round(v2, rd64(p + 8)); v3 = round(v3, rd64(p + 16)); v4 = round(v4, rd64(p + 24));
+            p += 32;
+        } while (p <= limit);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = merge(h, v1); h = merge(h, v2); h = merge(h, v3); h = merge(h, v4);
+    } else {
+        h = seed + P5;
+    }
+    h += (uint64_t)len;
+    while (p + 8 <= len) { h ^= round(0, rd64(p)); h = rotl64(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= len) { h ^= rd32(p) * P1; h = rotl64(h, 23) * P2 + P3; p += 4; }
+    while (p < len) { h ^= (uint64_t)f(p) * P5; h = rotl64(h, 11) * P1; ++p; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+MXY_HD uint64_t xxh64(const uint8_t* p, size_t len, uint64_t seed) {
+    return xxh64_fetch([p](size_t o) { return p[o]; }, len, seed);
+}
+
+// rustc-hash 2.x (64-bit): hash = (hash + x) * K, finish = rotl(hash, 26). See DESIGN.md (unverified vs crate source).
+MXY_HD uint64_t fx_u32(uint32_t v) { return rotl64((uint64_t)v * 0xf1357aea2e62a9c5ULL, 26); }
+
+// PSL hashing: suffixes are hashed from their LAST byte to their first so that a right-to-left walk over a
+// domain can extend the hash one label at a time.
+MXY_HD uint64_t psl_hash_init() { return 0xcbf29ce484222325ULL; }
+MXY_HD uint64_t psl_hash_step(uint64_t h, uint8_t b) { return (h ^ b) * 0x100000001b3ULL; }
+MXY_HD uint64_t psl_hash_finish(uint64_t h) { h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ULL; h ^= h >> 32; return h; }
+
+}  // namespace mxy

@@ -1,0 +1,995 @@
+// HIP kernels for the `matchy match` hot path on gfx950 (MI355X, wave64).
+//
+//   k_tokenize  stage A: coalesced 16 B/lane log reads -> per-byte class bytes staged in LDS -> per-lane anchor
+//               detection from a 5-byte class history -> anchors compacted into a per-wave LDS ring with
+//               ballot/mbcnt -> 64 anchors validated per round, one per lane (IPv4, domain, hex hashes);
+//               IPv6 / e-mail / crypto-token anchors are forwarded to the rare list.
+//   k_rare      stage A': validators that are rare in logs and heavy in registers (IPv6 text, e-mail, Base58Check,
+//               Bech32, EIP-55, Monero) — one lane per anchor.
+//   k_lookup    stage B: one lane per candidate: MMDB trie walk / XXH64 literal probe / Aho-Corasick walk + glob
+//               verification, hits compacted with one atomic per wave.
+//
+// Semantics follow the reference CPU path; every rule cites the reference function it reproduces
+// (matchy-extractor/src/lib.rs = "ext", matchy-format/src/mmdb/tree.rs = "tree", matchy-literal-hash/src/lib.rs
+// = "lh", matchy-paraglob/src/paraglob_offset.rs = "pg"). The sequential `last_end` / `last_domain_end` state of
+// the reference is replaced by stateless per-run ownership rules, differential-tested
+// against oracle/.
+#include <hip/hip_runtime.h>
+
+#include "hashes.h"
+#include "scan_types.h"
+
+namespace mxy {
+
+// ------------------------------------------------------------------------------------------------ byte classes
+constexpr uint32_t C_B = 1, C_DIG = 2, C_DOT = 4, C_COLON = 8, C_AT = 16, C_LD = 32, C_NL = 64;
+constexpr uint32_t T_V4 = 1, T_DOM = 2, T_V6 = 4, T_AT = 8, T_TOK = 16;
+
+// BOUNDARY_LOOKUP (ext:1568-1593) as a 128-bit bitmap
+constexpr uint64_t bnd_lo() {
+    uint64_t m = 0;
+    const int cs[] = {0x09, 0x0a, 0x0d, 0x20, 0x22, 0x27, 0x28, 0x29, 0x2c, 0x2f, 0x3a, 0x3b, 0x3c, 0x3d, 0x3e};
+    for (int c : cs) m |= 1ull << c;
+    return m;
+}
+constexpr uint64_t bnd_hi() {
+    uint64_t m = 0;
+    const int cs[] = {0x40, 0x5b, 0x5d, 0x7b, 0x7d};
+    for (int c : cs) m |= 1ull << (c - 64);
+    return m;
+}
+__device__ __forceinline__ bool d_is_boundary(uint32_t b) {
+    if (b >= 128) return false;
+    uint64_t m = b < 64 ? bnd_lo() : bnd_hi();
+    return (m >> (b & 63)) & 1;
+}
+__device__ __forceinline__ bool d_is_digit(uint32_t b) { return b - '0' < 10u; }
+__device__ __forceinline__ bool d_is_alpha(uint32_t b) { return (b | 0x20) - 'a' < 26u; }
+__device__ __forceinline__ bool d_is_alnum(uint32_t b) { return d_is_digit(b) || d_is_alpha(b); }
+__device__ __forceinline__ bool d_is_hex(uint32_t b) { return d_is_digit(b) || ((b | 0x20) - 'a' < 6u); }
+__device__ __forceinline__ bool d_is_domain_char_fast(uint32_t b) { return d_is_alnum(b) || b == '-' || b == '.' || b >= 0x80; }  // ext:1597-1629
+__device__ __forceinline__ bool d_is_domain_char(uint32_t b) { return d_is_alnum(b) || b == '-' || b == '.'; }                      // ext:1639
+__device__ __forceinline__ bool d_is_email_local(uint32_t b) { return d_is_alnum(b) || b == '.' || b == '-' || b == '_' || b == '+'; }  // ext:1644
+
+__device__ __forceinline__ uint32_t class_of(uint32_t b) {
+    uint32_t c = 0;
+    if (d_is_boundary(b)) c |= C_B;
+    if (d_is_digit(b)) c |= C_DIG;
+    if (b == '.') c |= C_DOT;
+    if (b == ':') c |= C_COLON;
+    if (b == '@') c |= C_AT;
+    if (d_is_alnum(b) || b >= 0x80) c |= C_LD;
+    if (b == '\n') c |= C_NL;
+    return c;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// Append one record per `emit` lane with a single atomic per wave. Returns the slot (or 0xFFFFFFFF).
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool emit) {
+    uint64_t m = __ballot(emit);
+    if (m == 0) return 0xFFFFFFFFu;
+    uint32_t leader = (uint32_t)__ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return emit ? base + (uint32_t)__popcll(m & lanemask_lt()) : 0xFFFFFFFFu;
+}
+
+struct LogView {
+    const uint8_t* p;
+    uint32_t len;
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return p[i]; }
+    // byte at i, with the end of the buffer acting as a boundary (ext: `end < chunk.len()` checks)
+    __device__ __forceinline__ uint32_t at_or_space(uint32_t i) const { return i < len ? p[i] : (uint32_t)' '; }
+};
+
+// Rust core::str::from_utf8 acceptance
+__device__ bool d_valid_utf8(const uint8_t* s, uint32_t n) {
+    uint32_t i = 0;
+    while (i < n) {
+        uint32_t c = s[i];
+        if (c < 0x80) { ++i; continue; }
+        uint32_t l = (c >= 0xC2 && c <= 0xDF) ? 2 : (c >= 0xE0 && c <= 0xEF) ? 3 : (c >= 0xF0 && c <= 0xF4) ? 4 : 0;
+        if (l == 0 || i + l > n) return false;
+        uint32_t c1 = s[i + 1];
+        uint32_t lo = 0x80, hi = 0xBF;
+        if (c == 0xE0) lo = 0xA0;
+        if (c == 0xED) hi = 0x9F;
+        if (c == 0xF0) lo = 0x90;
+        if (c == 0xF4) hi = 0x8F;
+        if (c1 < lo || c1 > hi) return false;
+        for (uint32_t k = 2; k < l; ++k) if ((s[i + k] & 0xC0) != 0x80) return false;
+        i += l;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ PSL
+__device__ bool psl_contains(const DevDb& db, uint64_t h, const uint8_t* s, uint32_t n) {
+    uint32_t slot = (uint32_t)h & db.psl_mask;
+    for (;;) {
+        PslSlot e = db.psl_slots[slot];
+        if (e.len == 0) return false;
+        if (e.hash == h && e.len == n) {
+            const uint8_t* q = db.psl_pool + e.off;
+            bool eq = true;
+            for (uint32_t k = 0; k < n; ++k) if (q[k] != s[k]) { eq = false; break; }
+            if (eq) return true;
+        }
+        slot = (slot + 1) & db.psl_mask;
+    }
+}
+// find_valid_tld_suffix_bytes(..).is_some() (ext:1671-1692) over log[lo,hi): dots right-to-left, hash grows leftwards.
+__device__ bool psl_suffix_exists(const DevDb& db, const uint8_t* log, uint32_t lo, uint32_t hi) {
+    uint64_t rh = psl_hash_init();
+    for (uint32_t q = hi; q-- > lo;) {
+        uint32_t c = log[q];
+        if (c == '.') {
+            if (psl_contains(db, psl_hash_finish(rh), log + q + 1, hi - q - 1)) return true;
+        }
+        rh = psl_hash_step(rh, (uint8_t)c);
+    }
+    return false;
+}
+__device__ __forceinline__ uint32_t tld_hash_step(uint32_t h, uint32_t c) { return (h ^ c) * 16777619u; }
+__device__ __forceinline__ uint32_t tld_hash_bit(uint32_t h) { return (h ^ (h >> 15)) & (TLD_BLOOM_BITS - 1); }
+
+// ------------------------------------------------------------------------------------------------ stage A validators
+// IPv4 (ext:813-869, 1120-1179). `dot` is the first dot of a maximal [0-9.] run whose first octet has 1-3 digits and
+// is preceded by a boundary or the buffer start (anchor rule). The whole run must parse as a dotted quad and be
+// followed by a boundary or the end of the buffer.
+__device__ bool val_ipv4(const LogView& lg, uint32_t dot, uint32_t& start, uint32_t& end, uint32_t& addr) {
+    uint32_t s = dot;
+    while (s > 0 && dot - s < 3 && d_is_digit(lg.at(s - 1))) --s;
+    if (s == dot) return false;
+    if (s > 0 && !d_is_boundary(lg.at(s - 1))) return false;
+    uint32_t pos = s, a = 0;
+    for (int idx = 0; idx < 4; ++idx) {
+        uint32_t v = 0, digits = 0, first = 0;
+        while (pos < lg.len && digits < 3) {
+            uint32_t c = lg.at(pos);
+            if (!d_is_digit(c)) break;
+            if (digits == 0) first = c;
+            v = v * 10 + (c - '0');
+            ++pos;
+            ++digits;
+        }
+        if (digits == 0 || v > 255) return false;
+        if (digits > 1 && first == '0') return false;
+        a = (a << 8) | v;
+        if (idx < 3) {
+            if (pos >= lg.len || lg.at(pos) != '.') return false;
+            ++pos;
+        }
+    }
+    if (pos < lg.len && !d_is_boundary(lg.at(pos))) return false;
+    start = s; end = pos; addr = a;
+    return true;
+}
+
+// Domain (ext:537-689). `j` is the first byte after a dot (anchor: label-char, '.', label-char). Only the LAST dot
+// of a maximal domain-char run owns the run; it validates the run as a whole.
+__device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* bloom, uint32_t min_labels, uint32_t j,
+                           uint32_t& start, uint32_t& end) {
+    uint32_t p = j, th = 2166136261u;
+    while (p < lg.len) {
+        uint32_t c = lg.at(p);
+        if (!d_is_domain_char_fast(c)) break;
+        if (c == '.') return false;  // a later dot owns this run
+        th = tld_hash_step(th, c);
+        ++p;
+    }
+    uint32_t e = p;
+    if (e - j > db.max_tld_len) return false;
+    uint32_t bit = tld_hash_bit(th);
+    if (!((bloom[bit >> 5] >> (bit & 31)) & 1)) return false;  // last label is no suffix's last label -> no PSL hit possible
+    // walk back to the run start: PSL probes at dots (first hit suffices), label rules of is_valid_domain (ext:637-689)
+    uint64_t rh = psl_hash_init();
+    bool found = false, bad = false, high = false;
+    uint32_t labels = 1, cur = 0, last_c = 0;
+    uint32_t q = e;
+    while (q > 0) {
+        uint32_t c = lg.at(q - 1);
+        if (!d_is_domain_char_fast(c)) break;
+        --q;
+        if (c == '.') {
+            if (cur == 0 || last_c == '-') bad = true;
+            if (!found && !bad) found = psl_contains(db, psl_hash_finish(rh), lg.p + q + 1, e - q - 1);
+            ++labels;
+            cur = 0;
+        } else {
+            if (cur == 0 && c == '-') bad = true;  // label ends with '-'
+            ++cur;
+            high |= c >= 0x80;
+        }
+        rh = psl_hash_step(rh, (uint8_t)c);
+        last_c = c;
+    }
+    uint32_t s = q;
+    if (cur == 0 || last_c == '-') bad = true;  // leftmost label empty / starts with '-'
+    if (bad || !found || labels < min_labels) return false;
+    if (s > 0 && !d_is_boundary(lg.at(s - 1))) return false;
+    if (e < lg.len && !d_is_boundary(lg.at(e))) return false;
+    if (high && !d_valid_utf8(lg.p + s, e - s)) return false;
+    start = s; end = e;
+    return true;
+}
+
+__device__ bool all_hex(const LogView& lg, uint32_t s, uint32_t n) {
+    for (uint32_t k = 0; k < n; ++k) if (!d_is_hex(lg.at(s + k))) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ k_tokenize
+constexpr int TOK_WAVES = 4;
+constexpr uint32_t BLK_BYTES = 1024;        // bytes per wave iteration: one 16-byte load per lane
+constexpr uint32_t CS_PREFIX = 16;          // class bytes kept in front of the block (only the last 4 are used)
+constexpr uint32_t QCAP = 128;              // anchor ring entries per wave
+
+struct WaveCtx {
+    uint32_t* cs32;     // class stage of this wave (dwords)
+    uint2* queue;       // anchor ring of this wave
+    uint32_t q_head, q_tail;
+};
+
+__device__ void drain_round(const TokParams& p, const DevDb& db, const uint32_t* bloom, WaveCtx& w, uint32_t n) {
+    LogView lg{p.log, p.len};
+    uint32_t lane = lane_id();
+    uint2 ent = make_uint2(0, 0);
+    if (lane < n) ent = w.queue[(w.q_head + lane) & (QCAP - 1)];
+    w.q_head += n;
+    uint32_t types = lane < n ? (ent.y & 0xFF) : 0;
+    uint32_t toklen = ent.y >> 8;
+    uint32_t pos = ent.x;
+
+    while (__ballot(types != 0)) {
+        Candidate c{0, 0, 0, 0};
+        RareAnchor ra{0, 0, 0};
+        bool emit = false, emit_rare = false;
+        uint32_t t = types & (0u - types);  // lowest pending type of this lane
+        types &= ~t;
+        if (t == T_V4) {
+            uint32_t s, e, a;
+            if (val_ipv4(lg, pos, s, e, a)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV4 << 24); c.v4 = a; emit = true; }
+        } else if (t == T_DOM) {
+            uint32_t s, e;
+            if (val_domain(lg, db, bloom, p.min_labels, pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true; }
+        } else if (t == T_V6) {
+            ra.pos = pos; ra.kind = RARE_V6; emit_rare = true;
+        } else if (t == T_AT) {
+            ra.pos = pos; ra.kind = RARE_AT; emit_rare = true;
+        } else if (t == T_TOK) {
+            uint32_t s = pos - toklen;
+            // hashes: token length 32/40/64/96/128 and all hex (ext:1212-1250)
+            int ht = toklen == 32 ? IT_MD5 : toklen == 40 ? IT_SHA1 : toklen == 64 ? IT_SHA256 : toklen == 96 ? IT_SHA384 : toklen == 128 ? IT_SHA512 : -1;
+            if (ht >= 0 && (p.flags & EX_HASHES) && all_hex(lg, s, toklen)) { c.start = s; c.len_type = toklen | ((uint32_t)ht << 24); emit = true; }
+            // crypto tokens: cheap prefix filters here, checksums in k_rare (ext:1289-1307, 1331-1350, 1388-1397)
+            uint32_t b0 = lg.at(s), b1 = lg.at(s + 1), b2 = lg.at(s + 2);
+            bool btc = (p.flags & EX_BITCOIN) && toklen >= 26 && toklen <= 62 && ((b0 == 'b' && b1 == 'c' && b2 == '1') || b0 == '1' || b0 == '3');
+            bool eth = (p.flags & EX_ETHEREUM) && toklen == 42 && b0 == '0' && b1 == 'x';
+            bool xmr = (p.flags & EX_MONERO) && toklen >= 90 && toklen <= 110 && (b0 == '4' || b0 == '8');
+            if (btc || eth || xmr) { ra.pos = s; ra.len = toklen; ra.kind = RARE_TOK; emit_rare = true; }
+        }
+        uint32_t slot = wave_append(&p.counters->n_cand, emit);
+        if (emit && slot < p.cand_cap) p.cands[slot] = c;
+        uint32_t rslot = wave_append(&p.counters->n_rare, emit_rare);
+        if (emit_rare && rslot < p.rare_cap) p.rare[rslot] = ra;
+    }
+}
+
+__global__ __launch_bounds__(TOK_WAVES * 64) void k_tokenize(TokParams p, DevDb db) {
+    __shared__ uint8_t ctab[256];
+    __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
+    __shared__ uint32_t cstage[TOK_WAVES][(CS_PREFIX + BLK_BYTES) / 4];
+    __shared__ uint2 queues[TOK_WAVES][QCAP];
+
+    ctab[threadIdx.x] = (uint8_t)class_of(threadIdx.x);
+    for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += blockDim.x) bloom[i] = db.tld_bloom[i];
+    __syncthreads();
+
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t gw = blockIdx.x * TOK_WAVES + wave, nw = gridDim.x * TOK_WAVES;
+    WaveCtx w;
+    w.cs32 = cstage[wave];
+    w.queue = queues[wave];
+    w.q_head = w.q_tail = 0;
+    const uint32_t len = p.len;
+    const bool want_tok = (p.flags & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
+    uint32_t type_mask = 0;
+    if (p.flags & EX_IPV4) type_mask |= T_V4;
+    if (p.flags & EX_DOMAINS) type_mask |= T_DOM;
+    if (p.flags & EX_IPV6) type_mask |= T_V6;
+    if (p.flags & EX_EMAILS) type_mask |= T_AT;
+    if (want_tok) type_mask |= T_TOK;
+    unsigned long long lines = 0;
+    const uint32_t sh8 = (lane & 3) * 8;
+
+    for (uint32_t seg = gw; seg < p.n_segs; seg += nw) {
+        const uint32_t seg_start = seg * SEG_BYTES;
+        // positions 0..len are scanned: position `len` is the virtual boundary that closes a trailing token
+        const uint32_t seg_end = min(seg_start + SEG_BYTES, len + 1);
+        // ---- carry-in: classes of the 4 bytes before the segment, and the last boundary within 256 bytes
+        int32_t lastB;
+        if (seg_start == 0) {
+            lastB = -1;
+            if (lane == 0) w.cs32[CS_PREFIX / 4 - 1] = C_B * 0x01010101u;
+        } else {
+            lastB = (int32_t)seg_start - 257;  // "far": any token reaching back this far is longer than 128
+            for (uint32_t r = 0; r < 4; ++r) {
+                uint32_t base = seg_start - 256 + r * 64;
+                uint32_t c = ctab[p.log[base + lane]];
+                uint64_t bm = __ballot(c & C_B);
+                if (bm) lastB = (int32_t)(base + 63 - __clzll((unsigned long long)bm));
+            }
+            if (lane == 0) {
+                uint32_t pre = 0;
+                for (uint32_t k = 0; k < 4; ++k) pre |= (uint32_t)ctab[p.log[seg_start - 4 + k]] << (8 * k);
+                w.cs32[CS_PREFIX / 4 - 1] = pre;
+            }
+        }
+        for (uint32_t blk = seg_start; blk < seg_end; blk += BLK_BYTES) {
+            // ---- stage 1 KiB: coalesced 16 B per lane, bytes -> class bytes, one ds_write_b128 per lane
+            uint32_t pos0 = blk + lane * 16;
+            uint32_t wv[4];
+            if (pos0 + 16 <= len) {
+                uint4 v = *reinterpret_cast<const uint4*>(p.log + pos0);
+                wv[0] = v.x; wv[1] = v.y; wv[2] = v.z; wv[3] = v.w;
+            } else {
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t x = 0;
+                    for (int b = 0; b < 4; ++b) {
+                        uint32_t q = pos0 + k * 4 + b;
+                        x |= (q < len ? (uint32_t)p.log[q] : (uint32_t)' ') << (8 * b);
+                    }
+                    wv[k] = x;
+                }
+            }
+            uint32_t cv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t x = wv[k];
+                cv[k] = (uint32_t)ctab[x & 0xFF] | ((uint32_t)ctab[(x >> 8) & 0xFF] << 8) | ((uint32_t)ctab[(x >> 16) & 0xFF] << 16) |
+                        ((uint32_t)ctab[x >> 24] << 24);
+            }
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<uint4*>(&w.cs32[CS_PREFIX / 4 + lane * 4]) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+            __builtin_amdgcn_wave_barrier();
+
+            const uint32_t rows = min(16u, (seg_end - blk + 63) / 64);
+            for (uint32_t r = 0; r < rows; ++r) {
+                const uint32_t row_base = blk + r * 64;
+                const uint32_t j = row_base + lane;
+                const uint32_t di = (CS_PREFIX + r * 64 + lane) >> 2;
+                const uint32_t d1 = w.cs32[di], d0 = w.cs32[di - 1];
+                // hist bytes: [0]=class(j-4) [1]=class(j-3) [2]=class(j-2) [3]=class(j-1)
+                const uint32_t hist = __builtin_amdgcn_alignbyte(d1, d0, lane & 3);
+                const uint32_t c0 = (d1 >> sh8) & 0xFF;
+                const bool valid = j <= len;
+
+                lines += (unsigned long long)__popcll(__ballot((c0 & C_NL) && j < len));
+
+                uint32_t types = 0;
+                // T_DOM: label-char at j, '.' at j-1, label-char at j-2
+                if ((c0 & C_LD) && (hist & (C_DOT << 24)) && (hist & (C_LD << 16))) types |= T_DOM;
+                // T_V4: '.' at j preceded by 1-3 digits preceded by a boundary
+                if ((c0 & C_DOT) && (hist & (C_DIG << 24))) {
+                    bool ok = (hist & (C_B << 16)) || ((hist & (C_DIG << 16)) && ((hist & (C_B << 8)) || ((hist & (C_DIG << 8)) && (hist & C_B))));
+                    if (ok) types |= T_V4;
+                }
+                // T_V6: "::" ending at j, not preceded by a third ':'
+                if ((c0 & C_COLON) && (hist & (C_COLON << 24)) && !(hist & (C_COLON << 16))) types |= T_V6;
+                if (c0 & C_AT) types |= T_AT;
+                // T_TOK: boundary at j closing a token [lb+1, j) whose length passes the extractor length filters
+                const uint64_t bmask = __ballot(c0 & C_B);
+                uint32_t toklen = 0;
+                if (want_tok) {
+                    uint64_t m = bmask & lanemask_lt();
+                    int32_t lb = m ? (int32_t)(row_base + 63 - __clzll((unsigned long long)m)) : lastB;
+                    uint32_t tl = (uint32_t)((int32_t)j - 1 - lb);
+                    bool tokend = (c0 & C_B) && !(hist & (C_B << 24));
+                    bool lenok = (tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128;
+                    if (tokend && lenok) { types |= T_TOK; toklen = tl; }
+                }
+                if (bmask) lastB = (int32_t)(row_base + 63 - __clzll((unsigned long long)bmask));
+                types &= type_mask;
+                if (!valid) types = 0;
+
+                // ---- compact anchors into the ring
+                const uint64_t am = __ballot(types != 0);
+                if (am) {
+                    if (types) {
+                        uint32_t slot = (w.q_tail + (uint32_t)__popcll(am & lanemask_lt())) & (QCAP - 1);
+                        w.queue[slot] = make_uint2(j, types | (toklen << 8));
+                    }
+                    w.q_tail += (uint32_t)__popcll(am);
+                    __builtin_amdgcn_wave_barrier();
+                    if (w.q_tail - w.q_head >= 64) drain_round(p, db, bloom, w, 64);
+                }
+            }
+            // keep the last 4 class bytes as the next block's prefix
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) w.cs32[CS_PREFIX / 4 - 1] = w.cs32[(CS_PREFIX + BLK_BYTES) / 4 - 1];
+            __builtin_amdgcn_wave_barrier();
+        }
+        // anchors never wait across segments: the carry state is rebuilt per segment anyway
+        if (w.q_tail != w.q_head) drain_round(p, db, bloom, w, w.q_tail - w.q_head);
+    }
+    // one atomic per wave for the line count
+    if (lane == 0 && lines) atomicAdd(&p.counters->lines, lines);
+}
+
+// ------------------------------------------------------------------------------------------------ rare validators
+// Rust `<Ipv6Addr as FromStr>` restricted to [0-9A-Fa-f:] input (no embedded IPv4 possible): read_ipv6_addr.
+__device__ bool d_parse_ipv6(const uint8_t* s, uint32_t n, uint16_t seg[8]) {
+    uint32_t pos = 0;
+    uint16_t head[8], tail[7];
+    for (int i = 0; i < 8; ++i) head[i] = 0;
+    for (int i = 0; i < 7; ++i) tail[i] = 0;
+    auto read_groups = [&](uint16_t* g, uint32_t limit) -> uint32_t {
+        for (uint32_t i = 0; i < limit; ++i) {
+            uint32_t save = pos;
+            if (i > 0) {
+                if (pos < n && s[pos] == ':') ++pos;
+                else { pos = save; return i; }
+            }
+            uint32_t v = 0, digits = 0, q = pos;
+            bool ok = true;
+            while (q < n && d_is_hex(s[q])) {
+                uint32_t ch = s[q];
+                v = v * 16 + (d_is_digit(ch) ? ch - '0' : (ch | 0x20) - 'a' + 10);
+                ++digits;
+                ++q;
+                if (digits > 4) { ok = false; break; }
+            }
+            if (!ok || digits == 0) { pos = save; return i; }
+            g[i] = (uint16_t)v;
+            pos = q;
+        }
+        return limit;
+    };
+    uint32_t hs = read_groups(head, 8);
+    if (hs == 8) {
+        if (pos != n) return false;
+        for (int i = 0; i < 8; ++i) seg[i] = head[i];
+        return true;
+    }
+    if (!(pos < n && s[pos] == ':')) return false;
+    ++pos;
+    if (!(pos < n && s[pos] == ':')) return false;
+    ++pos;
+    uint32_t limit = 8 - (hs + 1);
+    uint32_t ts = read_groups(tail, limit);
+    if (pos != n) return false;
+    for (uint32_t i = 0; i < ts; ++i) head[8 - ts + i] = tail[i];
+    for (int i = 0; i < 8; ++i) seg[i] = head[i];
+    return true;
+}
+
+__device__ __forceinline__ uint32_t d_lower(uint32_t c) { return (c - 'A' < 26u) ? c + 32 : c; }
+
+// IPv6 (ext:1044-1116): `p2` is the index of the second ':' of a "::" that is not preceded by a third ':'.
+__device__ bool val_ipv6(const LogView& lg, uint32_t p2, uint32_t& start, uint32_t& end) {
+    uint32_t s = p2 - 1;
+    while (s > 0) { uint32_t c = lg.at(s - 1); if (!d_is_hex(c) && c != ':') break; --s; }
+    uint32_t e = p2 + 1;
+    while (e < lg.len) { uint32_t c = lg.at(e); if (!d_is_hex(c) && c != ':') break; ++e; }
+    uint32_t n = e - s;
+    if (n < 8 || n > 64) return false;  // > 39 can never parse; 64 bounds the local work
+    const uint8_t* c = lg.p + s;
+    if ((c[0] == ':' && c[1] == ':') || (c[n - 2] == ':' && c[n - 1] == ':')) return false;
+    // fe80::/10 text prefix filter (ext:1425-1456)
+    if (d_lower(c[0]) == 'f' && d_lower(c[1]) == 'e') { uint32_t x = d_lower(c[2]); if (x == '8' || x == '9' || x == 'a' || x == 'b') return false; }
+    uint16_t seg[8];
+    if (!d_parse_ipv6(c, n, seg)) return false;
+    start = s; end = e;
+    return true;
+}
+
+// E-mail (ext:891-950, 1182-1196)
+__device__ bool val_email(const LogView& lg, const DevDb& db, uint32_t at, uint32_t& start, uint32_t& end) {
+    uint32_t s = at;
+    while (s > 0 && d_is_email_local(lg.at(s - 1))) --s;
+    if (s == at) return false;
+    if (s > 0 && !d_is_boundary(lg.at(s - 1))) return false;
+    uint32_t e = at + 1;
+    while (e < lg.len && d_is_domain_char(lg.at(e))) ++e;
+    if (e == at + 1) return false;
+    if (e < lg.len && !d_is_boundary(lg.at(e))) return false;
+    bool has_letter = false, has_dot = false;
+    for (uint32_t k = s; k < at; ++k) {
+        uint32_t c = lg.at(k);
+        if (c == '.' && k + 1 < at && lg.at(k + 1) == '.') return false;
+        has_letter |= d_is_alpha(c);
+    }
+    if (!has_letter) return false;
+    for (uint32_t k = at + 1; k < e; ++k) has_dot |= lg.at(k) == '.';
+    if (!has_dot) return false;
+    if (!psl_suffix_exists(db, lg.p, at + 1, e)) return false;
+    start = s; end = e;  // all bytes are ASCII: from_utf8 always succeeds
+    return true;
+}
+
+// ---- SHA-256 (one 64-byte block at a time), Keccak-f[1600], base58, bech32 — rare path, scratch arrays are fine.
+__device__ void d_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
+    const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+        0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+        0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+        0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+        0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+        0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    uint32_t total = ((len + 9 + 63) / 64) * 64;
+    auto byte_at = [&](uint32_t i) -> uint32_t {
+        if (i < len) return data[i];
+        if (i == len) return 0x80;
+        if (i >= total - 8) { uint64_t bits = (uint64_t)len * 8; return (uint32_t)(bits >> (8 * (total - 1 - i))) & 0xFF; }
+        return 0;
+    };
+    auto rotr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+    for (uint32_t off = 0; off < total; off += 64) {
+        uint32_t w[64];
+        for (int i = 0; i < 16; ++i)
+            w[i] = (byte_at(off + 4 * i) << 24) | (byte_at(off + 4 * i + 1) << 16) | (byte_at(off + 4 * i + 2) << 8) | byte_at(off + 4 * i + 3);
+        for (int i = 16; i < 64; ++i) {
+            uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+            uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; ++i) {
+            uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+            uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+}
+
+__device__ void d_keccak_f(uint64_t st[25]) {
+    const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+                             0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+                             0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+                             0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+                             0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    const int ROTC[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+    const int PILN[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    for (int round = 0; round < 24; ++round) {
+        uint64_t bc[5];
+        for (int i = 0; i < 5; ++i) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
+        for (int i = 0; i < 5; ++i) {
+            uint64_t t = bc[(i + 4) % 5] ^ rotl64(bc[(i + 1) % 5], 1);
+            for (int j = 0; j < 25; j += 5) st[j + i] ^= t;
+        }
+        uint64_t t = st[1];
+        for (int i = 0; i < 24; ++i) { int j = PILN[i]; uint64_t b = st[j]; st[j] = rotl64(t, ROTC[i]); t = b; }
+        for (int j = 0; j < 25; j += 5) {
+            for (int i = 0; i < 5; ++i) bc[i] = st[j + i];
+            for (int i = 0; i < 5; ++i) st[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+        }
+        st[0] ^= RC[round];
+    }
+}
+// Keccak-256 with the original 0x01 padding (tiny-keccak Keccak::v256), input <= 135 bytes (one block)
+__device__ void d_keccak256_1blk(const uint8_t* data, uint32_t len, uint8_t out[32]) {
+    uint64_t st[25];
+    for (int i = 0; i < 25; ++i) st[i] = 0;
+    for (uint32_t i = 0; i < 136; ++i) {
+        uint32_t b = i < len ? data[i] : 0;
+        if (i == len) b ^= 0x01;
+        if (i == 135) b ^= 0x80;
+        st[i / 8] ^= (uint64_t)b << (8 * (i % 8));
+    }
+    d_keccak_f(st);
+    for (int i = 0; i < 4; ++i) for (int b = 0; b < 8; ++b) out[8 * i + b] = (uint8_t)(st[i] >> (8 * b));
+}
+
+__device__ int d_b58_val(uint32_t c) {
+    // "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz"
+    if (c >= '1' && c <= '9') return (int)c - '1';
+    if (c >= 'A' && c <= 'H') return (int)c - 'A' + 9;
+    if (c >= 'J' && c <= 'N') return (int)c - 'J' + 17;
+    if (c >= 'P' && c <= 'Z') return (int)c - 'P' + 22;
+    if (c >= 'a' && c <= 'k') return (int)c - 'a' + 33;
+    if (c >= 'm' && c <= 'z') return (int)c - 'm' + 44;
+    return -1;
+}
+// bs58::decode(..).into_vec(): out is big-endian, length returned (0 on invalid character); n <= 110 -> <= 96 bytes
+__device__ uint32_t d_base58_decode(const uint8_t* s, uint32_t n, uint8_t out[112]) {
+    uint8_t num[96];
+    uint32_t nlen = 0, zeros = 0;
+    bool leading = true;
+    for (uint32_t i = 0; i < n; ++i) {
+        int v = d_b58_val(s[i]);
+        if (v < 0) return 0;
+        if (leading && v == 0) { ++zeros; continue; }
+        leading = false;
+        uint32_t carry = (uint32_t)v;
+        for (uint32_t k = 0; k < nlen; ++k) { carry += (uint32_t)num[k] * 58u; num[k] = (uint8_t)carry; carry >>= 8; }
+        while (carry && nlen < 96) { num[nlen++] = (uint8_t)carry; carry >>= 8; }
+    }
+    uint32_t o = 0;
+    for (uint32_t k = 0; k < zeros; ++k) out[o++] = 0;
+    for (uint32_t k = nlen; k-- > 0;) out[o++] = num[k];
+    return o;
+}
+__device__ bool val_btc_base58(const uint8_t* s, uint32_t n) {  // ext:1799-1822
+    uint8_t dec[112], h1[32], h2[32];
+    uint32_t dl = d_base58_decode(s, n, dec);
+    if (dl < 5) return false;
+    d_sha256(dec, dl - 4, h1);
+    d_sha256(h1, 32, h2);
+    return h2[0] == dec[dl - 4] && h2[1] == dec[dl - 3] && h2[2] == dec[dl - 2] && h2[3] == dec[dl - 1];
+}
+__device__ bool val_monero(const uint8_t* s, uint32_t n) {  // ext:1895-1920
+    uint8_t dec[112], h[32];
+    uint32_t dl = d_base58_decode(s, n, dec);
+    if (dl < 5) return false;
+    d_keccak256_1blk(dec, dl - 4, h);  // dl <= 81
+    return h[0] == dec[dl - 4] && h[1] == dec[dl - 3] && h[2] == dec[dl - 2] && h[3] == dec[dl - 1];
+}
+__device__ int d_bech32_val(uint32_t c) {
+    const char* CS = "qpzry9x8gf2tvdw0s3jn54khce6mua7l";
+    for (int i = 0; i < 32; ++i) if ((uint32_t)CS[i] == c) return i;
+    return -1;
+}
+// bech32::decode(addr) succeeds and hrp == "bc" (ext:1825-1835) for a token that starts with "bc1"
+__device__ bool val_btc_bech32(const uint8_t* s, uint32_t n) {
+    // separator = last '1'; it must be the one at index 2, so no '1' may follow; data symbols lower-case charset only
+    // (hrp is lower-case, any upper-case letter makes the string mixed-case); non-ASCII bytes are invalid symbols.
+    if (n < 3 + 6) return false;
+    auto step = [](uint32_t chk, uint32_t v) {
+        const uint32_t GEN[5] = {0x3b6a57b2, 0x26508e6d, 0x1ea119fa, 0x3d4233dd, 0x2a1462b3};
+        uint32_t top = chk >> 25;
+        chk = ((chk & 0x1ffffff) << 5) ^ v;
+        for (int i = 0; i < 5; ++i) if ((top >> i) & 1) chk ^= GEN[i];
+        return chk;
+    };
+    uint32_t chk = 1;
+    chk = step(chk, 'b' >> 5); chk = step(chk, 'c' >> 5); chk = step(chk, 0); chk = step(chk, 'b' & 31); chk = step(chk, 'c' & 31);
+    for (uint32_t k = 3; k < n; ++k) {
+        int v = d_bech32_val(s[k]);
+        if (v < 0) return false;
+        chk = step(chk, (uint32_t)v);
+    }
+    return chk == 1 || chk == 0x2bc830a3u;
+}
+__device__ bool val_eth(const uint8_t* a) {  // ext:1328-1361, 1840-1892: "0x" + 40 hex, EIP-55 when mixed case
+    bool all_lower = true, all_upper = true;
+    uint8_t lower[40], hash[32];
+    for (int i = 0; i < 40; ++i) {
+        uint32_t c = a[2 + i];
+        if (!d_is_hex(c)) return false;
+        if (d_is_alpha(c)) { if (c >= 'a') all_upper = false; else all_lower = false; }
+        lower[i] = (uint8_t)d_lower(c);
+    }
+    if (all_lower || all_upper) return true;
+    d_keccak256_1blk(lower, 40, hash);
+    for (int i = 0; i < 40; ++i) {
+        uint32_t c = a[2 + i];
+        if (d_is_alpha(c)) {
+            uint32_t nib = (i & 1) ? (hash[i / 2] & 0x0f) : (hash[i / 2] >> 4);
+            if ((c < 'a') != (nib >= 8)) return false;
+        }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
+    LogView lg{p.log, p.len};
+    uint32_t n = min(p.counters->n_rare, p.rare_cap);
+    for (uint32_t base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
+        uint32_t i = base + threadIdx.x;
+        Candidate c{0, 0, 0, 0};
+        bool emit = false;
+        if (i < n) {
+            RareAnchor ra = p.rare[i];
+            if (ra.kind == RARE_V6) {
+                uint32_t s, e;
+                if (val_ipv6(lg, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV6 << 24); emit = true; }
+            } else if (ra.kind == RARE_AT) {
+                uint32_t s, e;
+                if (val_email(lg, db, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_EMAIL << 24); emit = true; }
+            }
+        }
+        uint32_t slot = wave_append(&p.counters->n_cand, emit);
+        if (emit && slot < p.cand_cap) p.cands[slot] = c;
+        // tokens can yield up to three items (Bitcoin, Ethereum, Monero are independent extractors)
+        for (int which = 0; which < 3; ++which) {
+            bool em = false;
+            Candidate ct{0, 0, 0, 0};
+            if (i < n) {
+                RareAnchor ra = p.rare[i];
+                if (ra.kind == RARE_TOK) {
+                    const uint8_t* s = lg.p + ra.pos;
+                    uint32_t tl = ra.len;
+                    int ty = -1;
+                    // a token made of non-boundary bytes may contain high bytes; every accepted form is pure ASCII,
+                    // so the reference's from_utf8 precondition is implied by the per-symbol checks
+                    if (which == 0 && (p.flags & EX_BITCOIN) && tl >= 26 && tl <= 62) {
+                        if (s[0] == 'b' && s[1] == 'c' && s[2] == '1') { if (val_btc_bech32(s, tl)) ty = IT_BITCOIN; }
+                        else if (s[0] == '1' || s[0] == '3') { if (val_btc_base58(s, tl)) ty = IT_BITCOIN; }
+                    } else if (which == 1 && (p.flags & EX_ETHEREUM) && tl == 42 && s[0] == '0' && s[1] == 'x') {
+                        if (val_eth(s)) ty = IT_ETHEREUM;
+                    } else if (which == 2 && (p.flags & EX_MONERO) && tl >= 90 && tl <= 110 && (s[0] == '4' || s[0] == '8')) {
+                        if (val_monero(s, tl)) ty = IT_MONERO;
+                    }
+                    if (ty >= 0) { ct.start = ra.pos; ct.len_type = tl | ((uint32_t)ty << 24); em = true; }
+                }
+            }
+            uint32_t sl = wave_append(&p.counters->n_cand, em);
+            if (em && sl < p.cand_cap) p.cands[sl] = ct;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ stage B: lookups
+// SearchTree::lookup_v4 / lookup_v6 (tree:46-125). Returns record (> node_count) or 0 for "not found".
+__device__ bool trie_v4(const DevDb& db, uint32_t addr, uint32_t& data_off, uint32_t& prefix) {
+    uint32_t node = db.ip_version == 6 ? db.v4_start_node : 0;
+    uint32_t depth = 0;
+    for (int bi = 0; bi < 32; ++bi) {
+        uint2 nd = db.ip_nodes[node];
+        uint32_t rec = ((addr >> (31 - bi)) & 1) ? nd.y : nd.x;
+        if (rec == db.node_count) return false;
+        if (rec < db.node_count) { node = rec; ++depth; }
+        else {
+            uint32_t off = rec - db.node_count;
+            if (off < 16) return false;  // reference: MmdbError -> lookup error; treated as not found (never produced by builders)
+            data_off = off - 16;
+            prefix = depth + 1;  // tree:76-80: depth counts from 96 in v6 trees and 96 is subtracted again
+            return true;
+        }
+    }
+    return false;
+}
+__device__ bool trie_v6(const DevDb& db, const uint16_t seg[8], uint32_t& data_off, uint32_t& prefix) {
+    uint32_t node = 0;
+    for (int bi = 0; bi < 128; ++bi) {
+        uint2 nd = db.ip_nodes[node];
+        uint32_t bit = (seg[bi >> 4] >> (15 - (bi & 15))) & 1;
+        uint32_t rec = bit ? nd.y : nd.x;
+        if (rec == db.node_count) return false;
+        if (rec < db.node_count) node = rec;
+        else {
+            uint32_t off = rec - db.node_count;
+            if (off < 16) return false;
+            data_off = off - 16;
+            prefix = (uint32_t)bi + 1;
+            return true;
+        }
+    }
+    return false;
+}
+
+// LiteralHash::lookup (lh:467-525) over the re-hashed device table
+__device__ bool lit_lookup(const DevDb& db, const uint8_t* s, uint32_t n, uint32_t& pattern_id) {
+    uint64_t h = xxh64(s, n, 0);
+    uint32_t slot = (uint32_t)(h ^ (h >> 32)) & db.lit_mask;
+    for (;;) {
+        LitSlot e = db.lit_slots[slot];
+        if (e.str_off == 0xFFFFFFFFu) return false;
+        if (e.hash == h) {
+            const uint8_t* q = db.lit_pool + e.str_off;
+            uint32_t sl = (uint32_t)q[0] | ((uint32_t)q[1] << 8);
+            if (sl == n) {
+                bool eq = true;
+                for (uint32_t k = 0; k < n; ++k) if (q[2 + k] != s[k]) { eq = false; break; }
+                if (eq) { pattern_id = e.pattern_id; return true; }
+            }
+        }
+        slot = (slot + 1) & db.lit_mask;
+    }
+}
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+
+// find_ac_transition (pg:1271-1353): returns target node offset or 0xFFFFFFFF
+__device__ uint32_t ac_transition(const uint8_t* ac, uint32_t ac_len, uint32_t node_off, uint32_t ch) {
+    if (node_off + 20 > ac_len) return 0xFFFFFFFFu;
+    uint32_t w0 = ld32(ac + node_off);
+    uint32_t kind = w0 & 0xFF;
+    if (kind == 1) return ((w0 >> 8) & 0xFF) == ch ? ld32(ac + node_off + 12) : 0xFFFFFFFFu;
+    if (kind == 2) {
+        uint32_t eo = ld32(ac + node_off + 12), cnt = (w0 >> 16) & 0xFF;
+        if (eo + cnt * 8 > ac_len) return 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            uint32_t ec = ac[eo + i * 8];
+            if (ec == ch) return ld32(ac + eo + i * 8 + 4);
+            if (ec > ch) return 0xFFFFFFFFu;
+        }
+        return 0xFFFFFFFFu;
+    }
+    if (kind == 3) {
+        uint32_t t = ld32(ac + node_off + 12) + ch * 4;
+        if (t + 4 > ac_len) return 0xFFFFFFFFu;
+        uint32_t target = ld32(ac + t);
+        return target != 0 ? target : 0xFFFFFFFFu;
+    }
+    return 0xFFFFFFFFu;
+}
+
+__device__ __forceinline__ uint32_t utf8_adv(uint32_t c) { return c < 0x80 ? 1 : c < 0xE0 ? 2 : c < 0xF0 ? 3 : 4; }
+__device__ __forceinline__ bool is_rust_char(uint32_t c) { return c < 0xD800 || (c > 0xDFFF && c <= 0x10FFFF); }
+
+// match_glob_from_buffer / match_segments_impl (pg:1364-1639), case-sensitive. The recursion is replayed with an
+// explicit stack of Star frames; every call of the reference consumes one unit of the 100 000-step budget here too.
+__device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const uint8_t* text, uint32_t tn, uint32_t* err) {
+    const uint8_t* pg = db.pg;
+    uint32_t io = db.glob_seg_off + pattern_id * 8;
+    if (io + 8 > db.pg_len) return false;
+    uint32_t first = ld32(pg + io);
+    uint32_t count = ld32(pg + io + 4) & 0xFFFF;
+    uint32_t steps = 100000;
+    uint32_t st_seg[MAX_GLOB_STARS], st_pos[MAX_GLOB_STARS];
+    int sp = 0;
+    uint32_t pos = 0, seg = 0;
+    bool result = false;
+    for (;;) {
+        // ---- CALL(pos, seg)
+        bool ret = false;
+        if (steps == 0) return false;  // once exhausted every remaining call returns false (pg:1415-1417)
+        --steps;
+        if (seg >= count) { result = pos >= tn; ret = true; }
+        else {
+            uint32_t so = first + seg * 12;
+            if (so + 12 > db.pg_len) { result = false; ret = true; }
+            else {
+                uint32_t h0 = ld32(pg + so);
+                uint32_t st = h0 & 0xFF, fl = (h0 >> 8) & 0xFF;
+                uint32_t dlen = ld32(pg + so + 4), doff = ld32(pg + so + 8);
+                if (st == 0) {
+                    bool ok = doff + dlen <= db.pg_len && tn - pos >= dlen;
+                    if (ok) for (uint32_t k = 0; k < dlen; ++k) if (pg[doff + k] != text[pos + k]) { ok = false; break; }
+                    if (ok) { pos += dlen; ++seg; } else { result = false; ret = true; }
+                } else if (st == 1) {
+                    if (seg + 1 >= count) { result = true; ret = true; }
+                    else if (sp >= (int)MAX_GLOB_STARS) { atomicOr(err, 2u); return false; }
+                    else { st_seg[sp] = seg; st_pos[sp] = pos; ++sp; ++seg; }
+                } else if (st == 2) {
+                    if (pos < tn) { pos += utf8_adv(text[pos]); ++seg; } else { result = false; ret = true; }
+                } else if (st == 3) {
+                    if (pos >= tn || doff + dlen > db.pg_len) { result = false; ret = true; }
+                    else {
+                        uint32_t c = text[pos], adv = utf8_adv(c);
+                        uint32_t cp = adv == 1 ? c : adv == 2 ? (c & 0x1F) : adv == 3 ? (c & 0x0F) : (c & 0x07);
+                        for (uint32_t k = 1; k < adv && pos + k < tn; ++k) cp = (cp << 6) | (text[pos + k] & 0x3F);
+                        bool in_class = false;
+                        for (uint32_t k = 0; k < dlen / 12 && !in_class; ++k) {
+                            const uint8_t* it = pg + doff + k * 12;
+                            uint32_t ty = it[0], c1 = ld32(it + 4), c2 = ld32(it + 8);
+                            if (ty == 0) in_class = is_rust_char(c1) && cp == c1;
+                            else if (ty == 1) in_class = is_rust_char(c1) && is_rust_char(c2) && cp >= c1 && cp <= c2;
+                        }
+                        if ((fl & 1) ? !in_class : in_class) { pos += adv; ++seg; } else { result = false; ret = true; }
+                    }
+                } else { result = false; ret = true; }
+            }
+        }
+        if (!ret) continue;
+        // ---- RETURN(result) to the innermost Star frame
+        for (;;) {
+            if (sp == 0) return result;
+            if (result) { --sp; continue; }  // star returns true: propagate
+            uint32_t fp = st_pos[sp - 1];
+            if (fp >= tn) { --sp; continue; }  // star exhausted: returns false, propagate
+            fp += utf8_adv(text[fp]);
+            st_pos[sp - 1] = fp;
+            pos = fp;
+            seg = st_seg[sp - 1] + 1;
+            break;
+        }
+    }
+}
+
+// Paraglob::find_all (pg:1028-1182): returns the sorted unique pattern ids in out[0..n)
+__device__ uint32_t glob_find_all(const DevDb& db, const uint8_t* text, uint32_t tn, uint32_t* out, uint32_t* err) {
+    uint32_t n = 0;
+    auto insert = [&](uint32_t id) {
+        uint32_t k = 0;
+        while (k < n && out[k] < id) ++k;
+        if (k < n && out[k] == id) return;
+        if (n >= MAX_GLOB_RESULTS) { atomicOr(err, 1u); return; }
+        for (uint32_t m = n; m > k; --m) out[m] = out[m - 1];
+        out[k] = id;
+        ++n;
+    };
+    auto contains = [&](uint32_t id) { for (uint32_t k = 0; k < n; ++k) if (out[k] == id) return true; return false; };
+    auto consider = [&](uint32_t pid) {
+        uint32_t eo = db.patterns_off + pid * 16;
+        if (eo + 16 > db.pg_len) return;
+        uint32_t entry_id = ld32(db.pg + eo);
+        uint32_t ptype = db.pg[eo + 4];
+        if (contains(entry_id)) return;
+        if (ptype == 0 || glob_match(db, entry_id, text, tn, err)) insert(entry_id);
+    };
+    for (uint32_t i = 0; i < db.wild_count; ++i) {
+        uint32_t wo = db.wild_off + i * 8;
+        if (wo + 8 > db.pg_len) continue;
+        uint32_t pid = ld32(db.pg + wo);
+        if (db.patterns_off + pid * 16 + 16 > db.pg_len) continue;
+        if (!contains(pid) && glob_match(db, pid, text, tn, err)) insert(pid);
+    }
+    if (db.ac_size > 0 && tn > 0) {
+        const uint8_t* ac = db.pg + db.ac_start;
+        uint32_t cur = 0;
+        for (uint32_t i = 0; i < tn; ++i) {
+            uint32_t ch = text[i];
+            for (;;) {
+                uint32_t nx = ac_transition(ac, db.ac_size, cur, ch);
+                if (nx != 0xFFFFFFFFu) { cur = nx; break; }
+                if (cur == 0) break;
+                if (cur + 20 > db.ac_size) break;
+                cur = ld32(ac + cur + 8);
+            }
+            if (cur + 20 > db.ac_size) continue;
+            uint32_t pc = ac[cur + 3];
+            if (pc) {
+                uint32_t po = ld32(ac + cur + 16);
+                if (po + pc * 4 <= db.ac_size) {
+                    for (uint32_t k = 0; k < pc; ++k) {
+                        uint32_t lit = ld32(ac + po + k * 4);
+                        if (lit >= db.n_ac_lits) continue;
+                        for (uint32_t q = db.lit2pat_off[lit]; q < db.lit2pat_off[lit + 1]; ++q) consider(db.lit2pat[q]);
+                    }
+                }
+            }
+        }
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
+    uint32_t n = min(p.counters->n_cand, p.cand_cap);
+    uint32_t stride = gridDim.x * blockDim.x;
+    // loop bound is wave-uniform so that wave_append sees converged waves
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        uint32_t i = base + threadIdx.x;
+        Hit h{};
+        bool emit = false;
+        uint32_t globs[MAX_GLOB_RESULTS];
+        uint32_t ng = 0;
+        if (i < n) {
+            Candidate c = p.cands[i];
+            uint32_t type = c.len_type >> 24, tl = c.len_type & 0xFFFFFF;
+            const uint8_t* text = p.log + c.start;
+            h.cand = i; h.start = c.start; h.len_type = c.len_type;
+            if (type == IT_IPV4) {
+                uint32_t off, pfx;
+                if (db.has_ip && trie_v4(db, c.v4, off, pfx)) { h.kind = 2; h.a = off; h.prefix_len = (uint8_t)pfx; emit = true; }
+            } else if (type == IT_IPV6) {
+                uint16_t seg[8];
+                uint32_t off, pfx;
+                if (db.has_ip && d_parse_ipv6(text, tl, seg) && trie_v6(db, seg, off, pfx)) { h.kind = 2; h.a = off; h.prefix_len = (uint8_t)pfx; emit = true; }
+            } else {
+                uint32_t pid = 0xFFFFFFFFu;
+                if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q)) pid = q; }
+                if (db.has_glob) ng = glob_find_all(db, text, tl, globs, &p.counters->error);
+                if (pid != 0xFFFFFFFFu || ng) { h.kind = 3; h.a = pid; h.n_globs = (uint16_t)ng; emit = true; }
+            }
+        }
+        if (emit && ng) {
+            uint32_t io = atomicAdd(&p.counters->n_ids, ng);
+            h.ids_off = io;
+            for (uint32_t k = 0; k < ng; ++k) if (io + k < p.ids_cap) p.ids[io + k] = globs[k];
+        }
+        uint32_t slot = wave_append(&p.counters->n_hits, emit);
+        if (emit && slot < p.hit_cap) p.hits[slot] = h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launch wrappers
+void launch_tokenize(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_tokenize, dim3(grid), dim3(TOK_WAVES * 64), 0, stream, p, db);
+}
+void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_rare, dim3(grid), dim3(64), 0, stream, p, db);
+}
+void launch_lookup(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_lookup, dim3(grid), dim3(256), 0, stream, p, db);
+}
+
+}  // namespace mxy

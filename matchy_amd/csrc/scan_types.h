@@ -1,0 +1,127 @@
+// Types shared between the host pipeline and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mxy {
+
+// MATCHY_ITEM_TYPE_* (reference: crates/matchy/include/matchy/matchy.h:233-288)
+enum ItemType : uint8_t {
+    IT_DOMAIN = 0, IT_EMAIL = 1, IT_IPV4 = 2, IT_IPV6 = 3, IT_MD5 = 4, IT_SHA1 = 5, IT_SHA256 = 6,
+    IT_SHA384 = 7, IT_SHA512 = 8, IT_BITCOIN = 9, IT_ETHEREUM = 10, IT_MONERO = 11, IT_COUNT = 12
+};
+// MATCHY_EXTRACT_* (matchy.h:188-228)
+enum ExtractFlags : uint32_t {
+    EX_DOMAINS = 1, EX_EMAILS = 2, EX_IPV4 = 4, EX_IPV6 = 8, EX_HASHES = 16, EX_BITCOIN = 32, EX_ETHEREUM = 64,
+    EX_MONERO = 128, EX_ALL = 255
+};
+
+// One validated candidate (what Extractor::extract_from_chunk yields), 16 bytes.
+struct Candidate {
+    uint32_t start;      // byte offset in the scanned buffer
+    uint32_t len_type;   // length in bits 0..23, ItemType in bits 24..31
+    uint32_t v4;         // IPv4 address (host order) for IT_IPV4, else 0
+    uint32_t pad;
+};
+
+// Anchors that need the rare-path validators (IPv6, e-mail, crypto tokens), 12 bytes.
+enum RareKind : uint32_t { RARE_V6 = 0, RARE_AT = 1, RARE_TOK = 2 };
+struct RareAnchor {
+    uint32_t pos;   // RARE_V6: index of the 2nd ':' of a "::"; RARE_AT: index of '@'; RARE_TOK: token start
+    uint32_t len;   // RARE_TOK: token length
+    uint32_t kind;
+};
+
+// One database hit, 24 bytes. For IP hits `a` is the data-section offset; for pattern hits `a` is the literal
+// pattern id (or 0xFFFFFFFF) and [ids_off, ids_off + n_globs) indexes the glob-id side buffer.
+struct Hit {
+    uint32_t cand;       // index into the candidate array
+    uint32_t a;
+    uint32_t ids_off;
+    uint16_t n_globs;
+    uint8_t kind;        // 2 = IP, 3 = pattern (QueryResult discriminants used by the oracle too)
+    uint8_t prefix_len;
+    uint32_t start;      // copy of the candidate span/type so the host needs no second gather
+    uint32_t len_type;
+};
+
+struct LitSlot { uint64_t hash; uint32_t str_off; uint32_t pattern_id; };   // str_off 0xFFFFFFFF = empty
+struct PslSlot { uint64_t hash; uint32_t off; uint32_t len; };              // len 0 = empty
+
+// Device-resident database image (all pointers are device pointers).
+struct DevDb {
+    // IP tree, re-laid out as one uint2 {left,right} per node (records widened to 32 bit, host byte order)
+    const uint2* ip_nodes;
+    uint32_t node_count;
+    uint32_t ip_version;     // 4 or 6
+    uint32_t v4_start_node;  // node reached after the 96 zero-bit steps of tree.rs:258-277 (v6 trees)
+    uint32_t has_ip;
+    // literal hash, re-hashed into one power-of-two open-addressing table keyed by the stored XXH64
+    const LitSlot* lit_slots;
+    uint32_t lit_mask;
+    uint32_t has_literal;
+    const uint8_t* lit_pool;  // LHSH string pool: {u16 len, bytes, NUL}
+    uint32_t lit_pool_size;
+    // paraglob buffer as stored on disk + a dense literal-id -> pattern-id list (from the ACLH table)
+    const uint8_t* pg;
+    uint32_t pg_len;
+    uint32_t has_glob;
+    uint32_t ac_start, ac_size;
+    uint32_t patterns_off, pattern_count;
+    uint32_t wild_off, wild_count;
+    uint32_t glob_seg_off;
+    const uint32_t* lit2pat_off;  // [n_ac_lits + 1]
+    const uint32_t* lit2pat;
+    uint32_t n_ac_lits;
+    // public-suffix table
+    const PslSlot* psl_slots;
+    uint32_t psl_mask;
+    const uint8_t* psl_pool;
+    const uint32_t* tld_bloom;    // TLD_BLOOM_WORDS words: bloom over the LAST labels of all suffixes
+    uint32_t max_tld_len;
+};
+
+constexpr uint32_t TLD_BLOOM_BITS = 32768;
+constexpr uint32_t TLD_BLOOM_WORDS = TLD_BLOOM_BITS / 32;
+
+struct ScanCounters {
+    unsigned long long lines;        // '\n' bytes
+    uint32_t n_cand;                 // candidates appended (may exceed capacity → overflow)
+    uint32_t n_rare;
+    uint32_t n_hits;
+    uint32_t n_ids;
+    uint32_t error;                  // bit0: glob result list overflow, bit1: glob star-stack overflow
+    uint32_t pad;
+};
+
+struct TokParams {
+    const uint8_t* log;
+    uint32_t len;
+    uint32_t flags;           // ExtractFlags
+    uint32_t min_labels;
+    uint32_t n_segs;
+    Candidate* cands;
+    uint32_t cand_cap;
+    RareAnchor* rare;
+    uint32_t rare_cap;
+    ScanCounters* counters;
+};
+
+struct LookupParams {
+    const uint8_t* log;
+    uint32_t len;
+    const Candidate* cands;
+    uint32_t cand_cap;
+    Hit* hits;
+    uint32_t hit_cap;
+    uint32_t* ids;
+    uint32_t ids_cap;
+    ScanCounters* counters;
+};
+
+constexpr uint32_t SEG_BYTES = 16384;  // bytes of log per wavefront work item
+constexpr uint32_t MAX_GLOB_RESULTS = 32;
+constexpr uint32_t MAX_GLOB_STARS = 24;
+
+}  // namespace mxy

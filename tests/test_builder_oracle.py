@@ -1,0 +1,188 @@
+"""CPU: databases written by our builder (host C++, matchy_builder_* C ABI) are read by the oracle — an independent
+restatement of the reference reader — and must give the answers the reference's own tests assert
+(crates/matchy/tests/test_ip_longest_prefix_match.rs, test_ip_exact_match.rs, test_literal_hash.rs,
+crates/matchy-paraglob/tests/integration_tests.rs, crates/matchy-paraglob/src/paraglob_offset.rs:1890-1944).
+No GPU calls: only the builder half of the library is exercised here."""
+import json
+
+import pytest
+
+import matchy_amd as M
+
+
+def build(entries, epoch=1700000000):
+    b = M.DatabaseBuilder(build_epoch=epoch)
+    for k, v in entries:
+        b.add_entry(k, v)
+    blob = b.build()
+    b.close()
+    return blob
+
+
+def test_library_exports_every_declared_symbol():
+    L = M.lib()
+    for name in M.EXPORTED_SYMBOLS:
+        assert hasattr(L, name), name
+    # header and list agree
+    import re
+    from pathlib import Path
+    hdr = (Path(__file__).parent.parent / "include" / "matchy_amd.h").read_text()
+    declared = set(re.findall(r"\b(matchy_[a-z0-9_]+)\s*\(", hdr))
+    declared = {d for d in declared if not d.endswith("_t")}
+    assert declared == set(M.EXPORTED_SYMBOLS), declared ^ set(M.EXPORTED_SYMBOLS)
+
+
+def test_longest_prefix_specific_then_general(oracle):
+    # test_ip_longest_prefix_match.rs:13-79
+    db = oracle.Database(build([("192.0.2.1", {"type": "specific"}), ("192.0.2.0/24", {"type": "general"})]))
+    r = db.lookup("192.0.2.1")
+    assert r["kind"] == "ip" and r["prefix_len"] == 32 and r["data"] == {"type": "specific"}
+    r = db.lookup("192.0.2.2")
+    assert r["kind"] == "ip" and r["data"] == {"type": "general"}
+    assert db.lookup("192.0.3.1")["kind"] == "notfound"
+
+
+def test_longest_prefix_general_then_specific(oracle):
+    # test_ip_longest_prefix_match.rs:84-150 (reverse insertion order, same answers)
+    db = oracle.Database(build([("192.0.2.0/24", {"type": "general"}), ("192.0.2.1", {"type": "specific"})]))
+    r = db.lookup("192.0.2.1")
+    assert r["prefix_len"] == 32 and r["data"] == {"type": "specific"}
+    assert db.lookup("192.0.2.200")["data"] == {"type": "general"}
+
+
+def test_three_levels(oracle):
+    # :155-210
+    db = oracle.Database(build([("192.0.0.0/8", {"level": "8"}), ("192.0.2.1", {"level": "32"}), ("192.0.2.0/24", {"level": "24"})]))
+    assert db.lookup("192.0.2.1")["data"]["level"] == "32"
+    assert db.lookup("192.0.2.2")["data"]["level"] == "24"
+    assert db.lookup("192.1.1.1")["data"]["level"] == "8"
+    assert db.lookup("193.0.0.1")["kind"] == "notfound"
+
+
+def test_ipv6_three_levels(oracle):
+    # :265-320
+    db = oracle.Database(build([("2001:db8::/64", {"level": "64"}), ("2001:db8::1", {"level": "128"}), ("2001:db8::/96", {"level": "96"})]))
+    assert db.lookup("2001:db8::1")["data"]["level"] == "128"
+    assert db.lookup("2001:db8::1")["prefix_len"] == 128
+    assert db.lookup("2001:db8::2")["data"]["level"] == "96"
+    assert db.lookup("2001:db8::1:0:0")["data"]["level"] == "64"
+    assert db.lookup("2001:db9::1")["kind"] == "notfound"
+    md = db.metadata()
+    assert md["ip_version"] == 6 and md["record_size"] == 24
+
+
+def test_ipv4_inside_ipv6_tree(oracle):
+    # matchy-ip-trie/src/lib.rs:150-154 + tree.rs:258-277: v4 keys live under 96 zero bits
+    db = oracle.Database(build([("2001:db8::1", {"v": 6}), ("10.1.2.3", {"v": 4}), ("10.9.0.0/16", {"v": 16})]))
+    assert db.lookup("10.1.2.3") == {"kind": "ip", "prefix_len": 32, "data": {"v": 4}}
+    r = db.lookup("10.9.77.1")
+    assert r["kind"] == "ip" and r["prefix_len"] == 16 and r["data"] == {"v": 16}
+    assert db.lookup("10.1.2.4")["kind"] == "notfound"
+    assert db.lookup("2001:db8::1")["data"] == {"v": 6}
+
+
+def test_literal_hash_roundtrip(oracle):
+    # matchy-literal-hash/src/lib.rs:678-714, crates/matchy/tests/test_literal_hash.rs
+    ents = [(f"pattern_{i}", {"id": i}) for i in range(100)]
+    db = oracle.Database(build(ents))
+    for i in range(100):
+        r = db.lookup(f"pattern_{i}")
+        assert r["kind"] == "pattern" and r["pattern_ids"] == [i] and r["data"] == [{"id": i}]
+    assert db.lookup("pattern_100")["kind"] == "notfound"
+    md = db.metadata()
+    assert md["literal_entry_count"] == 100 and md["pattern_section_offset"] == 0 and md["literal_section_offset"] > 0
+    assert md["database_type"] == "Paraglob-Pattern"
+
+
+def test_literal_hash_many_shards(oracle):
+    ents = [(f"host{i}.example{i % 97}.com", {"n": i % 5}) for i in range(12000)]
+    db = oracle.Database(build(ents))
+    for i in (0, 1, 4999, 11999):
+        assert db.lookup(f"host{i}.example{i % 97}.com")["data"] == [{"n": i % 5}]
+    assert db.lookup("host12000.example69.com")["kind"] == "notfound"
+
+
+def test_paraglob_semantics(oracle):
+    # paraglob_offset.rs:1890-1944 and matchy-paraglob/tests/integration_tests.rs
+    db = oracle.Database(build([("*.txt", {"p": 0}), ("test_*", {"p": 1})]))
+    assert db.lookup("test_file.txt")["pattern_ids"] == [0, 1]
+    assert db.lookup("test_file.bin")["pattern_ids"] == [1]
+    assert db.lookup("other.bin")["kind"] == "notfound"
+    db = oracle.Database(build([("*", {"p": 0}), ("??", {"p": 1})]))
+    assert db.lookup("ab")["pattern_ids"] == [0, 1]
+    assert db.lookup("abc")["pattern_ids"] == [0]
+    db = oracle.Database(build([("*test*", {"p": 0}), ("test*", {"p": 1}), ("*test", {"p": 2})]))
+    assert db.lookup("test")["pattern_ids"] == [0, 1, 2]
+    assert db.lookup("testing")["pattern_ids"] == [0, 1]
+    assert db.lookup("mytest")["pattern_ids"] == [0, 2]
+    assert db.lookup("mytesting")["pattern_ids"] == [0]
+    # literal patterns inside paraglob match as substrings (Q9)
+    db = oracle.Database(build([("glob:hello", {"p": 0}), ("glob:world", {"p": 1})]))
+    assert db.lookup("hello world")["pattern_ids"] == [0, 1]
+    # character classes
+    db = oracle.Database(build([("file[0-9].txt", {"p": 0}), ("file[!0-9].txt", {"p": 1})]))
+    assert db.lookup("file7.txt")["pattern_ids"] == [0]
+    assert db.lookup("fileX.txt")["pattern_ids"] == [1]
+    # glob whose literals are all < 3 bytes can never match (Q8)
+    db = oracle.Database(build([("*.a?", {"p": 0}), ("*.evil.com", {"p": 1})]))
+    assert db.lookup("x.ab")["kind"] == "notfound"
+    assert db.lookup("www.evil.com")["pattern_ids"] == [1]
+
+
+def test_combined_database_and_cli_style_lookup(oracle):
+    # processing/mod.rs:615-702 + cli_tests.rs:946-1009
+    db = oracle.Database(build([("8.8.8.8", {"who": "dns"}), ("evil.com", {"why": "bad"}), ("*.malware.com", {"why": "glob"})]))
+    text = b"DNS query to evil.com from 8.8.8.8\nGET http://bad.malware.com/x\nnothing here\n"
+    hits, lines, st = db.scan(text, source="test.log")
+    got = [(h["type"], text[h["start"]:h["end"]].decode()) for h in hits]
+    assert got == [("Domain", "evil.com"), ("IPv4", "8.8.8.8"), ("Domain", "bad.malware.com")]
+    assert st.lines == 3
+    recs = [json.loads(l) for l in lines]
+    assert recs[0] == {"data": [{"why": "bad"}], "match_type": "pattern", "matched_text": "evil.com", "pattern_count": 1,
+                       "source": "test.log", "timestamp": "0.000"}
+    assert recs[1] == {"cidr": "8.8.8.8/32", "data": {"who": "dns"}, "match_type": "ip", "matched_text": "8.8.8.8",
+                       "prefix_len": 32, "source": "test.log", "timestamp": "0.000"}
+    assert recs[2]["matched_text"] == "bad.malware.com" and recs[2]["pattern_count"] == 1
+    # key order of the emitted JSON is sorted (serde_json without preserve_order)
+    assert lines[1].startswith('{"cidr":"8.8.8.8/32","data":{"who":"dns"},"match_type":"ip","matched_text":"8.8.8.8","prefix_len":32,')
+
+
+def test_entry_type_detection_and_prefixes(oracle):
+    db = oracle.Database(build([("literal:*.not-a-glob.com", {"k": 1}), ("glob:no-wildcards.com", {"k": 2}), ("ip:10.0.0.0/8", {"k": 3}),
+                                ("[unclosed", {"k": 4})]))
+    assert db.lookup("*.not-a-glob.com")["data"] == [{"k": 1}]
+    assert db.lookup("x.not-a-glob.com")["kind"] == "notfound"
+    assert db.lookup("www.no-wildcards.com.evil")["data"] == [{"k": 2}]   # substring semantics of paraglob literals
+    assert db.lookup("10.200.1.1")["data"] == {"k": 3}
+    assert db.lookup("[unclosed")["data"] == [{"k": 4}]                     # invalid glob syntax falls back to literal
+
+
+def test_data_types_roundtrip(oracle):
+    data = {"s": "str", "u16": 80, "u32": 70000, "u64": 5000000000, "neg": -5, "b": True, "arr": [1, "two", {"three": 3}],
+            "nested": {"a": {"b": "c"}}, "dup": "str", "long": "x" * 300}
+    db = oracle.Database(build([("1.2.3.4", data), ("5.6.7.8", data), ("9.9.9.9", {"s": "str"})]))
+    assert db.lookup("1.2.3.4")["data"] == data
+    assert db.lookup("5.6.7.8")["data"] == data
+    assert db.lookup("9.9.9.9")["data"] == {"s": "str"}
+
+
+def test_invalid_inputs_are_rejected():
+    b = M.DatabaseBuilder()
+    with pytest.raises(ValueError):
+        b.add_entry("glob:[unclosed", {})
+    with pytest.raises(ValueError):
+        b.add_entry("ip:not-an-ip", {})
+    L = M.lib()
+    assert L.matchy_builder_add(None, b"x", b"{}") == -5
+    assert L.matchy_builder_add(b._h, b"x", b"{not json") == -2
+
+
+def test_metadata_fields(oracle):
+    db = oracle.Database(build([("1.2.3.4", {"a": 1}), ("evil.com", {"a": 2}), ("*.x.org", {"a": 3})], epoch=1234567))
+    md = db.metadata()
+    assert md["build_epoch"] == 1234567
+    assert md["database_type"] == "Paraglob-Combined-IP-Pattern"
+    assert md["binary_format_major_version"] == 2 and md["languages"] == ["en"]
+    assert md["ip_entry_count"] == 1 and md["literal_entry_count"] == 1 and md["glob_entry_count"] == 1
+    assert md["match_mode"] == 0 and md["node_count"] == 32 and md["record_size"] == 24
+    assert md["pattern_section_offset"] % 4 == 0 and md["literal_section_offset"] > md["pattern_section_offset"]
