@@ -1,0 +1,196 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (libmatchy_amd.so), against the CPU oracle on the
+same inputs. Integer/byte work: every comparison is exact."""
+import json
+import random
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def M():
+    import matchy_amd
+    matchy_amd.lib()
+    return matchy_amd
+
+
+@pytest.fixture(scope="module")
+def gpu_extractor(M):
+    ex = M.Extractor()
+    yield ex
+    ex.close()
+
+
+def norm(items):
+    return [(t, s, e, v) for (t, s, e, v) in items]
+
+
+def test_extractor_golden_vectors(M, gpu_extractor, oracle):
+    cases = json.loads((GOLD / "extractor_kat.json").read_text())["cases"]
+    exs = {}
+    for c in cases:
+        data = bytes.fromhex(c["input_hex"]) if "input_hex" in c else c["input"].encode()
+        if c["min_labels"] != 2:
+            continue  # the C ABI has no min_domain_labels knob (neither has the reference's), covered by the oracle test
+        key = c["flags"]
+        if key not in exs:
+            exs[key] = M.Extractor(flags=key)
+        got = exs[key].extract_from_chunk(data)
+        want = oracle.extract(data, flags=c["flags"])
+        assert norm(got) == norm(want), (c["ref"], data)
+        by_type = {}
+        for t, s, e, v in got:
+            by_type.setdefault(t, []).append(v)
+        for t, w in c["expect"].items():
+            assert by_type.get(t, []) == w, (c["ref"], t)
+    for e in exs.values():
+        e.close()
+
+
+ADVERSARIAL = [
+    b"", b"\n", b".", b"..", b"a.b", b"1.2.3.4", b"1.2.3.4\n", b" 1.2.3.4", b"1.2.3.4.", b".1.2.3.4", b"1.2.3.4.5", b"01.2.3.4", b"1.2.3.04",
+    b"0.0.0.0", b"255.255.255.255", b"256.1.1.1", b"1.2.3.4:80", b"x1.2.3.4", b"1.2.3.4x", b"[1.2.3.4]", b"1..2.3.4", b"1.2.3.4/24",
+    b"999.1.1.1 1.1.1.1", b"a=1.2.3.4;b=5.6.7.8", b"1234.1.1.1", b"1.1.1.1111", b"1.2.3", b"1.2.3.4 5.6.7.8 9.10.11.12",
+    b"foo.com", b"foo.com.", b".foo.com", b"foo..com", b"-foo.com", b"foo-.com", b"foo.-com", b"foo.com-", b"a.b.c.d.e.f.com", b"foo.co.uk",
+    b"foo.co.za", b"foo.za", b"foo.ck", b"x.foo.ck", b"EXAMPLE.COM", b"example.COM", b"foo_bar.com", b"foo.com_bar", b"foo.com/path", b"http://foo.com:8080/",
+    b"user@foo.com", b"a@b", b"@foo.com", b"user@", b"user@@foo.com", b"u.s.e.r@foo.co.uk", b"u..r@foo.com", b"123@foo.com", b"user@foo.com.", b"<user@foo.com>",
+    b"a::b", b"::1", b"fe80::1", b"FE80::1", b"feb0::1234:5678", b"fec0::1234:5678", b"2001:db8::1", b"2001:db8::1::2", b"2001:db8:::1", b"1:2:3:4:5:6:7::8",
+    b"1:2:3:4:5:6::7:8", b"12345::abcd:1", b"abcd::12345:1", b"x2001:db8::1", b"2001:db8::1x", b"2001:db8::1]", b"::ffff:1.2.3.4", b"2001:db8::", b"::2001:db8:1",
+    b"a" * 300 + b".com", b"a." * 200 + b"com", b"1." * 100, b":" * 50, b"::" * 30 + b"1", b"@" * 40, b"." * 100, b"0x" * 30,
+    b"5d41402abc4b2a76b9719d911017c592", b"x5d41402abc4b2a76b9719d911017c592", b"5d41402abc4b2a76b9719d911017c592.", b"=5d41402abc4b2a76b9719d911017c592;",
+    b"5d41402abc4b2a76b9719d911017c59", b"5d41402abc4b2a76b9719d911017c5922", b"A" * 40, b"a" * 64, b"f" * 96, b"0" * 128, b"0" * 129, b"g" * 32,
+    b"0x5aAeb6053F3E94C9b9A09f33669435E7Ef1BeAed", b"0x5aaeb6053f3e94c9b9a09f33669435e7ef1beaed", b"0X5aaeb6053f3e94c9b9a09f33669435e7ef1beaed",
+    b"0x5AAEB6053F3E94C9B9A09F33669435E7EF1BEAED", b"x0x5aaeb6053f3e94c9b9a09f33669435e7ef1beaed", b"0x5aaeb6053f3e94c9b9a09f33669435e7ef1beaed0",
+    b"1A1zP1eP5QGefi2DMPTfTL5SLmv7DivfNa", b"1A1zP1eP5QGefi2DMPTfTL5SLmv7DivfNb", b"3Cbq7aT1tY8kMxWLbitaG7yT6bPbKChq64", b"bc1qar0srrr7xfkvy5l643lydnw9re59gtzzwf5mdq",
+    b"bc1qar0srrr7xfkvy5l643lydnw9re59gtzzwf5mdQ", b"BC1QAR0SRRR7XFKVY5L643LYDNW9RE59GTZZWF5MDQ", b"bc1pw508d6qejxtdg4y5r3zarvary0c5xw7kw508d6qejxtdg4y5r3zarvary0c5xw7kt5nd6y",
+    b"bc1p5cyxnuxmeuwuvkwfem96lqzszd02n6xdcjrs20cac6yqjjwudpxqkedrcr", "münchen.de".encode(), "x.münchen.de y".encode(), b"caf\xc3\xa9.fr", b"caf\xc3.fr", b"\xff\xfe.com",
+    b"\x80abc.com", b"abc\x80.com", b"a.b\xe2\x82\xac.com", b"a.\xed\xa0\x80.com", b"key=val.ue.com&x=1", b"https://a.b.example.org/p?q=1.2.3.4&r=x@y.io",
+]
+
+
+def test_extractor_adversarial_inputs(gpu_extractor, oracle):
+    for data in ADVERSARIAL:
+        for wrap in (lambda d: d, lambda d: b"x " + d + b" y", lambda d: d + b"\n" + d, lambda d: b"\n" + d + b"\n"):
+            buf = wrap(data)
+            assert norm(gpu_extractor.extract_from_chunk(buf)) == norm(oracle.extract(buf)), buf
+
+
+ALPHABETS = [
+    b"0123456789.", b"0123456789abcdef:", b"abc.-", b"ab.@-_+1", b"0x123abcdefABCDEF ", b"a1.:@ /-\n", bytes(range(256)),
+    b"comnetorg.uk.co.za", b" \t\n/,;:()[]{}<>\"'@=ab1.", b"13bc1qpzry9x8gf2tvdw0s3jn54khce6mua7l ",
+]
+
+
+def test_extractor_differential_fuzz(gpu_extractor, oracle):
+    rng = random.Random(20251212)
+    for it in range(400):
+        alpha = rng.choice(ALPHABETS)
+        n = rng.choice([1, 5, 17, 63, 64, 65, 127, 128, 129, 200, 1000, 1023, 1024, 1025, 5000])
+        buf = bytes(rng.choice(alpha) for _ in range(n))
+        got, want = norm(gpu_extractor.extract_from_chunk(buf)), norm(oracle.extract(buf))
+        assert got == want, (it, buf)
+
+
+def test_extractor_segment_and_block_edges(gpu_extractor, oracle):
+    # tokens / runs that straddle the 64-byte row, 1 KiB block and 16 KiB segment edges of the tokenizer
+    payloads = [b"10.20.30.40", b"evil.example.com", b"user@mail.example.org", b"2001:db8::8a2e:370:7334",
+                b"5d41402abc4b2a76b9719d911017c592", b"2c26b46b68ffc68ff99b453c1d30413413422d706483bfa0f98a5e886266e7ae",
+                b"0x5aAeb6053F3E94C9b9A09f33669435E7Ef1BeAed", b"1A1zP1eP5QGefi2DMPTfTL5SLmv7DivfNa"]
+    for edge in (64, 1024, 16384, 32768):
+        for pl in payloads:
+            for shift in range(0, len(pl) + 2):
+                pre = edge - shift
+                if pre < 1:
+                    continue
+                buf = b"a" * (pre - 1) + b" " + pl + b" tail\n"
+                assert norm(gpu_extractor.extract_from_chunk(buf)) == norm(oracle.extract(buf)), (edge, pl, shift)
+    # unterminated last token ends exactly at the end of the buffer
+    for pl in payloads:
+        for pad in (0, 1, 15, 16, 63, 64, 1023):
+            buf = b"x" * pad + b" " + pl
+            assert norm(gpu_extractor.extract_from_chunk(buf)) == norm(oracle.extract(buf)), (pl, pad)
+
+
+def _scan_both(M, oracle, blob, text):
+    db = M.Database(blob)
+    sc = M.Scanner(db)
+    res = sc.scan(text)
+    got_hits = res.hits()
+    got_lines = res.ndjson(text, source="t.log")
+    got_stats = (res.lines, res.candidates)
+    res.close(); sc.close(); db.close()
+    odb = oracle.Database(blob)
+    want_hits, want_lines, st = odb.scan(text, source="t.log")
+    return got_hits, got_lines, got_stats, want_hits, want_lines, (st.lines, st.candidates)
+
+
+def test_scan_small_combined_database(M, oracle):
+    b = M.DatabaseBuilder(build_epoch=1)
+    for k, v in [("8.8.8.8", {"who": "dns"}), ("evil.com", {"why": "bad"}), ("*.malware.com", {"why": "glob"}), ("10.0.0.0/8", {"net": "rfc1918"}),
+                 ("2001:db8::/32", {"net": "doc"}), ("5d41402abc4b2a76b9719d911017c592", {"h": "md5"}), ("glob:paypa1", {"sub": "string"}),
+                 ("*.evil.*", {"g": 2}), ("bad-??.example.[a-c]om", {"g": 3}), ("*", {"g": "all"}) if False else ("zzz.invalid", {})]:
+        b.add_entry(k, v)
+    blob = b.build()
+    text = (b"DNS query to evil.com from 8.8.8.8\nGET http://bad.malware.com/x from 10.1.2.3\n"
+            b"v6 client 2001:db8:85a3::8a2e:370:7334 fetched www.paypa1-login.net/a?h=5d41402abc4b2a76b9719d911017c592\n"
+            b"a.evil.b c.evil.com bad-ab.example.com bad-ab.example.dom nothing.here.zz 11.1.1.1\n")
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, text)
+    assert gh == wh
+    assert gl == wl
+    assert gs == ws
+    assert len(gh) >= 8
+
+
+@pytest.mark.parametrize("cfgname,lines", [("c1", 10000), ("c2/20", 20000), ("c4/20", 20000)])
+def test_scan_synthetic_configs(M, oracle, cfgname, lines):
+    from tools import synth
+    cfg = synth.config(cfgname)
+    blob = synth.build_db(cfg)
+    text = synth.make_log(cfg, 0, lines)
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, text)
+    assert gs == ws
+    assert len(gh) == len(wh)
+    assert gh == wh
+    assert gl == wl
+    assert len(gh) > lines // 200
+
+
+def test_single_query_api(M, oracle):
+    from tools import synth
+    cfg = synth.config("c1")
+    blob = synth.build_db(cfg)
+    db = M.Database(blob)
+    odb = oracle.Database(blob)
+    keys = [k.decode() for k, _ in synth.ioc_entries(cfg)]
+    probes = keys[::37] + ["1.2.3.4", "nope.example.com", "::1", "2001:db8::1", "not an ip", ""]
+    for k in keys[::37]:
+        if "/" in k:
+            probes.append(k.split("/")[0])
+        if k.startswith("*."):
+            probes.append("www" + k[1:])
+    for q in probes:
+        want = odb.lookup(q)
+        got = db.lookup(q)
+        if want["kind"] == "ip":
+            assert got == {"found": True, "prefix_len": want["prefix_len"], "data": want["data"]}, q
+        elif want["kind"] == "pattern" and want["data"] and want["data"][0] is not None:
+            assert got == {"found": True, "prefix_len": 0, "data": want["data"][0]}, q
+        else:
+            assert got is None, q
+    db.close()
+
+
+def test_null_and_error_handling(M):
+    L = M.lib()
+    assert L.matchy_open(None) is None
+    assert L.matchy_open(b"/nonexistent/file.mxy") is None
+    assert L.matchy_open_buffer(b"garbage-not-a-db", 16) is None
+    assert L.matchy_open_with_options(b"/nonexistent", None) is None
+    r = L.matchy_query(None, b"x")
+    assert not r.found
+    L.matchy_close(None)
+    L.matchy_scanner_free(None)

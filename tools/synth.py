@@ -1,0 +1,102 @@
+"""Synthetic workloads of BASELINE.json for tests and bench.py — not part of the product library.
+
+`make_log` / `ioc_keys` wrap tools/synthgen.cpp (built on demand with g++); `build_db` feeds the indicator set
+through the product's own builder C ABI (matchy_builder_add), i.e. the same path `matchy build` uses.
+"""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "build" / "libsynthgen.so"
+SRC = HERE / "synthgen.cpp"
+
+SEED = 0x6D61746368790001  # "matchy\0\1" — SURVEY §8d
+
+
+class Cfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_ip", C.c_uint32), ("n_cidr", C.c_uint32), ("n_dom", C.c_uint32),
+                ("n_hash", C.c_uint32), ("n_glob", C.c_uint32), ("hit_permille", C.c_uint32)]
+
+
+def config(name: str) -> Cfg:
+    """Indicator mixes of the BASELINE configs (scaled variants carry a suffix, e.g. 'c2/100')."""
+    scale = 1
+    if "/" in name:
+        name, s = name.split("/")
+        scale = int(s)
+    presets = {
+        # C1: 1K-indicator CSV (400 /32, 100 CIDR, 350 domains, 100 globs, 50 hashes)
+        "c1": dict(n_ip=400, n_cidr=100, n_dom=350, n_hash=50, n_glob=100),
+        # C2: 100K mixed IoCs, no globs
+        "c2": dict(n_ip=40000, n_cidr=10000, n_dom=35000, n_hash=15000, n_glob=0),
+        # C3: 1M domain/hash indicators
+        "c3": dict(n_ip=0, n_cidr=0, n_dom=700000, n_hash=300000, n_glob=0),
+        # C4: C2 with 10K domains replaced by *.domain globs
+        "c4": dict(n_ip=40000, n_cidr=10000, n_dom=25000, n_hash=15000, n_glob=10000),
+    }
+    p = {k: max(v // scale, 1 if v else 0) for k, v in presets[name].items()}
+    return Cfg(seed=SEED, hit_permille=20, **p)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB.exists() or LIB.stat().st_mtime < SRC.stat().st_mtime:
+            LIB.parent.mkdir(exist_ok=True)
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(LIB), str(SRC)], check=True)
+        L = C.CDLL(str(LIB))
+        L.synth_log.argtypes = [C.POINTER(Cfg), C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]
+        L.synth_log.restype = C.c_size_t
+        for f in (L.synth_ioc_key, L.synth_ioc_data):
+            f.argtypes = [C.POINTER(Cfg), C.c_int, C.c_uint32, C.c_char_p, C.c_size_t]
+            f.restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+def make_log(cfg: Cfg, first_line: int, n_lines: int) -> bytes:
+    L = lib()
+    cap = n_lines * 320 + 1024
+    buf = C.create_string_buffer(cap)
+    n = L.synth_log(C.byref(cfg), first_line, n_lines, buf, cap)
+    if n > cap:
+        buf = C.create_string_buffer(n)
+        n = L.synth_log(C.byref(cfg), first_line, n_lines, buf, n)
+    return buf.raw[:n]
+
+
+def make_log_into(cfg: Cfg, first_line: int, n_lines: int, ptr: int, cap: int) -> int:
+    """Generate straight into caller memory (e.g. a pinned torch tensor). Returns bytes written (or needed)."""
+    return lib().synth_log(C.byref(cfg), first_line, n_lines, ptr, cap)
+
+
+KINDS = (("ip", 0, "n_ip"), ("cidr", 1, "n_cidr"), ("domain", 2, "n_dom"), ("hash", 3, "n_hash"), ("glob", 4, "n_glob"))
+
+
+def ioc_entries(cfg: Cfg):
+    """Yield (key, json_data) for every indicator of the config, in CSV row order."""
+    L = lib()
+    kb = C.create_string_buffer(512)
+    db = C.create_string_buffer(512)
+    for _, kind, field in KINDS:
+        for i in range(getattr(cfg, field)):
+            L.synth_ioc_key(C.byref(cfg), kind, i, kb, 512)
+            L.synth_ioc_data(C.byref(cfg), kind, i, db, 512)
+            yield kb.value, db.value
+
+
+def build_db(cfg: Cfg, epoch=1700000000) -> bytes:
+    import matchy_amd as M
+    ML = M.lib()
+    b = M.DatabaseBuilder(build_epoch=epoch)
+    for key, data in ioc_entries(cfg):
+        rc = ML.matchy_builder_add(b._h, key, data)
+        if rc != 0:
+            raise ValueError(f"builder rejected {key!r}: {M.last_error()}")
+    blob = b.build()
+    b.close()
+    return blob

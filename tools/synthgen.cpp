@@ -1,0 +1,209 @@
+// tools/synthgen.cpp — deterministic synthetic data for tests and bench.py (NOT part of the product library).
+//
+// Implements the workload of SURVEY.md §8(d) / BASELINE.json: nginx "combined" access-log lines and the
+// indicator sets of configs C1..C5. Every line and every indicator is a pure function of (seed, index)
+// (splitmix64), so the log generator can plant database indicators without any shared state and any line
+// range can be produced independently. Shape follows the reference's own generator idea
+// (crates/matchy/examples/generate_logs.rs:21-71: fixed pools, rare threat lines) in nginx format.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace {
+
+inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+struct Cfg {
+    uint64_t seed;
+    uint32_t n_ip, n_cidr, n_dom, n_hash, n_glob;
+    uint32_t hit_permille;   // share of lines (per mille) whose client IP / referer is planted from the DB
+};
+
+const char* TLDS[20] = {"com", "net", "org", "info", "biz", "io", "co", "ru", "cn", "de", "uk", "fr", "nl", "br", "in", "xyz", "top", "site", "online", "app"};
+const char* WORDS[32] = {"alpha", "bravo", "cargo", "delta", "ember", "fable", "gamma", "haven", "ionic", "jolly", "karma", "lumen", "mango", "noble", "ocean", "pixel",
+                         "quark", "raven", "sigma", "tango", "umbra", "vivid", "waltz", "xenon", "yield", "zebra", "amber", "blaze", "coral", "drift", "eagle", "frost"};
+const char* UAS[20] = {
+    "Mozilla/5.0 (Windows NT 10.0; Win64; x64) AppleWebKit/537.36 (KHTML, like Gecko) Chrome/120.0.0.0 Safari/537.36",
+    "Mozilla/5.0 (Macintosh; Intel Mac OS X 10_15_7) AppleWebKit/605.1.15 (KHTML, like Gecko) Version/17.1 Safari/605.1.15",
+    "Mozilla/5.0 (X11; Linux x86_64; rv:121.0) Gecko/20100101 Firefox/121.0",
+    "Mozilla/5.0 (iPhone; CPU iPhone OS 17_1 like Mac OS X) AppleWebKit/605.1.15 (KHTML, like Gecko) Version/17.1 Mobile/15E148 Safari/604.1",
+    "Mozilla/5.0 (Linux; Android 14; Pixel 8) AppleWebKit/537.36 (KHTML, like Gecko) Chrome/119.0.6045.163 Mobile Safari/537.36",
+    "curl/8.4.0",
+    "python-requests/2.31.0",
+    "Go-http-client/2.0",
+    "Mozilla/5.0 (compatible; Googlebot/2.1; +http://www.google.com/bot.html)",
+    "Mozilla/5.0 (compatible; bingbot/2.0; +http://www.bing.com/bingbot.htm)",
+    "Mozilla/5.0 (Windows NT 10.0; Win64; x64) AppleWebKit/537.36 (KHTML, like Gecko) Chrome/118.0.0.0 Safari/537.36 Edg/118.0.2088.76",
+    "Wget/1.21.4",
+    "okhttp/4.12.0",
+    "Mozilla/5.0 (Windows NT 6.1; WOW64; Trident/7.0; rv:11.0) like Gecko",
+    "Apache-HttpClient/4.5.14 (Java/17.0.9)",
+    "Mozilla/5.0 (X11; Ubuntu; Linux x86_64; rv:109.0) Gecko/20100101 Firefox/115.0",
+    "PostmanRuntime/7.35.0",
+    "Mozilla/5.0 (iPad; CPU OS 16_6 like Mac OS X) AppleWebKit/605.1.15 (KHTML, like Gecko) CriOS/119.0.6045.169 Mobile/15E148 Safari/604.1",
+    "facebookexternalhit/1.1 (+http://www.facebook.com/externalhit_uatext.php)",
+    "Slackbot-LinkExpanding 1.0 (+https://api.slack.com/robots)"};
+const char* MONTHS[12] = {"Jan", "Feb", "Mar", "Apr", "May", "Jun", "Jul", "Aug", "Sep", "Oct", "Nov", "Dec"};
+const char* EXTS[8] = {"html", "php", "js", "css", "png", "json", "jpg", "svg"};
+
+void ipv4_str(uint32_t a, std::string& out) {
+    char b[20];
+    snprintf(b, sizeof(b), "%u.%u.%u.%u", a >> 24, (a >> 16) & 255, (a >> 8) & 255, a & 255);
+    out += b;
+}
+uint32_t public_v4(uint64_t h) {  // first octet 1..223, never 10/127 so benign and planted pools stay apart from 10.x test nets
+    uint32_t a = (uint32_t)(h >> 16);
+    uint32_t o = 1 + (uint32_t)((h >> 48) % 223);
+    if (o == 10 || o == 127) o = 11;
+    return (o << 24) | (a & 0x00FFFFFF);
+}
+void hex_of(uint64_t seed, int nchars, std::string& out) {
+    static const char* H = "0123456789abcdef";
+    uint64_t x = seed;
+    for (int i = 0; i < nchars; ++i) {
+        if (i % 16 == 0) x = splitmix64(x + i);
+        out.push_back(H[(x >> (4 * (i % 16))) & 15]);
+    }
+}
+
+// ---- indicators: kind 0 ip, 1 cidr, 2 domain, 3 hash, 4 glob
+void ioc_key(const Cfg& c, int kind, uint32_t i, std::string& out) {
+    uint64_t h = splitmix64(c.seed ^ (0xA5A5ull << 32) ^ ((uint64_t)kind << 40) ^ i);
+    switch (kind) {
+        case 0: ipv4_str(public_v4(h), out); break;
+        case 1: {
+            // prefixes /16../30: the set covers ~1-2 % of the IPv4 space, so the line hit rate stays a few per cent
+            uint32_t p = 16 + (uint32_t)((h >> 8) % 15);
+            uint32_t a = public_v4(splitmix64(h));
+            a &= p == 32 ? 0xFFFFFFFFu : ~((1u << (32 - p)) - 1);
+            ipv4_str(a, out);
+            out += "/" + std::to_string(p);
+            break;
+        }
+        case 2: out += std::string(WORDS[h & 31]) + WORDS[(h >> 5) & 31] + std::to_string(i) + "." + TLDS[(h >> 10) % 20]; break;
+        case 3: { int n = (i % 3 == 0) ? 32 : (i % 3 == 1) ? 40 : 64; hex_of(h, n, out); break; }
+        case 4: out += std::string("*.") + WORDS[h & 31] + "-" + WORDS[(h >> 5) & 31] + std::to_string(i) + "." + TLDS[(h >> 10) % 20]; break;
+    }
+}
+void ioc_data(const Cfg& c, int kind, uint32_t i, std::string& out) {
+    static const char* LV[4] = {"low", "medium", "high", "critical"};
+    static const char* CAT[8] = {"malware", "phishing", "c2", "botnet", "spam", "scanner", "tor-exit", "ransomware"};
+    uint64_t h = splitmix64(c.seed ^ (0x5A5Aull << 32) ^ ((uint64_t)kind << 40) ^ i);
+    out += std::string("{\"threat_level\":\"") + LV[h & 3] + "\",\"category\":\"" + CAT[(h >> 2) & 7] + "\",\"source\":\"feed-" + std::to_string((h >> 5) & 15) + "\"}";
+}
+
+void path_of(uint64_t h, std::string& out) {
+    uint32_t t = (uint32_t)(h % 10000);
+    uint64_t g = splitmix64(0xBADC0FFEEull ^ t);
+    int depth = 1 + (int)(g & 3);
+    for (int d = 0; d < depth; ++d) { out.push_back('/'); out += WORDS[(g >> (4 + 5 * d)) & 31]; }
+    if ((g >> 40) & 1) { out.push_back('.'); out += EXTS[(g >> 41) & 7]; }
+}
+
+void gen_line(const Cfg& c, uint64_t L, std::string& out) {
+    uint64_t h = splitmix64(c.seed ^ L);
+    uint64_t h2 = splitmix64(h);
+    uint64_t h3 = splitmix64(h2);
+    // client address
+    uint32_t r = (uint32_t)(h % 1000);
+    uint32_t n_ipdb = c.n_ip + c.n_cidr;
+    if (r < c.hit_permille && n_ipdb) {
+        uint32_t j = (uint32_t)((h >> 12) % n_ipdb);
+        if (j < c.n_ip) ioc_key(c, 0, j, out);
+        else {
+            std::string k;
+            ioc_key(c, 1, j - c.n_ip, k);
+            unsigned a, b, cc, d, p;
+            sscanf(k.c_str(), "%u.%u.%u.%u/%u", &a, &b, &cc, &d, &p);
+            uint32_t net = (a << 24) | (b << 16) | (cc << 8) | d;
+            uint32_t host = (uint32_t)(h2 >> 7) & (p == 32 ? 0u : ((1u << (32 - p)) - 1));
+            ipv4_str(net | host, out);
+        }
+    } else if (r >= 990) {
+        char b[64];
+        snprintf(b, sizeof(b), "2001:db8:%x::%x", (unsigned)((h >> 20) & 0xFFFF), (unsigned)((h >> 36) & 0xFFFF) | 1u);
+        out += b;
+    } else {
+        ipv4_str(public_v4(splitmix64(0x77ull ^ ((h >> 12) % 1000000))), out);
+    }
+    // timestamp
+    uint64_t sec = L / 50;  // 50 requests per second
+    char ts[64];
+    snprintf(ts, sizeof(ts), " - - [%02u/%s/2026:%02u:%02u:%02u +0000] \"", (unsigned)(1 + (sec / 86400) % 28), MONTHS[(sec / (86400 * 28)) % 12],
+             (unsigned)((sec / 3600) % 24), (unsigned)((sec / 60) % 60), (unsigned)(sec % 60));
+    out += ts;
+    out += (h2 & 7) ? "GET " : "POST ";
+    path_of(h2 >> 3, out);
+    if ((h2 >> 20) % 1000 == 0 && c.n_hash) {  // 0.1 %: hash in query string, 10 % of those from the DB
+        out += "?h=";
+        if ((h2 >> 32) % 10 == 0) ioc_key(c, 3, (uint32_t)((h2 >> 36) % c.n_hash), out);
+        else hex_of(h3, ((h2 >> 40) & 1) ? 32 : 64, out);
+    }
+    static const int STATUS[8] = {200, 200, 200, 200, 301, 304, 404, 500};
+    char sb[64];
+    snprintf(sb, sizeof(sb), " HTTP/1.1\" %d %u \"", STATUS[(h3 >> 3) & 7], (unsigned)(200 + (h3 >> 8) % 50000));
+    out += sb;
+    // referer
+    uint32_t rr = (uint32_t)((h3 >> 24) % 1000);
+    if (rr < 600) out += "-";
+    else {
+        out += "https://";
+        uint32_t pick = (uint32_t)((h3 >> 34) % 1000);
+        uint32_t half = c.hit_permille / 2 ? c.hit_permille / 2 : 1;
+        if (pick < half && c.n_dom) ioc_key(c, 2, (uint32_t)((h3 >> 44) % c.n_dom), out);
+        else if (pick < 2 * half && c.n_glob) {
+            std::string g;
+            ioc_key(c, 4, (uint32_t)((h3 >> 44) % c.n_glob), g);
+            out += std::string(WORDS[(h3 >> 50) & 31]) + g.substr(1);  // "<word>.<glob domain>"
+        } else {
+            uint64_t d = splitmix64(0x99ull ^ ((h3 >> 40) % 200000));
+            out += std::string("site") + std::to_string((unsigned)(d % 200000)) + "." + TLDS[(d >> 20) % 20];
+        }
+        path_of(h3 >> 5, out);
+    }
+    out += "\" \"";
+    out += UAS[(h >> 50) % 20];
+    out += "\"\n";
+}
+
+}  // namespace
+
+extern "C" {
+
+struct synth_cfg_t { uint64_t seed; uint32_t n_ip, n_cidr, n_dom, n_hash, n_glob, hit_permille; };
+
+static Cfg to_cfg(const synth_cfg_t* c) { return Cfg{c->seed, c->n_ip, c->n_cidr, c->n_dom, c->n_hash, c->n_glob, c->hit_permille}; }
+
+// Writes lines [first, first+n) into out (capacity cap). Returns bytes written, or the required size if cap is too small.
+size_t synth_log(const synth_cfg_t* cfg, uint64_t first, uint64_t n, uint8_t* out, size_t cap) {
+    Cfg c = to_cfg(cfg);
+    size_t pos = 0;
+    std::string line;
+    for (uint64_t L = first; L < first + n; ++L) {
+        line.clear();
+        gen_line(c, L, line);
+        if (pos + line.size() <= cap) memcpy(out + pos, line.data(), line.size());
+        pos += line.size();
+    }
+    return pos;
+}
+size_t synth_ioc_key(const synth_cfg_t* cfg, int kind, uint32_t i, char* out, size_t cap) {
+    std::string s;
+    ioc_key(to_cfg(cfg), kind, i, s);
+    if (s.size() + 1 <= cap) memcpy(out, s.c_str(), s.size() + 1);
+    return s.size();
+}
+size_t synth_ioc_data(const synth_cfg_t* cfg, int kind, uint32_t i, char* out, size_t cap) {
+    std::string s;
+    ioc_data(to_cfg(cfg), kind, i, s);
+    if (s.size() + 1 <= cap) memcpy(out, s.c_str(), s.size() + 1);
+    return s.size();
+}
+
+}  // extern "C"
