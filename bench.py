@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py — `matchy match` hot path on MI355X: log GB/s scanned (+ lines/s) at a 100K-indicator database.
+
+Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU).
+A "step" is one pass of the hot path (tokenize -> rare validators -> database lookup -> hit records on the host)
+over one batch of synthetic nginx log that is ALREADY RESIDENT IN HBM when the timed region starts.
+
+Workload at N=1 = BASELINE.json configs[1]: 100K mixed IoCs (40K IPv4 + 10K CIDR + 35K domains + 15K hashes),
+10M nginx-style lines, 1x MI355X. For N>1 every rank scans its own 10M-line block (line-block sharding, no
+collective on the data path; `scaling` = weak). Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--lines", type=int, default=10_000_000, help="log lines per GPU (BASELINE config: 10M)")
+    ap.add_argument("--config", default="c2", help="indicator mix (tools/synth.py): c2 = 100K mixed IoCs")
+    ap.add_argument("--cpu-lines", type=int, default=3_000_000, help="lines of the same log timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ["MATCHY_AMD_DEVICE"] = str(local_rank)
+
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import matchy_amd as M
+    from tools import synth
+
+    cfg = synth.config(args.config)
+    blob = synth.build_db(cfg)
+    db = M.Database(blob)
+    scanner = M.Scanner(db, device=local_rank, profile=True)
+
+    # ---- synthetic batch: this rank's line block, generated on the host, uploaded once
+    first_line = rank * args.lines
+    cap = args.lines * 200 + (1 << 20)
+    host = torch.empty(cap, dtype=torch.uint8)
+    nbytes = synth.make_log_into(cfg, first_line, args.lines, host.data_ptr(), cap)
+    if nbytes > cap:
+        host = torch.empty(nbytes, dtype=torch.uint8)
+        nbytes = synth.make_log_into(cfg, first_line, args.lines, host.data_ptr(), nbytes)
+    if nbytes >= 0x7FFF0000:
+        raise SystemExit("batch exceeds the 2 GiB single-launch limit; lower --lines")
+    dlog = torch.empty(nbytes + 64, dtype=torch.uint8, device=dev)
+    dlog[:nbytes].copy_(host[:nbytes])
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        res = scanner.scan_device(dlog.data_ptr(), nbytes, stream=stream, fetch_hits=True)
+        out = (res.lines, res.candidates, res.n_hits)
+        res.close()
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        counts = step()
+    tok_ms, look_ms, rare_ms = [], [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+        t = scanner.timing_ms()
+        tok_ms.append(t["tokenize"]); look_ms.append(t["lookup"]); rare_ms.append(t["rare"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tb = torch.tensor([float(nbytes), float(counts[0])], dtype=torch.float64, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        total_bytes, total_lines = float(tb[0].item()), float(tb[1].item())
+    else:
+        total_bytes, total_lines = float(nbytes), float(counts[0])
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_bytes / (elapsed / args.steps) / 1e9
+    avg_tok = sum(tok_ms) / len(tok_ms)
+    achieved = nbytes / (avg_tok * 1e-3) / 1e9  # algorithmic bytes of one k_tokenize launch = len(log)
+
+    cpu = None
+    parity = None
+    if rank == 0 and not args.no_cpu:
+        # ---- CPU baseline: the oracle ("port" of the reference CPU path) on a bounded sample of the SAME log,
+        # all host cores, newline-aligned chunks + 10 000-entry per-thread LRU like `matchy match` defaults.
+        from oracle import oracle
+        n_cpu_lines = min(args.cpu_lines, args.lines)
+        # sample = first n_cpu_lines lines of this rank's batch
+        hv = host[:nbytes].numpy()
+        import numpy as np
+        nl = np.flatnonzero(hv[: min(nbytes, n_cpu_lines * 400)] == 10)
+        sample_end = int(nl[n_cpu_lines - 1]) + 1 if len(nl) >= n_cpu_lines else nbytes
+        sample = hv[:sample_end].tobytes()
+        odb = oracle.Database(blob)
+        cores = min(len(os.sched_getaffinity(0)), 16)  # GPU box share: 16 host cores per GPU
+        ohits, _, st = odb.scan(sample, threads=cores, cache=10000, want_json=False)
+        cpu = {"value": round(len(sample) / st.seconds / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
+               "sample": f"first {n_cpu_lines} lines ({len(sample)} B) of the same log, {cores} threads, 256 KiB newline-aligned chunks, LRU 10000",
+               "lines_per_s": round(st.lines / st.seconds, 1)}
+        # parity in the same run: GPU hits on the sample == oracle hits
+        res = scanner.scan_device(dlog.data_ptr(), sample_end, stream=stream, fetch_hits=True)
+        ghits = res.hits()
+        res.close()
+        parity = "ok" if ghits == ohits else f"MISMATCH gpu={len(ghits)} cpu={len(ohits)}"
+
+    if rank == 0:
+        out = {
+            "metric": "log GB/s scanned (matchy match hot path, 100K IoCs)",
+            "value": round(value, 3),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {cfg.n_ip + cfg.n_cidr + cfg.n_dom + cfg.n_hash + cfg.n_glob} mixed IoCs "
+                                   f"({cfg.n_ip} IPv4 + {cfg.n_cidr} CIDR + {cfg.n_dom} domains + {cfg.n_hash} hashes + {cfg.n_glob} globs), "
+                                   f"{args.lines} nginx-style lines per GPU",
+                       "lines_per_gpu": args.lines, "bytes_per_gpu": nbytes, "sharding": "line-block per GPU, DB replicated, no collective"},
+            "lines_per_s": round(total_lines / (elapsed / args.steps), 1),
+            "candidates_per_step": counts[1],
+            "hits_per_step": counts[2],
+            "kernel_ms": {"k_tokenize": round(avg_tok, 4), "k_rare": round(sum(rare_ms) / len(rare_ms), 4), "k_lookup": round(sum(look_ms) / len(look_ms), 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel": "k_tokenize", "algorithmic_bytes_per_launch": nbytes},
+            "cpu_baseline": cpu,
+            "parity_vs_oracle": parity,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,7 @@ struct Db {
     DevBuf<uint8_t> qbuf;
     DevBuf<Candidate> qcand;
     std::string format;
+    int default_device = 0;
 
     std::shared_ptr<DeviceDb> device_db(int device) {
         if ((int)dev.size() <= device) dev.resize(device + 1);
@@ -125,7 +126,12 @@ matchy_t* open_bytes(std::vector<uint8_t>&& bytes) {
             set_error("matchy_amd: no HIP device available (this build has no CPU lookup path)");
             return nullptr;
         }
-        db->device_db(0);  // "uploaded once to device memory" at open
+        // "uploaded once to device memory" at open. One process per GPU selects its device with MATCHY_AMD_DEVICE.
+        int dev0 = 0;
+        if (const char* e = getenv("MATCHY_AMD_DEVICE")) dev0 = atoi(e);
+        if (dev0 < 0 || dev0 >= ndev) { set_error("MATCHY_AMD_DEVICE out of range"); return nullptr; }
+        db->default_device = dev0;
+        db->device_db(dev0);
         return reinterpret_cast<matchy_t*>(db.release());
     } catch (const HipError& e) { set_error(e.what); return nullptr; }
     catch (const std::exception& e) { set_error(e.what()); return nullptr; }
@@ -291,7 +297,7 @@ void matchy_query_into(const matchy_t* dbc, const char* query, matchy_result_t* 
     if (!valid_utf8_host((const uint8_t*)query, qn)) return;  // CStr::to_str failure -> found=false
     try {
         std::lock_guard<std::mutex> lk(db->mu);
-        if (!db->query_scanner) db->query_scanner = std::make_unique<Scanner>(db->img, db->device_db(0), EX_ALL, 2);
+        if (!db->query_scanner) db->query_scanner = std::make_unique<Scanner>(db->img, db->device_db(db->default_device), EX_ALL, 2);
         // Database::lookup (database.rs:725-804): try IpAddr first, otherwise the string path
         IpAddr ip;
         std::string text(query, qn);
