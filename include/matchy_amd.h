@@ -174,17 +174,22 @@ void matchy_scanner_free(matchy_scanner_t *scanner);
 /* Scan a host buffer (copied to the device in newline-aligned pieces of < 1 GiB). */
 int32_t matchy_scanner_scan(matchy_scanner_t *scanner, const uint8_t *data, size_t len, matchy_scan_result_t *out);
 /* Scan bytes that are already resident in device memory (16-byte aligned, len < 2^31) on `hip_stream`
- * (a hipStream_t, NULL = default stream). With fetch_hits=false only counters are read back. */
+ * (a hipStream_t, NULL = default stream). fetch_mode: 0 = only counters are read back (n_hits is set, hits is NULL),
+ * 1 = hit records in device order (like the reference, whose result order is unspecified), 3 = canonical order. */
+#define MATCHY_SCAN_FETCH_COUNTS 0u
+#define MATCHY_SCAN_FETCH_HITS 1u
+#define MATCHY_SCAN_FETCH_SORTED 3u
 int32_t matchy_scanner_scan_device(matchy_scanner_t *scanner, const void *device_ptr, size_t len, void *hip_stream,
-                                   bool fetch_hits, matchy_scan_result_t *out);
+                                   uint32_t fetch_mode, matchy_scan_result_t *out);
 void matchy_scan_result_free(matchy_scan_result_t *result);
 /* The NDJSON record `matchy match` prints for hit i (match_processor/parallel.rs:297-369). `text` points at the
  * scanned bytes on the host. Returned string: matchy_free_string(). */
 char *matchy_scan_hit_to_json(const matchy_scanner_t *scanner, const matchy_scan_result_t *result, size_t i,
                               const uint8_t *text, const char *source);
-/* Per-kernel HIP-event timing of the last scan: out[0..3] = tokenize, rare, lookup, total (milliseconds). */
+/* Per-kernel HIP-event timing of the last scan (recorded on the scan's stream):
+ * out[0..4] = k_anchor, k_validate, k_rare, k_lookup, total (milliseconds). */
 void matchy_scanner_set_profile(matchy_scanner_t *scanner, bool enabled);
-void matchy_scanner_get_timing(const matchy_scanner_t *scanner, float out_ms[4]);
+void matchy_scanner_get_timing(const matchy_scanner_t *scanner, float out_ms[5]);
 /* Last error message of the calling thread ("" if none). */
 const char *matchy_amd_last_error(void);
 /* Deterministic builds for tests: fixes the build_epoch metadata value. */

@@ -110,7 +110,7 @@ def lib():
         "matchy_scanner_create": (vp, [vp, C.c_uint32, C.c_int32]),
         "matchy_scanner_free": (None, [vp]),
         "matchy_scanner_scan": (C.c_int32, [vp, cp, C.c_size_t, C.POINTER(_ScanResult)]),
-        "matchy_scanner_scan_device": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_bool, C.POINTER(_ScanResult)]),
+        "matchy_scanner_scan_device": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_uint32, C.POINTER(_ScanResult)]),
         "matchy_scan_result_free": (None, [C.POINTER(_ScanResult)]),
         "matchy_scan_hit_to_json": (vp, [vp, C.POINTER(_ScanResult), C.c_size_t, cp, cp]),
         "matchy_scanner_set_profile": (None, [vp, C.c_bool]),
@@ -333,17 +333,18 @@ class Scanner:
             raise RuntimeError(f"matchy_scanner_scan failed: rc={rc} {last_error()}")
         return ScanResult(self, raw)
 
-    def scan_device(self, device_ptr: int, nbytes: int, stream: int = 0, fetch_hits=True) -> ScanResult:
+    def scan_device(self, device_ptr: int, nbytes: int, stream: int = 0, fetch_mode=1) -> ScanResult:
+        """fetch_mode: 0 counters only, 1 hit records in device order, 3 hit records in canonical order."""
         raw = _ScanResult()
-        rc = lib().matchy_scanner_scan_device(self._h, device_ptr, nbytes, stream, fetch_hits, C.byref(raw))
+        rc = lib().matchy_scanner_scan_device(self._h, device_ptr, nbytes, stream, fetch_mode, C.byref(raw))
         if rc != 0:
             raise RuntimeError(f"matchy_scanner_scan_device failed: rc={rc} {last_error()}")
         return ScanResult(self, raw)
 
     def timing_ms(self):
-        out = (C.c_float * 4)()
+        out = (C.c_float * 5)()
         lib().matchy_scanner_get_timing(self._h, out)
-        return dict(tokenize=out[0], rare=out[1], lookup=out[2], total=out[3])
+        return dict(anchor=out[0], validate=out[1], rare=out[2], lookup=out[3], total=out[4])
 
     def close(self):
         if self._h:

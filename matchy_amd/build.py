@@ -8,7 +8,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libmatchy_amd.so"
-SOURCES = ["scan_kernels.hip", "engine.cpp", "db_image.cpp", "db_builder.cpp", "data_codec.cpp", "capi.cpp"]
+SOURCES = ["k_anchor.hip", "scan_kernels.hip", "engine.cpp", "db_image.cpp", "db_builder.cpp", "data_codec.cpp", "capi.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

@@ -138,12 +138,12 @@ matchy_t* open_bytes(std::vector<uint8_t>&& bytes) {
 }
 
 // Fill matchy_scan_result_t from a ScanOutput. `bases[i]` = absolute offset of the piece hit i came from.
-void fill_result(const DbImage& img, const ScanOutput& so, const std::vector<uint64_t>* bases, uint64_t bytes, matchy_scan_result_t* out) {
+void fill_result(const DbImage& img, const ScanOutput& so, const std::vector<uint64_t>* bases, uint64_t bytes, bool sorted, matchy_scan_result_t* out) {
     auto* in = new ScanResultInternal();
     std::vector<uint32_t> order(so.hits.size());
     for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
     auto abs_start = [&](uint32_t i) { return (uint64_t)so.hits[i].start + (bases ? (*bases)[i] : 0); };
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    if (sorted) std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         uint64_t sa = abs_start(a), sb = abs_start(b);
         if (sa != sb) return sa < sb;
         int ra = type_rank(so.hits[a].len_type >> 24), rb = type_rank(so.hits[b].len_type >> 24);
@@ -442,10 +442,10 @@ matchy_scanner_t* matchy_scanner_create(const matchy_t* dbc, uint32_t extract_fl
 }
 void matchy_scanner_free(matchy_scanner_t* s) { delete reinterpret_cast<ScannerH*>(s); }
 void matchy_scanner_set_profile(matchy_scanner_t* s, bool on) { if (s) reinterpret_cast<ScannerH*>(s)->sc->set_profile(on); }
-void matchy_scanner_get_timing(const matchy_scanner_t* s, float out[4]) {
+void matchy_scanner_get_timing(const matchy_scanner_t* s, float out[5]) {
     if (!s || !out) return;
     const ScanTiming& t = reinterpret_cast<const ScannerH*>(s)->sc->timing();
-    out[0] = t.tokenize_ms; out[1] = t.rare_ms; out[2] = t.lookup_ms; out[3] = t.total_ms;
+    out[0] = t.anchor_ms; out[1] = t.validate_ms; out[2] = t.rare_ms; out[3] = t.lookup_ms; out[4] = t.total_ms;
 }
 
 int32_t matchy_scanner_scan(matchy_scanner_t* s, const uint8_t* data, size_t len, matchy_scan_result_t* out) {
@@ -456,13 +456,13 @@ int32_t matchy_scanner_scan(matchy_scanner_t* s, const uint8_t* data, size_t len
         std::vector<uint64_t> bases;
         h->sc->scan_host(data, len, true, false, so, &bases);
         bases.resize(so.hits.size());
-        fill_result(h->sc->image(), so, &bases, len, out);
+        fill_result(h->sc->image(), so, &bases, len, true, out);
         return MATCHY_SUCCESS;
     } catch (const HipError& e) { set_error(e.what); return MATCHY_ERROR_IO; }
     catch (const std::exception& e) { set_error(e.what()); return MATCHY_ERROR_IO; }
 }
 
-int32_t matchy_scanner_scan_device(matchy_scanner_t* s, const void* dptr, size_t len, void* stream, bool fetch_hits, matchy_scan_result_t* out) {
+int32_t matchy_scanner_scan_device(matchy_scanner_t* s, const void* dptr, size_t len, void* stream, uint32_t fetch_mode, matchy_scan_result_t* out) {
     if (!s || !out || !dptr) return MATCHY_ERROR_INVALID_PARAM;
     if (len >= 0x7FFF0000ull) return MATCHY_ERROR_INVALID_PARAM;
     ScannerH* h = reinterpret_cast<ScannerH*>(s);
@@ -470,9 +470,9 @@ int32_t matchy_scanner_scan_device(matchy_scanner_t* s, const void* dptr, size_t
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st);
         ScanOutput so;
-        h->sc->fetch(so, false, st, fetch_hits);
-        fill_result(h->sc->image(), so, nullptr, len, out);
-        if (!fetch_hits) out->n_hits = so.n_hits;  // count only; `hits` stays empty
+        h->sc->fetch(so, false, st, (fetch_mode & 1) != 0);
+        fill_result(h->sc->image(), so, nullptr, len, (fetch_mode & 2) != 0, out);
+        if (!(fetch_mode & 1)) out->n_hits = so.n_hits;  // count only; `hits` stays empty
         return MATCHY_SUCCESS;
     } catch (const HipError& e) { set_error(e.what); return MATCHY_ERROR_IO; }
     catch (const std::exception& e) { set_error(e.what()); return MATCHY_ERROR_IO; }

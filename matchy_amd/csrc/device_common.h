@@ -1,0 +1,147 @@
+// Device-side helpers shared by the HIP kernels (byte classes, wave helpers, PSL probes).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hashes.h"
+#include "scan_types.h"
+
+namespace mxy {
+
+// ------------------------------------------------------------------------------------------------ byte classes
+constexpr uint32_t C_B = 1, C_DIG = 2, C_DOT = 4, C_COLON = 8, C_AT = 16, C_LD = 32, C_NL = 64, C_TLD1 = 128;
+
+// BOUNDARY_LOOKUP (ext:1568-1593) as a 128-bit bitmap
+constexpr uint64_t bnd_lo() {
+    uint64_t m = 0;
+    const int cs[] = {0x09, 0x0a, 0x0d, 0x20, 0x22, 0x27, 0x28, 0x29, 0x2c, 0x2f, 0x3a, 0x3b, 0x3c, 0x3d, 0x3e};
+    for (int c : cs) m |= 1ull << c;
+    return m;
+}
+constexpr uint64_t bnd_hi() {
+    uint64_t m = 0;
+    const int cs[] = {0x40, 0x5b, 0x5d, 0x7b, 0x7d};
+    for (int c : cs) m |= 1ull << (c - 64);
+    return m;
+}
+__device__ __forceinline__ bool d_is_boundary(uint32_t b) {
+    if (b >= 128) return false;
+    uint64_t m = b < 64 ? bnd_lo() : bnd_hi();
+    return (m >> (b & 63)) & 1;
+}
+__device__ __forceinline__ bool d_is_digit(uint32_t b) { return b - '0' < 10u; }
+__device__ __forceinline__ bool d_is_alpha(uint32_t b) { return (b | 0x20) - 'a' < 26u; }
+__device__ __forceinline__ bool d_is_alnum(uint32_t b) { return d_is_digit(b) || d_is_alpha(b); }
+__device__ __forceinline__ bool d_is_hex(uint32_t b) { return d_is_digit(b) || ((b | 0x20) - 'a' < 6u); }
+__device__ __forceinline__ bool d_is_domain_char_fast(uint32_t b) { return d_is_alnum(b) || b == '-' || b == '.' || b >= 0x80; }  // ext:1597-1629
+__device__ __forceinline__ bool d_is_domain_char(uint32_t b) { return d_is_alnum(b) || b == '-' || b == '.'; }                      // ext:1639
+__device__ __forceinline__ bool d_is_email_local(uint32_t b) { return d_is_alnum(b) || b == '.' || b == '-' || b == '_' || b == '+'; }  // ext:1644
+
+__device__ __forceinline__ uint32_t class_of(uint32_t b) {
+    uint32_t c = 0;
+    if (d_is_boundary(b)) c |= C_B;
+    if (d_is_digit(b)) c |= C_DIG;
+    if (b == '.') c |= C_DOT;
+    if (b == ':') c |= C_COLON;
+    if (b == '@') c |= C_AT;
+    if (d_is_alnum(b) || b >= 0x80) c |= C_LD;
+    if (b == '\n') c |= C_NL;
+    return c;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// Wave-private chunked list writer. A wave reserves CHUNK slots of a global list with ONE atomic and fills them with
+// ballot/mbcnt-compacted appends; slots it never fills are set to `sentinel` so readers can skip them. This keeps
+// the number of atomics on the shared list counter ~CHUNK/64 times lower than one atomic per append.
+template <class T, uint32_t CHUNK>
+struct ChunkWriter {
+    uint32_t base = 0xFFFFFFFFu;  // wave-uniform; 0xFFFFFFFF = no chunk yet
+    uint32_t used = 0;
+    uint32_t total = 0;           // entries really appended by this wave
+
+    __device__ __forceinline__ void pad_rest(T* out, uint32_t cap, const T& sentinel) {
+        if (base == 0xFFFFFFFFu) return;
+        for (uint32_t k = used + lane_id(); k < CHUNK; k += 64)
+            if (base + k < cap) out[base + k] = sentinel;
+        used = CHUNK;
+    }
+    // All lanes of the (converged) wave call this; lanes with emit=true store `v`.
+    __device__ __forceinline__ void append(bool emit, const T& v, T* out, uint32_t cap, uint32_t* counter, const T& sentinel) {
+        const uint64_t m = __ballot(emit);
+        if (m == 0) return;
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (base == 0xFFFFFFFFu || used + n > CHUNK) {
+            pad_rest(out, cap, sentinel);
+            uint32_t b = 0;
+            if (lane_id() == 0) b = atomicAdd(counter, CHUNK);
+            base = __builtin_amdgcn_readfirstlane(b);
+            used = 0;
+        }
+        if (emit) {
+            const uint32_t slot = base + used + (uint32_t)__popcll(m & lanemask_lt());
+            if (slot < cap) out[slot] = v;
+        }
+        used += n;
+        total += n;
+    }
+};
+
+struct LogView {
+    const uint8_t* p;
+    uint32_t len;
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return p[i]; }
+};
+
+// Rust core::str::from_utf8 acceptance
+__device__ inline bool d_valid_utf8(const uint8_t* s, uint32_t n) {
+    uint32_t i = 0;
+    while (i < n) {
+        uint32_t c = s[i];
+        if (c < 0x80) { ++i; continue; }
+        uint32_t l = (c >= 0xC2 && c <= 0xDF) ? 2 : (c >= 0xE0 && c <= 0xEF) ? 3 : (c >= 0xF0 && c <= 0xF4) ? 4 : 0;
+        if (l == 0 || i + l > n) return false;
+        uint32_t c1 = s[i + 1];
+        uint32_t lo = 0x80, hi = 0xBF;
+        if (c == 0xE0) lo = 0xA0;
+        if (c == 0xED) hi = 0x9F;
+        if (c == 0xF0) lo = 0x90;
+        if (c == 0xF4) hi = 0x8F;
+        if (c1 < lo || c1 > hi) return false;
+        for (uint32_t k = 2; k < l; ++k) if ((s[i + k] & 0xC0) != 0x80) return false;
+        i += l;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ PSL
+__device__ inline bool psl_contains(const DevDb& db, uint64_t h, const uint8_t* s, uint32_t n) {
+    uint32_t slot = (uint32_t)h & db.psl_mask;
+    for (;;) {
+        PslSlot e = db.psl_slots[slot];
+        if (e.len == 0) return false;
+        if (e.hash == h && e.len == n) {
+            const uint8_t* q = db.psl_pool + e.off;
+            bool eq = true;
+            for (uint32_t k = 0; k < n; ++k) if (q[k] != s[k]) { eq = false; break; }
+            if (eq) return true;
+        }
+        slot = (slot + 1) & db.psl_mask;
+    }
+}
+// find_valid_tld_suffix_bytes(..).is_some() (ext:1671-1692) over log[lo,hi): dots right-to-left, hash grows leftwards.
+__device__ inline bool psl_suffix_exists(const DevDb& db, const uint8_t* log, uint32_t lo, uint32_t hi) {
+    uint64_t rh = psl_hash_init();
+    for (uint32_t q = hi; q-- > lo;) {
+        uint32_t c = log[q];
+        if (c == '.') {
+            if (psl_contains(db, psl_hash_finish(rh), log + q + 1, hi - q - 1)) return true;
+        }
+        rh = psl_hash_step(rh, (uint8_t)c);
+    }
+    return false;
+}
+__device__ __forceinline__ uint32_t tld_hash_step(uint32_t h, uint32_t c) { return (h ^ c) * 16777619u; }
+__device__ __forceinline__ uint32_t tld_hash_bit(uint32_t h) { return (h ^ (h >> 15)) & (TLD_BLOOM_BITS - 1); }
+
+}  // namespace mxy

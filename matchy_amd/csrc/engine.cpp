@@ -90,6 +90,7 @@ PslHost* load_psl() {
         uint32_t bit = tld_hash(last, ll);
         h->bloom[bit >> 5] |= 1u << (bit & 31);
         h->max_tld_len = std::max<uint32_t>(h->max_tld_len, (uint32_t)ll);
+        if (ll) h->tld_first[last[0] >> 5] |= 1u << (last[0] & 31);
     }
     return h;
 }
@@ -156,6 +157,7 @@ void DeviceDb::upload(const DbImage& img, int dev) {
     bloom.upload(psl.bloom);
     view.psl_slots = psl_slots.p; view.psl_mask = psl.mask; view.psl_pool = psl_pool.p; view.tld_bloom = bloom.p;
     view.max_tld_len = psl.max_tld_len;
+    for (int k = 0; k < 8; ++k) view.tld_first[k] = psl.tld_first[k];
     bytes_uploaded += psl.slots.size() * sizeof(PslSlot) + psl.pool.size() + psl.bloom.size() * 4;
 }
 
@@ -171,6 +173,7 @@ Scanner::Scanner(std::shared_ptr<const DbImage> img, std::shared_ptr<DeviceDb> d
 }
 
 Scanner::~Scanner() {
+    if (pinned_hits_) (void)hipHostFree(pinned_hits_);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
 }
 
@@ -179,6 +182,9 @@ void Scanner::ensure_capacity(uint32_t len) {
     size_t want_r = std::max<size_t>(1024, (size_t)len / 256);
     if (cands_.n < want_c) { cands_.alloc(want_c); hits_.alloc(std::max<size_t>(1024, want_c / 4)); ids_.alloc(std::max<size_t>(1024, want_c / 4)); }
     if (rare_.n < want_r) rare_.alloc(want_r);
+    size_t want_a = std::max<size_t>(4096, (size_t)len / 32);
+    if (v4_list_.n < want_a) v4_list_.alloc(want_a);
+    if (dom_list_.n < want_a) dom_list_.alloc(want_a);
 }
 
 void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream) {
@@ -190,18 +196,23 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters), stream));
     TokParams tp{};
     tp.log = dptr; tp.len = len; tp.flags = flags_; tp.min_labels = min_labels_;
+    if (const char* dbg = getenv("MATCHY_AMD_DEBUG")) tp.debug = (uint32_t)atoi(dbg);
     tp.n_segs = (uint32_t)(((uint64_t)len + 1 + SEG_BYTES - 1) / SEG_BYTES);
     tp.cands = cands_.p; tp.cand_cap = (uint32_t)cands_.n;
     tp.rare = rare_.p; tp.rare_cap = (uint32_t)rare_.n;
+    tp.v4_list = v4_list_.p; tp.v4_cap = (uint32_t)v4_list_.n;
+    tp.dom_list = dom_list_.p; tp.dom_cap = (uint32_t)dom_list_.n;
     tp.counters = counters_.p;
-    int grid_tok = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * 4);
+    int grid_tok = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * 8);
     if (grid_tok < 1) grid_tok = 1;
     if (profile_) MXY_HIP(hipEventRecord(ev_[0], stream));
-    launch_tokenize(tp, ddb_->view, grid_tok, stream);
+    launch_anchor(tp, ddb_->view, grid_tok, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[1], stream));
-    bool rare_possible = (flags_ & (EX_IPV6 | EX_EMAILS | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
-    if (rare_possible) launch_rare(tp, ddb_->view, std::min(n_cu_, 256), stream);
+    if (flags_ & (EX_IPV4 | EX_DOMAINS)) launch_validate(tp, ddb_->view, n_cu_ * 8, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
+    bool rare_possible = (flags_ & (EX_IPV6 | EX_EMAILS | EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
+    if (rare_possible) launch_rare(tp, ddb_->view, std::min(n_cu_, 256), stream);
+    if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
     if (lookup) {
         LookupParams lp{};
         lp.log = dptr; lp.len = len; lp.cands = cands_.p; lp.cand_cap = (uint32_t)cands_.n;
@@ -209,7 +220,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         lp.counters = counters_.p;
         launch_lookup(lp, ddb_->view, n_cu_ * 4, stream);
     }
-    if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
+    if (profile_) MXY_HIP(hipEventRecord(ev_[4], stream));
 }
 
 void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, bool want_hits) {
@@ -217,12 +228,14 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, bool w
         MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
         MXY_HIP(hipStreamSynchronize(stream));
         const ScanCounters& c = host_counters_;
-        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_hits > hits_.n || c.n_ids > ids_.n;
+        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_v4 > v4_list_.n || c.n_dom > dom_list_.n;
         if (!over) break;
         if (single_) throw HipError{"lookup_one: work buffers overflow"};
         // grow and run again: the kernels count past the capacity without writing, so the counts are exact demands
         if (c.n_cand > cands_.n) cands_.alloc((size_t)c.n_cand + c.n_cand / 4 + 1024);
         if (c.n_rare > rare_.n) rare_.alloc((size_t)c.n_rare + c.n_rare / 4 + 1024);
+        if (c.n_v4 > v4_list_.n) v4_list_.alloc((size_t)c.n_v4 + c.n_v4 / 4 + 1024);
+        if (c.n_dom > dom_list_.n) dom_list_.alloc((size_t)c.n_dom + c.n_dom / 4 + 1024);
         if (c.n_hits > hits_.n || hits_.n < cands_.n / 4) hits_.alloc(std::max<size_t>((size_t)c.n_hits + c.n_hits / 4 + 1024, cands_.n / 4));
         if (c.n_ids > ids_.n) ids_.alloc((size_t)c.n_ids + c.n_ids / 4 + 1024);
         scan_device(last_ptr_, last_len_, last_lookup_, stream);
@@ -231,17 +244,24 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, bool w
     const ScanCounters& c = host_counters_;
     if (c.error & 1) throw HipError{"scan: a candidate matched more than MAX_GLOB_RESULTS glob patterns"};
     if (c.error & 2) throw HipError{"scan: a glob pattern nests more than MAX_GLOB_STARS '*' segments"};
-    out.lines = c.lines; out.n_cand = c.n_cand; out.n_hits = last_lookup_ ? c.n_hits : 0;
+    out.lines = c.lines; out.n_cand = single_ ? c.n_cand : c.cand_true; out.n_hits = last_lookup_ ? c.hits_true : 0;
     if (profile_) {
-        MXY_HIP(hipEventElapsedTime(&timing_.tokenize_ms, ev_[0], ev_[1]));
-        MXY_HIP(hipEventElapsedTime(&timing_.rare_ms, ev_[1], ev_[2]));
-        MXY_HIP(hipEventElapsedTime(&timing_.lookup_ms, ev_[2], ev_[3]));
-        MXY_HIP(hipEventElapsedTime(&timing_.total_ms, ev_[0], ev_[3]));
+        MXY_HIP(hipEventElapsedTime(&timing_.anchor_ms, ev_[0], ev_[1]));
+        MXY_HIP(hipEventElapsedTime(&timing_.validate_ms, ev_[1], ev_[2]));
+        MXY_HIP(hipEventElapsedTime(&timing_.rare_ms, ev_[2], ev_[3]));
+        MXY_HIP(hipEventElapsedTime(&timing_.lookup_ms, ev_[3], ev_[4]));
+        MXY_HIP(hipEventElapsedTime(&timing_.total_ms, ev_[0], ev_[4]));
     }
     out.hits.clear(); out.ids.clear(); out.cands.clear();
-    if (last_lookup_ && want_hits && c.n_hits) {
-        out.hits.resize(c.n_hits);
-        MXY_HIP(hipMemcpyAsync(out.hits.data(), hits_.p, (size_t)c.n_hits * sizeof(Hit), hipMemcpyDeviceToHost, stream));
+    const bool get_hits = last_lookup_ && want_hits && c.n_hits;
+    if (get_hits) {
+        // D2H into pinned memory (pageable destinations run at a fraction of the PCIe rate)
+        if (pinned_hits_n_ < c.n_hits) {
+            if (pinned_hits_) (void)hipHostFree(pinned_hits_);
+            pinned_hits_n_ = (size_t)c.n_hits + c.n_hits / 4 + 4096;
+            MXY_HIP(hipHostMalloc((void**)&pinned_hits_, pinned_hits_n_ * sizeof(Hit), hipHostMallocDefault));
+        }
+        MXY_HIP(hipMemcpyAsync(pinned_hits_, hits_.p, (size_t)c.n_hits * sizeof(Hit), hipMemcpyDeviceToHost, stream));
         if (c.n_ids) {
             out.ids.resize(c.n_ids);
             MXY_HIP(hipMemcpyAsync(out.ids.data(), ids_.p, (size_t)c.n_ids * 4, hipMemcpyDeviceToHost, stream));
@@ -252,6 +272,16 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, bool w
         MXY_HIP(hipMemcpyAsync(out.cands.data(), cands_.p, (size_t)c.n_cand * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
     }
     MXY_HIP(hipStreamSynchronize(stream));
+    // drop the padding slots of partially filled chunks
+    if (get_hits) {
+        out.hits.reserve(c.hits_true);
+        for (size_t r = 0; r < c.n_hits; ++r) if (pinned_hits_[r].kind != 0xFF) out.hits.push_back(pinned_hits_[r]);
+    }
+    if (!out.cands.empty()) {
+        size_t w = 0;
+        for (size_t r = 0; r < out.cands.size(); ++r) if (out.cands[r].len_type != 0xFFFFFFFFu) out.cands[w++] = out.cands[r];
+        out.cands.resize(w);
+    }
     for (auto& t : out.by_type) t = 0;
     if (want_cands) for (const Candidate& cd : out.cands) { uint32_t ty = cd.len_type >> 24; if (ty < IT_COUNT) out.by_type[ty]++; }
 }

@@ -13,7 +13,8 @@
 namespace mxy {
 
 // kernel launch wrappers (scan_kernels.hip)
-void launch_tokenize(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
+void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
+void launch_validate(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_lookup(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream);
 
@@ -31,6 +32,7 @@ struct PslHost {
     std::vector<uint8_t> pool;
     std::vector<uint32_t> bloom;
     uint32_t mask = 0, max_tld_len = 0;
+    uint32_t tld_first[8] = {0};
     static const PslHost& get();  // throws std::runtime_error if the container cannot be found
 };
 
@@ -64,7 +66,7 @@ struct DeviceDb {
     void upload(const DbImage& img, int dev);
 };
 
-struct ScanTiming { float tokenize_ms = 0, rare_ms = 0, lookup_ms = 0, total_ms = 0; };
+struct ScanTiming { float anchor_ms = 0, validate_ms = 0, rare_ms = 0, lookup_ms = 0, total_ms = 0; };
 
 struct ScanOutput {
     std::vector<Candidate> cands;  // filled only when requested
@@ -102,17 +104,20 @@ private:
     uint32_t flags_, min_labels_;
     DevBuf<Candidate> cands_;
     DevBuf<RareAnchor> rare_;
+    DevBuf<uint32_t> v4_list_, dom_list_;
     DevBuf<Hit> hits_;
     DevBuf<uint32_t> ids_;
     DevBuf<ScanCounters> counters_;
     DevBuf<uint8_t> staging_;  // scan_host only
+    Hit* pinned_hits_ = nullptr;
+    size_t pinned_hits_n_ = 0;
     ScanCounters host_counters_{};
     uint32_t last_len_ = 0;
     const uint8_t* last_ptr_ = nullptr;
     bool last_lookup_ = false;
     bool single_ = false;
     bool profile_ = false;
-    hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     ScanTiming timing_;
     int n_cu_ = 256;
 };

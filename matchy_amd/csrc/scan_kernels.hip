@@ -1,11 +1,9 @@
 // HIP kernels for the `matchy match` hot path on gfx950 (MI355X, wave64).
 //
-//   k_tokenize  stage A: coalesced 16 B/lane log reads -> per-byte class bytes staged in LDS -> per-lane anchor
-//               detection from a 5-byte class history -> anchors compacted into a per-wave LDS ring with
-//               ballot/mbcnt -> 64 anchors validated per round, one per lane (IPv4, domain, hex hashes);
-//               IPv6 / e-mail / crypto-token anchors are forwarded to the rare list.
-//   k_rare      stage A': validators that are rare in logs and heavy in registers (IPv6 text, e-mail, Base58Check,
-//               Bech32, EIP-55, Monero) — one lane per anchor.
+//   (k_anchor, stage A1, lives in k_anchor.hip: streaming pass that compacts anchors into per-type lists)
+//   k_validate  stage A2: one lane per IPv4 / domain anchor: dotted-quad parse; domain run + PSL + label rules.
+//   k_rare      stage A3: validators that are rare in logs and heavy in registers (IPv6 text, e-mail, hex hashes,
+//               Base58Check, Bech32, EIP-55, Monero) — one lane per anchor.
 //   k_lookup    stage B: one lane per candidate: MMDB trie walk / XXH64 literal probe / Aho-Corasick walk + glob
 //               verification, hits compacted with one atomic per wave.
 //
@@ -19,122 +17,10 @@
 #include "hashes.h"
 #include "scan_types.h"
 
+#include "device_common.h"
+
 namespace mxy {
 
-// ------------------------------------------------------------------------------------------------ byte classes
-constexpr uint32_t C_B = 1, C_DIG = 2, C_DOT = 4, C_COLON = 8, C_AT = 16, C_LD = 32, C_NL = 64;
-constexpr uint32_t T_V4 = 1, T_DOM = 2, T_V6 = 4, T_AT = 8, T_TOK = 16;
-
-// BOUNDARY_LOOKUP (ext:1568-1593) as a 128-bit bitmap
-constexpr uint64_t bnd_lo() {
-    uint64_t m = 0;
-    const int cs[] = {0x09, 0x0a, 0x0d, 0x20, 0x22, 0x27, 0x28, 0x29, 0x2c, 0x2f, 0x3a, 0x3b, 0x3c, 0x3d, 0x3e};
-    for (int c : cs) m |= 1ull << c;
-    return m;
-}
-constexpr uint64_t bnd_hi() {
-    uint64_t m = 0;
-    const int cs[] = {0x40, 0x5b, 0x5d, 0x7b, 0x7d};
-    for (int c : cs) m |= 1ull << (c - 64);
-    return m;
-}
-__device__ __forceinline__ bool d_is_boundary(uint32_t b) {
-    if (b >= 128) return false;
-    uint64_t m = b < 64 ? bnd_lo() : bnd_hi();
-    return (m >> (b & 63)) & 1;
-}
-__device__ __forceinline__ bool d_is_digit(uint32_t b) { return b - '0' < 10u; }
-__device__ __forceinline__ bool d_is_alpha(uint32_t b) { return (b | 0x20) - 'a' < 26u; }
-__device__ __forceinline__ bool d_is_alnum(uint32_t b) { return d_is_digit(b) || d_is_alpha(b); }
-__device__ __forceinline__ bool d_is_hex(uint32_t b) { return d_is_digit(b) || ((b | 0x20) - 'a' < 6u); }
-__device__ __forceinline__ bool d_is_domain_char_fast(uint32_t b) { return d_is_alnum(b) || b == '-' || b == '.' || b >= 0x80; }  // ext:1597-1629
-__device__ __forceinline__ bool d_is_domain_char(uint32_t b) { return d_is_alnum(b) || b == '-' || b == '.'; }                      // ext:1639
-__device__ __forceinline__ bool d_is_email_local(uint32_t b) { return d_is_alnum(b) || b == '.' || b == '-' || b == '_' || b == '+'; }  // ext:1644
-
-__device__ __forceinline__ uint32_t class_of(uint32_t b) {
-    uint32_t c = 0;
-    if (d_is_boundary(b)) c |= C_B;
-    if (d_is_digit(b)) c |= C_DIG;
-    if (b == '.') c |= C_DOT;
-    if (b == ':') c |= C_COLON;
-    if (b == '@') c |= C_AT;
-    if (d_is_alnum(b) || b >= 0x80) c |= C_LD;
-    if (b == '\n') c |= C_NL;
-    return c;
-}
-
-__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
-__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
-
-// Append one record per `emit` lane with a single atomic per wave. Returns the slot (or 0xFFFFFFFF).
-__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool emit) {
-    uint64_t m = __ballot(emit);
-    if (m == 0) return 0xFFFFFFFFu;
-    uint32_t leader = (uint32_t)__ffsll((unsigned long long)m) - 1;
-    uint32_t base = 0;
-    if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
-    return emit ? base + (uint32_t)__popcll(m & lanemask_lt()) : 0xFFFFFFFFu;
-}
-
-struct LogView {
-    const uint8_t* p;
-    uint32_t len;
-    __device__ __forceinline__ uint32_t at(uint32_t i) const { return p[i]; }
-    // byte at i, with the end of the buffer acting as a boundary (ext: `end < chunk.len()` checks)
-    __device__ __forceinline__ uint32_t at_or_space(uint32_t i) const { return i < len ? p[i] : (uint32_t)' '; }
-};
-
-// Rust core::str::from_utf8 acceptance
-__device__ bool d_valid_utf8(const uint8_t* s, uint32_t n) {
-    uint32_t i = 0;
-    while (i < n) {
-        uint32_t c = s[i];
-        if (c < 0x80) { ++i; continue; }
-        uint32_t l = (c >= 0xC2 && c <= 0xDF) ? 2 : (c >= 0xE0 && c <= 0xEF) ? 3 : (c >= 0xF0 && c <= 0xF4) ? 4 : 0;
-        if (l == 0 || i + l > n) return false;
-        uint32_t c1 = s[i + 1];
-        uint32_t lo = 0x80, hi = 0xBF;
-        if (c == 0xE0) lo = 0xA0;
-        if (c == 0xED) hi = 0x9F;
-        if (c == 0xF0) lo = 0x90;
-        if (c == 0xF4) hi = 0x8F;
-        if (c1 < lo || c1 > hi) return false;
-        for (uint32_t k = 2; k < l; ++k) if ((s[i + k] & 0xC0) != 0x80) return false;
-        i += l;
-    }
-    return true;
-}
-
-// ------------------------------------------------------------------------------------------------ PSL
-__device__ bool psl_contains(const DevDb& db, uint64_t h, const uint8_t* s, uint32_t n) {
-    uint32_t slot = (uint32_t)h & db.psl_mask;
-    for (;;) {
-        PslSlot e = db.psl_slots[slot];
-        if (e.len == 0) return false;
-        if (e.hash == h && e.len == n) {
-            const uint8_t* q = db.psl_pool + e.off;
-            bool eq = true;
-            for (uint32_t k = 0; k < n; ++k) if (q[k] != s[k]) { eq = false; break; }
-            if (eq) return true;
-        }
-        slot = (slot + 1) & db.psl_mask;
-    }
-}
-// find_valid_tld_suffix_bytes(..).is_some() (ext:1671-1692) over log[lo,hi): dots right-to-left, hash grows leftwards.
-__device__ bool psl_suffix_exists(const DevDb& db, const uint8_t* log, uint32_t lo, uint32_t hi) {
-    uint64_t rh = psl_hash_init();
-    for (uint32_t q = hi; q-- > lo;) {
-        uint32_t c = log[q];
-        if (c == '.') {
-            if (psl_contains(db, psl_hash_finish(rh), log + q + 1, hi - q - 1)) return true;
-        }
-        rh = psl_hash_step(rh, (uint8_t)c);
-    }
-    return false;
-}
-__device__ __forceinline__ uint32_t tld_hash_step(uint32_t h, uint32_t c) { return (h ^ c) * 16777619u; }
-__device__ __forceinline__ uint32_t tld_hash_bit(uint32_t h) { return (h ^ (h >> 15)) & (TLD_BLOOM_BITS - 1); }
 
 // ------------------------------------------------------------------------------------------------ stage A validators
 // IPv4 (ext:813-869, 1120-1179). `dot` is the first dot of a maximal [0-9.] run whose first octet has 1-3 digits and
@@ -222,203 +108,6 @@ __device__ bool all_hex(const LogView& lg, uint32_t s, uint32_t n) {
     return true;
 }
 
-// ------------------------------------------------------------------------------------------------ k_tokenize
-constexpr int TOK_WAVES = 4;
-constexpr uint32_t BLK_BYTES = 1024;        // bytes per wave iteration: one 16-byte load per lane
-constexpr uint32_t CS_PREFIX = 16;          // class bytes kept in front of the block (only the last 4 are used)
-constexpr uint32_t QCAP = 128;              // anchor ring entries per wave
-
-struct WaveCtx {
-    uint32_t* cs32;     // class stage of this wave (dwords)
-    uint2* queue;       // anchor ring of this wave
-    uint32_t q_head, q_tail;
-};
-
-__device__ void drain_round(const TokParams& p, const DevDb& db, const uint32_t* bloom, WaveCtx& w, uint32_t n) {
-    LogView lg{p.log, p.len};
-    uint32_t lane = lane_id();
-    uint2 ent = make_uint2(0, 0);
-    if (lane < n) ent = w.queue[(w.q_head + lane) & (QCAP - 1)];
-    w.q_head += n;
-    uint32_t types = lane < n ? (ent.y & 0xFF) : 0;
-    uint32_t toklen = ent.y >> 8;
-    uint32_t pos = ent.x;
-
-    while (__ballot(types != 0)) {
-        Candidate c{0, 0, 0, 0};
-        RareAnchor ra{0, 0, 0};
-        bool emit = false, emit_rare = false;
-        uint32_t t = types & (0u - types);  // lowest pending type of this lane
-        types &= ~t;
-        if (t == T_V4) {
-            uint32_t s, e, a;
-            if (val_ipv4(lg, pos, s, e, a)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV4 << 24); c.v4 = a; emit = true; }
-        } else if (t == T_DOM) {
-            uint32_t s, e;
-            if (val_domain(lg, db, bloom, p.min_labels, pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true; }
-        } else if (t == T_V6) {
-            ra.pos = pos; ra.kind = RARE_V6; emit_rare = true;
-        } else if (t == T_AT) {
-            ra.pos = pos; ra.kind = RARE_AT; emit_rare = true;
-        } else if (t == T_TOK) {
-            uint32_t s = pos - toklen;
-            // hashes: token length 32/40/64/96/128 and all hex (ext:1212-1250)
-            int ht = toklen == 32 ? IT_MD5 : toklen == 40 ? IT_SHA1 : toklen == 64 ? IT_SHA256 : toklen == 96 ? IT_SHA384 : toklen == 128 ? IT_SHA512 : -1;
-            if (ht >= 0 && (p.flags & EX_HASHES) && all_hex(lg, s, toklen)) { c.start = s; c.len_type = toklen | ((uint32_t)ht << 24); emit = true; }
-            // crypto tokens: cheap prefix filters here, checksums in k_rare (ext:1289-1307, 1331-1350, 1388-1397)
-            uint32_t b0 = lg.at(s), b1 = lg.at(s + 1), b2 = lg.at(s + 2);
-            bool btc = (p.flags & EX_BITCOIN) && toklen >= 26 && toklen <= 62 && ((b0 == 'b' && b1 == 'c' && b2 == '1') || b0 == '1' || b0 == '3');
-            bool eth = (p.flags & EX_ETHEREUM) && toklen == 42 && b0 == '0' && b1 == 'x';
-            bool xmr = (p.flags & EX_MONERO) && toklen >= 90 && toklen <= 110 && (b0 == '4' || b0 == '8');
-            if (btc || eth || xmr) { ra.pos = s; ra.len = toklen; ra.kind = RARE_TOK; emit_rare = true; }
-        }
-        uint32_t slot = wave_append(&p.counters->n_cand, emit);
-        if (emit && slot < p.cand_cap) p.cands[slot] = c;
-        uint32_t rslot = wave_append(&p.counters->n_rare, emit_rare);
-        if (emit_rare && rslot < p.rare_cap) p.rare[rslot] = ra;
-    }
-}
-
-__global__ __launch_bounds__(TOK_WAVES * 64) void k_tokenize(TokParams p, DevDb db) {
-    __shared__ uint8_t ctab[256];
-    __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
-    __shared__ uint32_t cstage[TOK_WAVES][(CS_PREFIX + BLK_BYTES) / 4];
-    __shared__ uint2 queues[TOK_WAVES][QCAP];
-
-    ctab[threadIdx.x] = (uint8_t)class_of(threadIdx.x);
-    for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += blockDim.x) bloom[i] = db.tld_bloom[i];
-    __syncthreads();
-
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t gw = blockIdx.x * TOK_WAVES + wave, nw = gridDim.x * TOK_WAVES;
-    WaveCtx w;
-    w.cs32 = cstage[wave];
-    w.queue = queues[wave];
-    w.q_head = w.q_tail = 0;
-    const uint32_t len = p.len;
-    const bool want_tok = (p.flags & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
-    uint32_t type_mask = 0;
-    if (p.flags & EX_IPV4) type_mask |= T_V4;
-    if (p.flags & EX_DOMAINS) type_mask |= T_DOM;
-    if (p.flags & EX_IPV6) type_mask |= T_V6;
-    if (p.flags & EX_EMAILS) type_mask |= T_AT;
-    if (want_tok) type_mask |= T_TOK;
-    unsigned long long lines = 0;
-    const uint32_t sh8 = (lane & 3) * 8;
-
-    for (uint32_t seg = gw; seg < p.n_segs; seg += nw) {
-        const uint32_t seg_start = seg * SEG_BYTES;
-        // positions 0..len are scanned: position `len` is the virtual boundary that closes a trailing token
-        const uint32_t seg_end = min(seg_start + SEG_BYTES, len + 1);
-        // ---- carry-in: classes of the 4 bytes before the segment, and the last boundary within 256 bytes
-        int32_t lastB;
-        if (seg_start == 0) {
-            lastB = -1;
-            if (lane == 0) w.cs32[CS_PREFIX / 4 - 1] = C_B * 0x01010101u;
-        } else {
-            lastB = (int32_t)seg_start - 257;  // "far": any token reaching back this far is longer than 128
-            for (uint32_t r = 0; r < 4; ++r) {
-                uint32_t base = seg_start - 256 + r * 64;
-                uint32_t c = ctab[p.log[base + lane]];
-                uint64_t bm = __ballot(c & C_B);
-                if (bm) lastB = (int32_t)(base + 63 - __clzll((unsigned long long)bm));
-            }
-            if (lane == 0) {
-                uint32_t pre = 0;
-                for (uint32_t k = 0; k < 4; ++k) pre |= (uint32_t)ctab[p.log[seg_start - 4 + k]] << (8 * k);
-                w.cs32[CS_PREFIX / 4 - 1] = pre;
-            }
-        }
-        for (uint32_t blk = seg_start; blk < seg_end; blk += BLK_BYTES) {
-            // ---- stage 1 KiB: coalesced 16 B per lane, bytes -> class bytes, one ds_write_b128 per lane
-            uint32_t pos0 = blk + lane * 16;
-            uint32_t wv[4];
-            if (pos0 + 16 <= len) {
-                uint4 v = *reinterpret_cast<const uint4*>(p.log + pos0);
-                wv[0] = v.x; wv[1] = v.y; wv[2] = v.z; wv[3] = v.w;
-            } else {
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t x = 0;
-                    for (int b = 0; b < 4; ++b) {
-                        uint32_t q = pos0 + k * 4 + b;
-                        x |= (q < len ? (uint32_t)p.log[q] : (uint32_t)' ') << (8 * b);
-                    }
-                    wv[k] = x;
-                }
-            }
-            uint32_t cv[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t x = wv[k];
-                cv[k] = (uint32_t)ctab[x & 0xFF] | ((uint32_t)ctab[(x >> 8) & 0xFF] << 8) | ((uint32_t)ctab[(x >> 16) & 0xFF] << 16) |
-                        ((uint32_t)ctab[x >> 24] << 24);
-            }
-            __builtin_amdgcn_wave_barrier();
-            *reinterpret_cast<uint4*>(&w.cs32[CS_PREFIX / 4 + lane * 4]) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-            __builtin_amdgcn_wave_barrier();
-
-            const uint32_t rows = min(16u, (seg_end - blk + 63) / 64);
-            for (uint32_t r = 0; r < rows; ++r) {
-                const uint32_t row_base = blk + r * 64;
-                const uint32_t j = row_base + lane;
-                const uint32_t di = (CS_PREFIX + r * 64 + lane) >> 2;
-                const uint32_t d1 = w.cs32[di], d0 = w.cs32[di - 1];
-                // hist bytes: [0]=class(j-4) [1]=class(j-3) [2]=class(j-2) [3]=class(j-1)
-                const uint32_t hist = __builtin_amdgcn_alignbyte(d1, d0, lane & 3);
-                const uint32_t c0 = (d1 >> sh8) & 0xFF;
-                const bool valid = j <= len;
-
-                lines += (unsigned long long)__popcll(__ballot((c0 & C_NL) && j < len));
-
-                uint32_t types = 0;
-                // T_DOM: label-char at j, '.' at j-1, label-char at j-2
-                if ((c0 & C_LD) && (hist & (C_DOT << 24)) && (hist & (C_LD << 16))) types |= T_DOM;
-                // T_V4: '.' at j preceded by 1-3 digits preceded by a boundary
-                if ((c0 & C_DOT) && (hist & (C_DIG << 24))) {
-                    bool ok = (hist & (C_B << 16)) || ((hist & (C_DIG << 16)) && ((hist & (C_B << 8)) || ((hist & (C_DIG << 8)) && (hist & C_B))));
-                    if (ok) types |= T_V4;
-                }
-                // T_V6: "::" ending at j, not preceded by a third ':'
-                if ((c0 & C_COLON) && (hist & (C_COLON << 24)) && !(hist & (C_COLON << 16))) types |= T_V6;
-                if (c0 & C_AT) types |= T_AT;
-                // T_TOK: boundary at j closing a token [lb+1, j) whose length passes the extractor length filters
-                const uint64_t bmask = __ballot(c0 & C_B);
-                uint32_t toklen = 0;
-                if (want_tok) {
-                    uint64_t m = bmask & lanemask_lt();
-                    int32_t lb = m ? (int32_t)(row_base + 63 - __clzll((unsigned long long)m)) : lastB;
-                    uint32_t tl = (uint32_t)((int32_t)j - 1 - lb);
-                    bool tokend = (c0 & C_B) && !(hist & (C_B << 24));
-                    bool lenok = (tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128;
-                    if (tokend && lenok) { types |= T_TOK; toklen = tl; }
-                }
-                if (bmask) lastB = (int32_t)(row_base + 63 - __clzll((unsigned long long)bmask));
-                types &= type_mask;
-                if (!valid) types = 0;
-
-                // ---- compact anchors into the ring
-                const uint64_t am = __ballot(types != 0);
-                if (am) {
-                    if (types) {
-                        uint32_t slot = (w.q_tail + (uint32_t)__popcll(am & lanemask_lt())) & (QCAP - 1);
-                        w.queue[slot] = make_uint2(j, types | (toklen << 8));
-                    }
-                    w.q_tail += (uint32_t)__popcll(am);
-                    __builtin_amdgcn_wave_barrier();
-                    if (w.q_tail - w.q_head >= 64) drain_round(p, db, bloom, w, 64);
-                }
-            }
-            // keep the last 4 class bytes as the next block's prefix
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) w.cs32[CS_PREFIX / 4 - 1] = w.cs32[(CS_PREFIX + BLK_BYTES) / 4 - 1];
-            __builtin_amdgcn_wave_barrier();
-        }
-        // anchors never wait across segments: the carry state is rebuilt per segment anyway
-        if (w.q_tail != w.q_head) drain_round(p, db, bloom, w, w.q_tail - w.q_head);
-    }
-    // one atomic per wave for the line count
-    if (lane == 0 && lines) atomicAdd(&p.counters->lines, lines);
-}
 
 // ------------------------------------------------------------------------------------------------ rare validators
 // Rust `<Ipv6Addr as FromStr>` restricted to [0-9A-Fa-f:] input (no embedded IPv4 possible): read_ipv6_addr.
@@ -678,52 +367,93 @@ __device__ bool val_eth(const uint8_t* a) {  // ext:1328-1361, 1840-1892: "0x" +
     return true;
 }
 
+// k_validate — stage A2: one lane per IPv4 / domain anchor written by k_anchor (lean kernel, high occupancy;
+// the dependent byte loads hit L2: anchors of one wave lie within a few KiB of each other).
+__global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
+    __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
+    for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += blockDim.x) bloom[i] = db.tld_bloom[i];
+    __syncthreads();
+    LogView lg{p.log, p.len};
+    ChunkWriter<Candidate, CAND_CHUNK> cw;
+    const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n4 = min(p.counters->n_v4, p.v4_cap);
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n4; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        Candidate c{0, 0, 0, 0};
+        bool emit = false;
+        const uint32_t a4 = i < n4 ? p.v4_list[i] : 0xFFFFFFFFu;
+        if (a4 != 0xFFFFFFFFu) {
+            uint32_t s, e, a;
+            if (val_ipv4(lg, a4, s, e, a)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV4 << 24); c.v4 = a; emit = true; }
+        }
+        cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+    }
+    const uint32_t nd = min(p.counters->n_dom, p.dom_cap);
+    for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        Candidate c{0, 0, 0, 0};
+        bool emit = false;
+        const uint32_t ad = i < nd ? p.dom_list[i] : 0xFFFFFFFFu;
+        if (ad != 0xFFFFFFFFu) {
+            uint32_t s, e;
+            if (val_domain(lg, db, bloom, p.min_labels, ad, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true; }
+        }
+        cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+    }
+    cw.pad_rest(p.cands, p.cand_cap, SC);
+    if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
+}
+
+// k_rare — stage A3: validators that are rare in logs and heavy in registers, one lane per rare anchor.
 __global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
     LogView lg{p.log, p.len};
+    ChunkWriter<Candidate, CAND_CHUNK> cw;
+    const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
     uint32_t n = min(p.counters->n_rare, p.rare_cap);
     for (uint32_t base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
         uint32_t i = base + threadIdx.x;
+        RareAnchor ra{0, 0xFF};
+        if (i < n) ra = p.rare[i];
+        const uint32_t kind = ra.len_kind & 0xFF, tl = ra.len_kind >> 8;
         Candidate c{0, 0, 0, 0};
         bool emit = false;
-        if (i < n) {
-            RareAnchor ra = p.rare[i];
-            if (ra.kind == RARE_V6) {
-                uint32_t s, e;
-                if (val_ipv6(lg, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV6 << 24); emit = true; }
-            } else if (ra.kind == RARE_AT) {
-                uint32_t s, e;
-                if (val_email(lg, db, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_EMAIL << 24); emit = true; }
-            }
+        if (kind == RARE_V6) {
+            uint32_t s, e;
+            if (val_ipv6(lg, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV6 << 24); emit = true; }
+        } else if (kind == RARE_AT) {
+            uint32_t s, e;
+            if (val_email(lg, db, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_EMAIL << 24); emit = true; }
         }
-        uint32_t slot = wave_append(&p.counters->n_cand, emit);
-        if (emit && slot < p.cand_cap) p.cands[slot] = c;
-        // tokens can yield up to three items (Bitcoin, Ethereum, Monero are independent extractors)
-        for (int which = 0; which < 3; ++which) {
+        cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+        // a token can yield up to four items: hash, Bitcoin, Ethereum, Monero are independent extractors
+        for (int which = 0; which < 4; ++which) {
             bool em = false;
             Candidate ct{0, 0, 0, 0};
-            if (i < n) {
-                RareAnchor ra = p.rare[i];
-                if (ra.kind == RARE_TOK) {
-                    const uint8_t* s = lg.p + ra.pos;
-                    uint32_t tl = ra.len;
-                    int ty = -1;
-                    // a token made of non-boundary bytes may contain high bytes; every accepted form is pure ASCII,
-                    // so the reference's from_utf8 precondition is implied by the per-symbol checks
-                    if (which == 0 && (p.flags & EX_BITCOIN) && tl >= 26 && tl <= 62) {
-                        if (s[0] == 'b' && s[1] == 'c' && s[2] == '1') { if (val_btc_bech32(s, tl)) ty = IT_BITCOIN; }
-                        else if (s[0] == '1' || s[0] == '3') { if (val_btc_base58(s, tl)) ty = IT_BITCOIN; }
-                    } else if (which == 1 && (p.flags & EX_ETHEREUM) && tl == 42 && s[0] == '0' && s[1] == 'x') {
-                        if (val_eth(s)) ty = IT_ETHEREUM;
-                    } else if (which == 2 && (p.flags & EX_MONERO) && tl >= 90 && tl <= 110 && (s[0] == '4' || s[0] == '8')) {
-                        if (val_monero(s, tl)) ty = IT_MONERO;
-                    }
-                    if (ty >= 0) { ct.start = ra.pos; ct.len_type = tl | ((uint32_t)ty << 24); em = true; }
+            if (kind == RARE_TOK) {
+                const uint8_t* s = lg.p + ra.pos;
+                int ty = -1;
+                // a token made of non-boundary bytes may contain high bytes; every accepted form is pure ASCII,
+                // so the reference's from_utf8 precondition is implied by the per-symbol checks
+                if (which == 0 && (p.flags & EX_HASHES)) {
+                    // hashes: token length 32/40/64/96/128 and all hex (ext:1212-1250)
+                    int ht = tl == 32 ? IT_MD5 : tl == 40 ? IT_SHA1 : tl == 64 ? IT_SHA256 : tl == 96 ? IT_SHA384 : tl == 128 ? IT_SHA512 : -1;
+                    if (ht >= 0 && all_hex(lg, ra.pos, tl)) ty = ht;
+                } else if (which == 1 && (p.flags & EX_BITCOIN) && tl >= 26 && tl <= 62) {
+                    if (s[0] == 'b' && s[1] == 'c' && s[2] == '1') { if (val_btc_bech32(s, tl)) ty = IT_BITCOIN; }
+                    else if (s[0] == '1' || s[0] == '3') { if (val_btc_base58(s, tl)) ty = IT_BITCOIN; }
+                } else if (which == 2 && (p.flags & EX_ETHEREUM) && tl == 42 && s[0] == '0' && s[1] == 'x') {
+                    if (val_eth(s)) ty = IT_ETHEREUM;
+                } else if (which == 3 && (p.flags & EX_MONERO) && tl >= 90 && tl <= 110 && (s[0] == '4' || s[0] == '8')) {
+                    if (val_monero(s, tl)) ty = IT_MONERO;
                 }
+                if (ty >= 0) { ct.start = ra.pos; ct.len_type = tl | ((uint32_t)ty << 24); em = true; }
             }
-            uint32_t sl = wave_append(&p.counters->n_cand, em);
-            if (em && sl < p.cand_cap) p.cands[sl] = ct;
+            cw.append(em, ct, p.cands, p.cand_cap, &p.counters->n_cand, SC);
         }
     }
+    cw.pad_rest(p.cands, p.cand_cap, SC);
+    if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
 }
 
 // ------------------------------------------------------------------------------------------------ stage B: lookups
@@ -942,18 +672,24 @@ __device__ uint32_t glob_find_all(const DevDb& db, const uint8_t* text, uint32_t
     return n;
 }
 
+// GLOB=false instantiation (databases without a PARAGLOB section) carries no glob state and stays register-lean.
+template <bool GLOB>
 __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
     uint32_t n = min(p.counters->n_cand, p.cand_cap);
     uint32_t stride = gridDim.x * blockDim.x;
-    // loop bound is wave-uniform so that wave_append sees converged waves
+    ChunkWriter<Hit, HIT_CHUNK> cw;
+    Hit SH{};
+    SH.kind = 0xFF;
+    // loop bound is wave-uniform so that the chunk writer sees converged waves
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
         uint32_t i = base + threadIdx.x;
         Hit h{};
         bool emit = false;
-        uint32_t globs[MAX_GLOB_RESULTS];
+        uint32_t globs[GLOB ? MAX_GLOB_RESULTS : 1];
         uint32_t ng = 0;
-        if (i < n) {
-            Candidate c = p.cands[i];
+        Candidate c{0, 0xFFFFFFFFu, 0, 0};
+        if (i < n) c = p.cands[i];
+        if (c.len_type != 0xFFFFFFFFu) {
             uint32_t type = c.len_type >> 24, tl = c.len_type & 0xFFFFFF;
             const uint8_t* text = p.log + c.start;
             h.cand = i; h.start = c.start; h.len_type = c.len_type;
@@ -967,29 +703,31 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
             } else {
                 uint32_t pid = 0xFFFFFFFFu;
                 if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q)) pid = q; }
-                if (db.has_glob) ng = glob_find_all(db, text, tl, globs, &p.counters->error);
+                if constexpr (GLOB) ng = glob_find_all(db, text, tl, globs, &p.counters->error);
                 if (pid != 0xFFFFFFFFu || ng) { h.kind = 3; h.a = pid; h.n_globs = (uint16_t)ng; emit = true; }
             }
         }
-        if (emit && ng) {
+        if (GLOB && emit && ng) {
             uint32_t io = atomicAdd(&p.counters->n_ids, ng);
             h.ids_off = io;
             for (uint32_t k = 0; k < ng; ++k) if (io + k < p.ids_cap) p.ids[io + k] = globs[k];
         }
-        uint32_t slot = wave_append(&p.counters->n_hits, emit);
-        if (emit && slot < p.hit_cap) p.hits[slot] = h;
+        cw.append(emit, h, p.hits, p.hit_cap, &p.counters->n_hits, SH);
     }
+    cw.pad_rest(p.hits, p.hit_cap, SH);
+    if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->hits_true, cw.total);
 }
 
 // ------------------------------------------------------------------------------------------------ launch wrappers
-void launch_tokenize(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_tokenize, dim3(grid), dim3(TOK_WAVES * 64), 0, stream, p, db);
+void launch_validate(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_validate, dim3(grid), dim3(256), 0, stream, p, db);
 }
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_rare, dim3(grid), dim3(64), 0, stream, p, db);
 }
 void launch_lookup(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_lookup, dim3(grid), dim3(256), 0, stream, p, db);
+    if (db.has_glob) hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(256), 0, stream, p, db);
+    else hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(256), 0, stream, p, db);
 }
 
 }  // namespace mxy

@@ -25,12 +25,11 @@ struct Candidate {
     uint32_t pad;
 };
 
-// Anchors that need the rare-path validators (IPv6, e-mail, crypto tokens), 12 bytes.
+// Anchors that need the rare-path validators (IPv6, e-mail, hash / crypto tokens), 8 bytes.
 enum RareKind : uint32_t { RARE_V6 = 0, RARE_AT = 1, RARE_TOK = 2 };
 struct RareAnchor {
-    uint32_t pos;   // RARE_V6: index of the 2nd ':' of a "::"; RARE_AT: index of '@'; RARE_TOK: token start
-    uint32_t len;   // RARE_TOK: token length
-    uint32_t kind;
+    uint32_t pos;       // RARE_V6: index of the 2nd ':' of a "::"; RARE_AT: index of '@'; RARE_TOK: token start
+    uint32_t len_kind;  // RareKind in bits 0..7, token length in bits 8..31
 };
 
 // One database hit, 24 bytes. For IP hits `a` is the data-section offset; for pattern hits `a` is the literal
@@ -80,6 +79,7 @@ struct DevDb {
     const uint8_t* psl_pool;
     const uint32_t* tld_bloom;    // TLD_BLOOM_WORDS words: bloom over the LAST labels of all suffixes
     uint32_t max_tld_len;
+    uint32_t tld_first[8];        // 256-bit set: bytes that start the last label of at least one suffix
 };
 
 constexpr uint32_t TLD_BLOOM_BITS = 32768;
@@ -89,9 +89,13 @@ struct ScanCounters {
     unsigned long long lines;        // '\n' bytes
     uint32_t n_cand;                 // candidates appended (may exceed capacity → overflow)
     uint32_t n_rare;
+    uint32_t n_v4;                   // IPv4 anchors (first dot of a digit run that follows a boundary)
+    uint32_t n_dom;                  // domain anchors (first byte of a label that follows a dot)
     uint32_t n_hits;
     uint32_t n_ids;
     uint32_t error;                  // bit0: glob result list overflow, bit1: glob star-stack overflow
+    uint32_t cand_true;              // candidates really written (n_cand counts chunk-allocated slots incl. padding)
+    uint32_t hits_true;
     uint32_t pad;
 };
 
@@ -100,11 +104,16 @@ struct TokParams {
     uint32_t len;
     uint32_t flags;           // ExtractFlags
     uint32_t min_labels;
+    uint32_t debug;           // profiling only: bit0 = drop anchors instead of validating them
     uint32_t n_segs;
     Candidate* cands;
     uint32_t cand_cap;
     RareAnchor* rare;
     uint32_t rare_cap;
+    uint32_t* v4_list;        // anchor positions written by k_anchor, consumed by k_validate
+    uint32_t v4_cap;
+    uint32_t* dom_list;
+    uint32_t dom_cap;
     ScanCounters* counters;
 };
 
@@ -120,6 +129,9 @@ struct LookupParams {
     ScanCounters* counters;
 };
 
+// Output lists are filled through wave-private chunks (one atomic per chunk, not per append); unused slots of a
+// chunk hold a sentinel (anchor 0xFFFFFFFF, Candidate.len_type 0xFFFFFFFF, RareAnchor kind 0xFF, Hit.kind 0xFF).
+constexpr uint32_t ANCHOR_CHUNK = 1024, RARE_CHUNK = 64, CAND_CHUNK = 512, HIT_CHUNK = 256;
 constexpr uint32_t SEG_BYTES = 16384;  // bytes of log per wavefront work item
 constexpr uint32_t MAX_GLOB_RESULTS = 32;
 constexpr uint32_t MAX_GLOB_STARS = 24;
