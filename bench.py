@@ -87,7 +87,10 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts0 = time.perf_counter()
         counts = step()
+        if os.environ.get("BENCH_DEBUG"):
+            print(f"step {1e3 * (time.perf_counter() - ts0):.3f} ms", file=sys.stderr)
         t = scanner.timing_ms()
         tok_ms.append(t["anchor"]); look_ms.append(t["lookup"]); rare_ms.append(t["rare"]); val_ms.append(t["validate"])
     barrier()

@@ -208,10 +208,10 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     if (profile_) MXY_HIP(hipEventRecord(ev_[0], stream));
     launch_anchor(tp, ddb_->view, grid_tok, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[1], stream));
-    if (flags_ & (EX_IPV4 | EX_DOMAINS)) launch_validate(tp, ddb_->view, n_cu_ * 8, stream);
+    if (flags_ & (EX_IPV4 | EX_DOMAINS | EX_IPV6 | EX_EMAILS)) launch_validate(tp, ddb_->view, n_cu_ * 8, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
-    bool rare_possible = (flags_ & (EX_IPV6 | EX_EMAILS | EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
-    if (rare_possible) launch_rare(tp, ddb_->view, std::min(n_cu_, 256), stream);
+    bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
+    if (rare_possible) launch_rare(tp, ddb_->view, n_cu_ * 4, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
     if (lookup) {
         LookupParams lp{};

@@ -401,21 +401,13 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         }
         cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     }
-    cw.pad_rest(p.cands, p.cand_cap, SC);
-    if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
-}
-
-// k_rare — stage A3: validators that are rare in logs and heavy in registers, one lane per rare anchor.
-__global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
-    LogView lg{p.log, p.len};
-    ChunkWriter<Candidate, CAND_CHUNK> cw;
-    const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
-    uint32_t n = min(p.counters->n_rare, p.rare_cap);
-    for (uint32_t base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
-        uint32_t i = base + threadIdx.x;
+    // IPv6 ("::") and e-mail ('@') anchors from the rare list
+    const uint32_t nr = min(p.counters->n_rare, p.rare_cap);
+    for (uint32_t base = blockIdx.x * blockDim.x; base < nr; base += stride) {
+        const uint32_t i = base + threadIdx.x;
         RareAnchor ra{0, 0xFF};
-        if (i < n) ra = p.rare[i];
-        const uint32_t kind = ra.len_kind & 0xFF, tl = ra.len_kind >> 8;
+        if (i < nr) ra = p.rare[i];
+        const uint32_t kind = ra.len_kind & 0xFF;
         Candidate c{0, 0, 0, 0};
         bool emit = false;
         if (kind == RARE_V6) {
@@ -426,6 +418,24 @@ __global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
             if (val_email(lg, db, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_EMAIL << 24); emit = true; }
         }
         cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+    }
+    cw.pad_rest(p.cands, p.cand_cap, SC);
+    if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
+}
+
+// k_rare — stage A3: token validators (hex hashes, Base58Check, Bech32, EIP-55, Monero): rare in logs and heavy in
+// registers, one lane per token anchor of the rare list.
+__global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
+    LogView lg{p.log, p.len};
+    ChunkWriter<Candidate, CAND_CHUNK> cw;
+    const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
+    uint32_t n = min(p.counters->n_rare, p.rare_cap);
+    for (uint32_t base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
+        uint32_t i = base + threadIdx.x;
+        RareAnchor ra{0, 0xFF};
+        if (i < n) ra = p.rare[i];
+        const uint32_t kind = ra.len_kind & 0xFF, tl = ra.len_kind >> 8;
+        if (__ballot(kind == RARE_TOK) == 0) continue;  // IPv6 / e-mail anchors are handled by k_validate
         // a token can yield up to four items: hash, Bitcoin, Ethereum, Monero are independent extractors
         for (int which = 0; which < 4; ++which) {
             bool em = false;
