@@ -175,7 +175,8 @@ void matchy_scanner_free(matchy_scanner_t *scanner);
 int32_t matchy_scanner_scan(matchy_scanner_t *scanner, const uint8_t *data, size_t len, matchy_scan_result_t *out);
 /* Scan bytes that are already resident in device memory (16-byte aligned, len < 2^31) on `hip_stream`
  * (a hipStream_t, NULL = default stream). fetch_mode: 0 = only counters are read back (n_hits is set, hits is NULL),
- * 1 = hit records in device order (like the reference, whose result order is unspecified), 3 = canonical order. */
+ * 1 = hit records in device order (like the reference, whose result order is unspecified); the arrays are BORROWED
+ * from the scanner and stay valid until its next scan or matchy_scanner_free; 3 = owned copy in canonical order. */
 #define MATCHY_SCAN_FETCH_COUNTS 0u
 #define MATCHY_SCAN_FETCH_HITS 1u
 #define MATCHY_SCAN_FETCH_SORTED 3u

@@ -2,6 +2,7 @@
 #include "../../include/matchy_amd.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -137,49 +138,36 @@ matchy_t* open_bytes(std::vector<uint8_t>&& bytes) {
     catch (const std::exception& e) { set_error(e.what()); return nullptr; }
 }
 
-// Fill matchy_scan_result_t from a ScanOutput. `bases[i]` = absolute offset of the piece hit i came from.
-void fill_result(const DbImage& img, const ScanOutput& so, const std::vector<uint64_t>* bases, uint64_t bytes, bool sorted, matchy_scan_result_t* out) {
-    auto* in = new ScanResultInternal();
-    std::vector<uint32_t> order(so.hits.size());
-    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
-    auto abs_start = [&](uint32_t i) { return (uint64_t)so.hits[i].start + (bases ? (*bases)[i] : 0); };
-    if (sorted) std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        uint64_t sa = abs_start(a), sb = abs_start(b);
-        if (sa != sb) return sa < sb;
-        int ra = type_rank(so.hits[a].len_type >> 24), rb = type_rank(so.hits[b].len_type >> 24);
-        if (ra != rb) return ra < rb;
-        return (so.hits[a].len_type & 0xFFFFFF) < (so.hits[b].len_type & 0xFFFFFF);
-    });
-    for (uint32_t oi : order) {
-        const Hit& h = so.hits[oi];
-        matchy_scan_hit_t m{};
-        m.start = abs_start(oi);
-        m.end = m.start + (h.len_type & 0xFFFFFF);
-        m.item_type = (uint8_t)(h.len_type >> 24);
-        m.kind = h.kind;
-        m.prefix_len = h.prefix_len;
-        if (h.kind == 2) {
-            m.data_offset = h.a;
-        } else {
-            // Database::lookup_string_uncached (database.rs:911-981): literal id (only if it has a data offset), then globs
-            m.ids_index = (uint32_t)in->ids.size();
-            if (h.a != 0xFFFFFFFFu) {
-                uint32_t off;
-                if (img.lit_data_offset(h.a, off)) { in->ids.push_back(h.a); in->offs.push_back(off); }
-            }
-            for (uint32_t k = 0; k < h.n_globs; ++k) {
-                uint32_t pid = so.ids[h.ids_off + k], off;
-                in->ids.push_back(pid);
-                in->offs.push_back(img.glob_data_offset(pid, off) ? (int64_t)off : -1);
-            }
-            m.n_ids = (uint32_t)in->ids.size() - m.ids_index;
-            if (m.n_ids == 0) continue;  // literal without mapping and no glob: NotFound in the reference
-        }
-        in->hits.push_back(m);
+static_assert(sizeof(FinalHit) == sizeof(matchy_scan_hit_t) && offsetof(FinalHit, data_offset) == offsetof(matchy_scan_hit_t, data_offset) &&
+                  offsetof(FinalHit, ids_index) == offsetof(matchy_scan_hit_t, ids_index) && offsetof(FinalHit, kind) == offsetof(matchy_scan_hit_t, kind),
+              "k_pack writes matchy_scan_hit_t records");
+
+// Hand the dense records to the caller. borrowed=true: pointers go straight to the scanner's pinned buffers (no per-hit
+// host work at all); otherwise the arrays are copied into the result and optionally put into canonical order.
+void fill_result(const FinalHit* fin, size_t n_fin, const uint32_t* ids, const long long* offs, size_t n_ids, uint64_t lines, uint64_t cands,
+                 uint64_t bytes, bool borrowed, bool sorted, matchy_scan_result_t* out) {
+    memset(out, 0, sizeof(*out));
+    out->lines = lines; out->candidates = cands; out->bytes = bytes;
+    out->n_hits = n_fin; out->n_ids = n_ids;
+    if (borrowed) {
+        out->hits = reinterpret_cast<const matchy_scan_hit_t*>(fin);
+        out->pattern_ids = ids;
+        out->data_offsets = reinterpret_cast<const int64_t*>(offs);
+        return;
     }
-    out->hits = in->hits.data(); out->n_hits = in->hits.size();
-    out->pattern_ids = in->ids.data(); out->data_offsets = in->offs.data(); out->n_ids = in->ids.size();
-    out->lines = so.lines; out->candidates = so.n_cand; out->bytes = bytes;
+    auto* in = new ScanResultInternal();
+    in->hits.resize(n_fin);
+    if (n_fin) memcpy(in->hits.data(), fin, n_fin * sizeof(FinalHit));
+    in->ids.assign(ids, ids + n_ids);
+    in->offs.assign(offs, offs + n_ids);
+    if (sorted) std::sort(in->hits.begin(), in->hits.end(), [](const matchy_scan_hit_t& a, const matchy_scan_hit_t& b) {
+        if (a.start != b.start) return a.start < b.start;
+        int ra = type_rank(a.item_type), rb = type_rank(b.item_type);
+        if (ra != rb) return ra < rb;
+        return a.end < b.end;
+    });
+    out->hits = in->hits.data();
+    out->pattern_ids = in->ids.data(); out->data_offsets = in->offs.data();
     out->_internal = in;
 }
 
@@ -380,11 +368,11 @@ int32_t matchy_extractor_extract_chunk(const matchy_extractor_t* ec, const uint8
         std::lock_guard<std::mutex> lk(e->mu);
         ScanOutput so;
         std::vector<uint64_t> bases;
-        e->scanner->scan_host(data, len, false, true, so, &bases);
+        e->scanner->scan_host(data, len, false, true, so, &bases, nullptr, nullptr, nullptr);
         size_t nc = so.cands.size();
         std::vector<uint32_t> order(nc);
         for (uint32_t i = 0; i < nc; ++i) order[i] = i;
-        auto abs_start = [&](uint32_t i) { return (uint64_t)so.cands[i].start + bases[so.hits.size() + i]; };
+        auto abs_start = [&](uint32_t i) { return (uint64_t)so.cands[i].start + bases[i]; };
         std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
             int ra = type_rank(so.cands[a].len_type >> 24), rb = type_rank(so.cands[b].len_type >> 24);
             if (ra != rb) return ra < rb;
@@ -453,10 +441,11 @@ int32_t matchy_scanner_scan(matchy_scanner_t* s, const uint8_t* data, size_t len
     ScannerH* h = reinterpret_cast<ScannerH*>(s);
     try {
         ScanOutput so;
-        std::vector<uint64_t> bases;
-        h->sc->scan_host(data, len, true, false, so, &bases);
-        bases.resize(so.hits.size());
-        fill_result(h->sc->image(), so, &bases, len, true, out);
+        std::vector<FinalHit> fin;
+        std::vector<uint32_t> fids;
+        std::vector<long long> foffs;
+        h->sc->scan_host(data, len, true, false, so, nullptr, &fin, &fids, &foffs);
+        fill_result(fin.data(), fin.size(), fids.data(), foffs.data(), fids.size(), so.lines, so.n_cand, len, false, true, out);
         return MATCHY_SUCCESS;
     } catch (const HipError& e) { set_error(e.what); return MATCHY_ERROR_IO; }
     catch (const std::exception& e) { set_error(e.what()); return MATCHY_ERROR_IO; }
@@ -470,9 +459,10 @@ int32_t matchy_scanner_scan_device(matchy_scanner_t* s, const void* dptr, size_t
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st);
         ScanOutput so;
-        h->sc->fetch(so, false, st, (fetch_mode & 1) != 0);
-        fill_result(h->sc->image(), so, nullptr, len, (fetch_mode & 2) != 0, out);
-        if (!(fetch_mode & 1)) out->n_hits = so.n_hits;  // count only; `hits` stays empty
+        h->sc->fetch(so, false, st, (fetch_mode & 1) ? HITS_FINAL : HITS_NONE);
+        const bool sorted = (fetch_mode & 2) != 0;
+        fill_result(so.fin, so.n_fin, so.fin_ids, so.fin_offs, so.n_fin_ids, so.lines, so.n_cand, len, !sorted, sorted, out);
+        if (!(fetch_mode & 1)) out->n_hits = so.n_hits;  // count only; `hits` stays NULL
         return MATCHY_SUCCESS;
     } catch (const HipError& e) { set_error(e.what); return MATCHY_ERROR_IO; }
     catch (const std::exception& e) { set_error(e.what()); return MATCHY_ERROR_IO; }

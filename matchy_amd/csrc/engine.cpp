@@ -152,6 +152,29 @@ void DeviceDb::upload(const DbImage& img, int dev) {
         view.lit2pat_off = lit2pat_off.p; view.lit2pat = lit2pat.p; view.n_ac_lits = (uint32_t)off.size() - 1;
         bytes_uploaded += pv.size() + (off.size() + ids.size()) * 4;
     }
+    {
+        // pattern id -> data offset tables for k_pack
+        std::vector<uint32_t> lo, go;
+        if (img.has_literal) {
+            if (!img.lit_data_offsets.empty()) lo = img.lit_data_offsets;
+            else {
+                uint32_t mx = 0;
+                for (auto& kv : img.lit_data_map) mx = std::max(mx, kv.first + 1);
+                lo.assign(mx, 0xFFFFFFFFu);
+                for (auto& kv : img.lit_data_map) lo[kv.first] = kv.second;
+            }
+        }
+        if (img.has_glob) {
+            go.resize(img.pdm_count);
+            if (img.pdm_count) memcpy(go.data(), img.bytes.data() + img.pdm_off, img.pdm_count * 4);
+        }
+        if (lo.empty()) lo.push_back(0xFFFFFFFFu);
+        if (go.empty()) go.push_back(0);
+        n_lit_offsets = img.has_literal ? (uint32_t)lo.size() : 0;
+        n_glob_offsets = img.has_glob ? (uint32_t)img.pdm_count : 0;
+        lit_offsets.upload(lo);
+        glob_offsets.upload(go);
+    }
     psl_slots.upload(psl.slots);
     psl_pool.upload(psl.pool);
     bloom.upload(psl.bloom);
@@ -173,7 +196,7 @@ Scanner::Scanner(std::shared_ptr<const DbImage> img, std::shared_ptr<DeviceDb> d
 }
 
 Scanner::~Scanner() {
-    if (pinned_hits_) (void)hipHostFree(pinned_hits_);
+    if (pinned_) (void)hipHostFree(pinned_);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
 }
 
@@ -182,6 +205,9 @@ void Scanner::ensure_capacity(uint32_t len) {
     size_t want_r = std::max<size_t>(1024, (size_t)len / 256);
     if (cands_.n < want_c) { cands_.alloc(want_c); hits_.alloc(std::max<size_t>(1024, want_c / 4)); ids_.alloc(std::max<size_t>(1024, want_c / 4)); }
     if (rare_.n < want_r) rare_.alloc(want_r);
+    if (tok_.n < want_r) tok_.alloc(want_r);
+    if (final_.n < hits_.n) { final_.alloc(hits_.n); }
+    if (final_ids_.n < hits_.n + ids_.n) { final_ids_.alloc(hits_.n + ids_.n); final_offs_.alloc(hits_.n + ids_.n); }
     size_t want_a = std::max<size_t>(4096, (size_t)len / 32);
     if (v4_list_.n < want_a) v4_list_.alloc(want_a);
     if (dom_list_.n < want_a) dom_list_.alloc(want_a);
@@ -200,6 +226,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.n_segs = (uint32_t)(((uint64_t)len + 1 + SEG_BYTES - 1) / SEG_BYTES);
     tp.cands = cands_.p; tp.cand_cap = (uint32_t)cands_.n;
     tp.rare = rare_.p; tp.rare_cap = (uint32_t)rare_.n;
+    tp.tok = tok_.p; tp.tok_cap = (uint32_t)tok_.n;
     tp.v4_list = v4_list_.p; tp.v4_cap = (uint32_t)v4_list_.n;
     tp.dom_list = dom_list_.p; tp.dom_cap = (uint32_t)dom_list_.n;
     tp.counters = counters_.p;
@@ -219,32 +246,51 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         lp.hits = hits_.p; lp.hit_cap = (uint32_t)hits_.n; lp.ids = ids_.p; lp.ids_cap = (uint32_t)ids_.n;
         lp.counters = counters_.p;
         launch_lookup(lp, ddb_->view, n_cu_ * 4, stream);
+        PackParams pp{};
+        pp.hits = hits_.p; pp.hit_cap = (uint32_t)hits_.n; pp.ids = ids_.p; pp.ids_cap = (uint32_t)ids_.n;
+        pp.lit_offsets = ddb_->lit_offsets.p; pp.n_lit = ddb_->n_lit_offsets;
+        pp.glob_offsets = ddb_->glob_offsets.p; pp.n_glob = ddb_->n_glob_offsets;
+        pp.out = final_.p; pp.out_cap = (uint32_t)final_.n;
+        pp.out_ids = final_ids_.p; pp.out_offs = final_offs_.p; pp.out_ids_cap = (uint32_t)final_ids_.n;
+        pp.counters = counters_.p;
+        launch_pack(pp, n_cu_ * 2, stream);
     }
     if (profile_) MXY_HIP(hipEventRecord(ev_[4], stream));
 }
 
-void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, bool want_hits) {
+void Scanner::ensure_pinned(size_t bytes) {
+    if (pinned_bytes_ >= bytes) return;
+    if (pinned_) (void)hipHostFree(pinned_);
+    pinned_bytes_ = bytes + bytes / 4 + (1 << 16);
+    MXY_HIP(hipHostMalloc(&pinned_, pinned_bytes_, hipHostMallocDefault));
+}
+
+void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode) {
     for (int attempt = 0; attempt < 6; ++attempt) {
         MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
         MXY_HIP(hipStreamSynchronize(stream));
         const ScanCounters& c = host_counters_;
-        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_v4 > v4_list_.n || c.n_dom > dom_list_.n;
+        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_v4 > v4_list_.n || c.n_dom > dom_list_.n;
         if (!over) break;
         if (single_) throw HipError{"lookup_one: work buffers overflow"};
         // grow and run again: the kernels count past the capacity without writing, so the counts are exact demands
         if (c.n_cand > cands_.n) cands_.alloc((size_t)c.n_cand + c.n_cand / 4 + 1024);
         if (c.n_rare > rare_.n) rare_.alloc((size_t)c.n_rare + c.n_rare / 4 + 1024);
+        if (c.n_tok > tok_.n) tok_.alloc((size_t)c.n_tok + c.n_tok / 4 + 1024);
         if (c.n_v4 > v4_list_.n) v4_list_.alloc((size_t)c.n_v4 + c.n_v4 / 4 + 1024);
         if (c.n_dom > dom_list_.n) dom_list_.alloc((size_t)c.n_dom + c.n_dom / 4 + 1024);
         if (c.n_hits > hits_.n || hits_.n < cands_.n / 4) hits_.alloc(std::max<size_t>((size_t)c.n_hits + c.n_hits / 4 + 1024, cands_.n / 4));
         if (c.n_ids > ids_.n) ids_.alloc((size_t)c.n_ids + c.n_ids / 4 + 1024);
+        if (final_.n < hits_.n) final_.alloc(hits_.n);
+        if (final_ids_.n < hits_.n + ids_.n) { final_ids_.alloc(hits_.n + ids_.n); final_offs_.alloc(hits_.n + ids_.n); }
         scan_device(last_ptr_, last_len_, last_lookup_, stream);
         if (attempt == 5) throw HipError{"scan: work buffers still overflow after regrowing"};
     }
     const ScanCounters& c = host_counters_;
     if (c.error & 1) throw HipError{"scan: a candidate matched more than MAX_GLOB_RESULTS glob patterns"};
     if (c.error & 2) throw HipError{"scan: a glob pattern nests more than MAX_GLOB_STARS '*' segments"};
-    out.lines = c.lines; out.n_cand = single_ ? c.n_cand : c.cand_true; out.n_hits = last_lookup_ ? c.hits_true : 0;
+    out.lines = c.lines; out.n_cand = single_ ? c.n_cand : c.cand_true;
+    out.n_hits = !last_lookup_ ? 0 : (single_ ? c.hits_true : c.n_final);
     if (profile_) {
         MXY_HIP(hipEventElapsedTime(&timing_.anchor_ms, ev_[0], ev_[1]));
         MXY_HIP(hipEventElapsedTime(&timing_.validate_ms, ev_[1], ev_[2]));
@@ -253,19 +299,29 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, bool w
         MXY_HIP(hipEventElapsedTime(&timing_.total_ms, ev_[0], ev_[4]));
     }
     out.hits.clear(); out.ids.clear(); out.cands.clear();
-    const bool get_hits = last_lookup_ && want_hits && c.n_hits;
-    if (get_hits) {
-        // D2H into pinned memory (pageable destinations run at a fraction of the PCIe rate)
-        if (pinned_hits_n_ < c.n_hits) {
-            if (pinned_hits_) (void)hipHostFree(pinned_hits_);
-            pinned_hits_n_ = (size_t)c.n_hits + c.n_hits / 4 + 4096;
-            MXY_HIP(hipHostMalloc((void**)&pinned_hits_, pinned_hits_n_ * sizeof(Hit), hipHostMallocDefault));
-        }
-        MXY_HIP(hipMemcpyAsync(pinned_hits_, hits_.p, (size_t)c.n_hits * sizeof(Hit), hipMemcpyDeviceToHost, stream));
+    out.fin = nullptr; out.fin_ids = nullptr; out.fin_offs = nullptr; out.n_fin = 0; out.n_fin_ids = 0;
+    const bool get_raw = last_lookup_ && hit_mode == HITS_RAW && c.n_hits;
+    const bool get_fin = last_lookup_ && hit_mode == HITS_FINAL && c.n_final;
+    // D2H into pinned memory (pageable destinations run at a fraction of the PCIe rate)
+    if (get_raw) {
+        ensure_pinned((size_t)c.n_hits * sizeof(Hit));
+        MXY_HIP(hipMemcpyAsync(pinned_, hits_.p, (size_t)c.n_hits * sizeof(Hit), hipMemcpyDeviceToHost, stream));
         if (c.n_ids) {
             out.ids.resize(c.n_ids);
             MXY_HIP(hipMemcpyAsync(out.ids.data(), ids_.p, (size_t)c.n_ids * 4, hipMemcpyDeviceToHost, stream));
         }
+    }
+    if (get_fin) {
+        const size_t hb = (size_t)c.n_final * sizeof(FinalHit), ib = (((size_t)c.n_final_ids * 4) + 7) & ~(size_t)7, ob = (size_t)c.n_final_ids * 8;
+        ensure_pinned(hb + ib + ob);
+        uint8_t* base = (uint8_t*)pinned_;
+        MXY_HIP(hipMemcpyAsync(base, final_.p, hb, hipMemcpyDeviceToHost, stream));
+        if (c.n_final_ids) {
+            MXY_HIP(hipMemcpyAsync(base + hb, final_ids_.p, (size_t)c.n_final_ids * 4, hipMemcpyDeviceToHost, stream));
+            MXY_HIP(hipMemcpyAsync(base + hb + ib, final_offs_.p, ob, hipMemcpyDeviceToHost, stream));
+        }
+        out.fin = (const FinalHit*)base; out.n_fin = c.n_final;
+        out.fin_ids = (const uint32_t*)(base + hb); out.fin_offs = (const long long*)(base + hb + ib); out.n_fin_ids = c.n_final_ids;
     }
     if (want_cands && c.n_cand) {
         out.cands.resize(c.n_cand);
@@ -273,9 +329,10 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, bool w
     }
     MXY_HIP(hipStreamSynchronize(stream));
     // drop the padding slots of partially filled chunks
-    if (get_hits) {
+    if (get_raw) {
+        const Hit* ph = (const Hit*)pinned_;
         out.hits.reserve(c.hits_true);
-        for (size_t r = 0; r < c.n_hits; ++r) if (pinned_hits_[r].kind != 0xFF) out.hits.push_back(pinned_hits_[r]);
+        for (size_t r = 0; r < c.n_hits; ++r) if (ph[r].kind != 0xFF) out.hits.push_back(ph[r]);
     }
     if (!out.cands.empty()) {
         size_t w = 0;
@@ -305,21 +362,20 @@ void Scanner::lookup_one(const std::string& text, Candidate c, ScanOutput& out) 
     bool prof = profile_;
     profile_ = false;
     single_ = true;
-    try { fetch(out, false, nullptr); } catch (...) { single_ = false; profile_ = prof; throw; }
+    try { fetch(out, false, nullptr, HITS_RAW); } catch (...) { single_ = false; profile_ = prof; throw; }
     single_ = false;
     profile_ = prof;
 }
 
-void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_cands, ScanOutput& out, std::vector<uint64_t>* chunk_bases) {
+void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_cands, ScanOutput& out, std::vector<uint64_t>* cand_bases,
+                        std::vector<FinalHit>* fin, std::vector<uint32_t>* fin_ids, std::vector<long long>* fin_offs) {
     // Cut into < 2^30-byte pieces at newlines (N4 in SURVEY §8a: no candidate class admits '\n').
     const size_t MAXC = (size_t)1 << 30;
     out = ScanOutput();
     size_t pos = 0;
-    std::vector<Hit> all_hits;
-    std::vector<uint32_t> all_ids;
     std::vector<Candidate> all_cands;
-    if (chunk_bases) chunk_bases->clear();
-    std::vector<uint64_t> hit_base, cand_base;
+    if (cand_bases) cand_bases->clear();
+    if (fin) { fin->clear(); fin_ids->clear(); fin_offs->clear(); }
     do {
         size_t n = std::min(MAXC, len - pos);
         if (pos + n < len) {
@@ -331,21 +387,24 @@ void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_
         if (n) MXY_HIP(hipMemcpy(staging_.p, data + pos, n, hipMemcpyHostToDevice));
         scan_device(staging_.p, (uint32_t)n, lookup, nullptr);
         ScanOutput part;
-        fetch(part, want_cands, nullptr);
+        fetch(part, want_cands, nullptr, lookup && fin ? HITS_FINAL : HITS_NONE);
         out.lines += part.lines; out.n_cand += part.n_cand; out.n_hits += part.n_hits;
         for (int t = 0; t < IT_COUNT; ++t) out.by_type[t] += part.by_type[t];
-        uint32_t id_shift = (uint32_t)all_ids.size(), cand_shift = (uint32_t)all_cands.size();
-        for (Hit h : part.hits) { h.ids_off += id_shift; h.cand += cand_shift; all_hits.push_back(h); hit_base.push_back(pos); }
-        all_ids.insert(all_ids.end(), part.ids.begin(), part.ids.end());
-        for (const Candidate& c : part.cands) { all_cands.push_back(c); cand_base.push_back(pos); }
+        if (fin && part.n_fin) {
+            const uint32_t id_shift = (uint32_t)fin_ids->size();
+            for (size_t i = 0; i < part.n_fin; ++i) {
+                FinalHit h = part.fin[i];
+                h.start += pos; h.end += pos;
+                if (h.kind == 3) h.ids_index += id_shift;
+                fin->push_back(h);
+            }
+            fin_ids->insert(fin_ids->end(), part.fin_ids, part.fin_ids + part.n_fin_ids);
+            fin_offs->insert(fin_offs->end(), part.fin_offs, part.fin_offs + part.n_fin_ids);
+        }
+        for (const Candidate& c : part.cands) { all_cands.push_back(c); if (cand_bases) cand_bases->push_back(pos); }
         pos += n;
     } while (pos < len);
-    out.hits.swap(all_hits); out.ids.swap(all_ids); out.cands.swap(all_cands);
-    if (chunk_bases) {
-        // bases for hits first, then for candidates (callers index by position in the respective vector)
-        chunk_bases->assign(hit_base.begin(), hit_base.end());
-        chunk_bases->insert(chunk_bases->end(), cand_base.begin(), cand_base.end());
-    }
+    out.cands.swap(all_cands);
 }
 
 }  // namespace mxy

@@ -17,6 +17,7 @@ void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t st
 void launch_validate(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_lookup(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream);
+void launch_pack(const PackParams& p, int grid, hipStream_t stream);
 
 struct HipError { std::string what; };
 #define MXY_HIP(expr)                                                                                   \
@@ -61,17 +62,27 @@ struct DeviceDb {
     DevBuf<LitSlot> lit_slots;
     DevBuf<uint8_t> lit_pool, pg, psl_pool;
     DevBuf<uint32_t> lit2pat_off, lit2pat, bloom;
+    DevBuf<uint32_t> lit_offsets, glob_offsets;  // pattern id -> data-section offset (k_pack)
     DevBuf<PslSlot> psl_slots;
+    uint32_t n_lit_offsets = 0, n_glob_offsets = 0;
     size_t bytes_uploaded = 0;
     void upload(const DbImage& img, int dev);
 };
 
-struct ScanTiming { float anchor_ms = 0, validate_ms = 0, rare_ms = 0, lookup_ms = 0, total_ms = 0; };
+struct ScanTiming { float anchor_ms = 0, validate_ms = 0, rare_ms = 0, lookup_ms = 0, total_ms = 0; };  // lookup includes k_pack
+
+enum HitMode { HITS_NONE = 0, HITS_FINAL = 1, HITS_RAW = 2 };
 
 struct ScanOutput {
     std::vector<Candidate> cands;  // filled only when requested
-    std::vector<Hit> hits;
+    std::vector<Hit> hits;         // HITS_RAW (single-query path)
     std::vector<uint32_t> ids;
+    // HITS_FINAL: dense records produced by k_pack, BORROWED from the scanner's pinned buffers
+    // (valid until the next scan on that scanner)
+    const FinalHit* fin = nullptr;
+    const uint32_t* fin_ids = nullptr;
+    const long long* fin_offs = nullptr;
+    size_t n_fin = 0, n_fin_ids = 0;
     uint64_t lines = 0;
     uint32_t n_cand = 0, n_hits = 0;
     uint64_t by_type[IT_COUNT] = {0};
@@ -86,11 +97,13 @@ public:
     // lookup=false stops after extraction. Results stay on the device until fetch().
     void scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream);
     // Copies counters (and hits / candidates) back. Call after scan_device; synchronises the stream.
-    void fetch(ScanOutput& out, bool want_cands, hipStream_t stream, bool want_hits = true);
+    void fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode = HITS_FINAL);
     // One synthetic candidate (single-query API): `text` is uploaded, only the lookup kernel runs.
     void lookup_one(const std::string& text, Candidate c, ScanOutput& out);
     // Convenience: host buffer -> internal device buffer -> scan -> fetch (chunks of < 2^31 bytes).
-    void scan_host(const uint8_t* data, size_t len, bool lookup, bool want_cands, ScanOutput& out, std::vector<uint64_t>* chunk_bases);
+    // `fin*` vectors receive owned copies of the final hits of all pieces, positions made absolute.
+    void scan_host(const uint8_t* data, size_t len, bool lookup, bool want_cands, ScanOutput& out, std::vector<uint64_t>* cand_bases,
+                   std::vector<FinalHit>* fin, std::vector<uint32_t>* fin_ids, std::vector<long long>* fin_offs);
     void set_profile(bool on) { profile_ = on; }
     const ScanTiming& timing() const { return timing_; }
     uint32_t flags() const { return flags_; }
@@ -103,14 +116,18 @@ private:
     std::shared_ptr<DeviceDb> ddb_;
     uint32_t flags_, min_labels_;
     DevBuf<Candidate> cands_;
-    DevBuf<RareAnchor> rare_;
+    DevBuf<RareAnchor> rare_, tok_;
+    DevBuf<FinalHit> final_;
+    DevBuf<uint32_t> final_ids_;
+    DevBuf<long long> final_offs_;
     DevBuf<uint32_t> v4_list_, dom_list_;
     DevBuf<Hit> hits_;
     DevBuf<uint32_t> ids_;
     DevBuf<ScanCounters> counters_;
     DevBuf<uint8_t> staging_;  // scan_host only
-    Hit* pinned_hits_ = nullptr;
-    size_t pinned_hits_n_ = 0;
+    void* pinned_ = nullptr;   // one pinned block: FinalHit[n] | u32 ids[m] | i64 offs[m]  (or Hit[n] for HITS_RAW)
+    size_t pinned_bytes_ = 0;
+    void ensure_pinned(size_t bytes);
     ScanCounters host_counters_{};
     uint32_t last_len_ = 0;
     const uint8_t* last_ptr_ = nullptr;

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     __shared__ uint32_t q_v4[AW][QCAP];
     __shared__ uint32_t q_dom[AW][QCAP];
     __shared__ uint2 q_misc[AW][QCAP];
+    __shared__ uint2 q_tok[AW][QCAP];
 
     ctab[threadIdx.x] = (uint8_t)(class_of(threadIdx.x) | (((db.tld_first[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1) ? C_TLD1 : 0));
     __syncthreads();
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     uint32_t* rv4 = q_v4[wave];
     uint32_t* rdom = q_dom[wave];
     uint2* rmisc = q_misc[wave];
+    uint2* rtok = q_tok[wave];
     const uint32_t len = p.len;
     const bool en_v4 = (p.flags & EX_IPV4) != 0, en_dom = (p.flags & EX_DOMAINS) != 0;
     const bool en_v6 = (p.flags & EX_IPV6) != 0, en_at = (p.flags & EX_EMAILS) != 0;
@@ -74,12 +76,13 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
 
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t nl_count = 0;                       // per-lane '\n' count, reduced once at the end
-    uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0, mh = 0, mt = 0;  // ring heads / tails (wave-uniform)
+    uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0, mh = 0, mt = 0, kh = 0, kt = 0;  // ring heads / tails (wave-uniform)
     ChunkWriter<uint32_t, ANCHOR_CHUNK> cw_v4, cw_dom;
-    ChunkWriter<uint2, RARE_CHUNK> cw_misc;  // rare anchors are sparse: small chunks keep the list dense
+    ChunkWriter<uint2, RARE_CHUNK> cw_misc, cw_tok;  // rare anchors are sparse: small chunks keep the lists dense
     const uint32_t S32 = 0xFFFFFFFFu;
     const uint2 S64 = make_uint2(0xFFFFFFFFu, 0xFFu);
     uint2* rare_out = reinterpret_cast<uint2*>(p.rare);
+    uint2* tok_out = reinterpret_cast<uint2*>(p.tok);
 
     for (uint32_t seg = gw; seg < p.n_segs; seg += nw) {
         const uint32_t seg_start = seg * SEG_BYTES;
@@ -217,9 +220,9 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                         const bool tok = cand && ((tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128);
                         const uint64_t m = __ballot(tok);
                         if (m) {
-                            if (tok) rmisc[(mt + mbcnt64(m)) & (QCAP - 1)] = make_uint2(j - tl, (uint32_t)RARE_TOK | (tl << 8));
-                            mt += (uint32_t)__popcll(m);
-                            if (mt - mh >= 64) flush_ring(rmisc, mh, 64u, cw_misc, rare_out, p.rare_cap, &p.counters->n_rare, S64);
+                            if (tok) rtok[(kt + mbcnt64(m)) & (QCAP - 1)] = make_uint2(j - tl, (uint32_t)RARE_TOK | (tl << 8));
+                            kt += (uint32_t)__popcll(m);
+                            if (kt - kh >= 64) flush_ring(rtok, kh, 64u, cw_tok, tok_out, p.tok_cap, &p.counters->n_tok, S64);
                         }
                     }
                     // carry: last boundary byte of this super-row, and its Z bits
@@ -242,9 +245,11 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     if (dt != dh) flush_ring(rdom, dh, dt - dh, cw_dom, p.dom_list, p.dom_cap, &p.counters->n_dom, S32);
     if (v4t != v4h) flush_ring(rv4, v4h, v4t - v4h, cw_v4, p.v4_list, p.v4_cap, &p.counters->n_v4, S32);
     if (mt != mh) flush_ring(rmisc, mh, mt - mh, cw_misc, rare_out, p.rare_cap, &p.counters->n_rare, S64);
+    if (kt != kh) flush_ring(rtok, kh, kt - kh, cw_tok, tok_out, p.tok_cap, &p.counters->n_tok, S64);
     cw_dom.pad_rest(p.dom_list, p.dom_cap, S32);
     cw_v4.pad_rest(p.v4_list, p.v4_cap, S32);
     cw_misc.pad_rest(rare_out, p.rare_cap, S64);
+    cw_tok.pad_rest(tok_out, p.tok_cap, S64);
     // line count: wave reduction of the per-lane counts, one atomic per wave
     unsigned long long lines = nl_count;
 #pragma unroll

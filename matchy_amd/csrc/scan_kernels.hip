@@ -55,12 +55,75 @@ __device__ bool val_ipv4(const LogView& lg, uint32_t dot, uint32_t& start, uint3
     return true;
 }
 
+// Same rules with two wide loads instead of ~17 dependent byte loads: the 20 bytes [dot-4, dot+16) are fetched at once
+// and parsed in registers. Callers use it only when that window lies inside the buffer.
+__device__ bool val_ipv4_fast(const uint8_t* log, uint32_t dot, uint32_t& start, uint32_t& end, uint32_t& addr) {
+    uint4 q;
+    uint32_t t4;
+    __builtin_memcpy(&q, log + dot - 4, 16);   // unaligned global_load_dwordx4 (unaligned access mode is on for gfx9+)
+    __builtin_memcpy(&t4, log + dot + 12, 4);
+    // first octet: digits at dot-1, dot-2, dot-3 (right to left), then a boundary
+    const uint32_t b3 = q.x >> 24, b2 = (q.x >> 16) & 0xFF, b1 = (q.x >> 8) & 0xFF, b0 = q.x & 0xFF;
+    if (!d_is_digit(b3)) return false;
+    const bool g2 = d_is_digit(b2), g1 = g2 && d_is_digit(b1);
+    const uint32_t n1 = 1u + g2 + g1;
+    const uint32_t before = g1 ? b0 : g2 ? b1 : b2;
+    if (!d_is_boundary(before)) return false;
+    const uint32_t first = g1 ? b1 : g2 ? b2 : b3;
+    uint32_t a = g1 ? (b1 - 48) * 100 + (b2 - 48) * 10 + (b3 - 48) : g2 ? (b2 - 48) * 10 + (b3 - 48) : (b3 - 48);
+    if (a > 255 || (n1 > 1 && first == '0')) return false;
+    // r0..r2 = the 12 bytes after the dot
+    uint32_t r0 = __builtin_amdgcn_alignbyte(q.z, q.y, 1), r1 = __builtin_amdgcn_alignbyte(q.w, q.z, 1), r2 = __builtin_amdgcn_alignbyte(t4, q.w, 1);
+    uint32_t pos = dot + 1;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const uint32_t c0 = r0 & 0xFF, c1 = (r0 >> 8) & 0xFF, c2 = (r0 >> 16) & 0xFF, c3 = r0 >> 24;
+        if (!d_is_digit(c0)) return false;
+        const bool h1 = d_is_digit(c1), h2 = h1 && d_is_digit(c2);
+        const uint32_t n = 1u + h1 + h2;
+        const uint32_t v = h2 ? (c0 - 48) * 100 + (c1 - 48) * 10 + (c2 - 48) : h1 ? (c0 - 48) * 10 + (c1 - 48) : (c0 - 48);
+        if (v > 255 || (h1 && c0 == '0')) return false;
+        const uint32_t sep = h2 ? c3 : h1 ? c2 : c1;
+        a = (a << 8) | v;
+        pos += n;
+        if (o < 2) {
+            if (sep != '.') return false;
+            pos += 1;
+            // drop n + 1 bytes: first n (1..3), then one more
+            r0 = __builtin_amdgcn_alignbyte(r1, r0, n); r1 = __builtin_amdgcn_alignbyte(r2, r1, n); r2 = __builtin_amdgcn_alignbyte(0u, r2, n);
+            r0 = __builtin_amdgcn_alignbyte(r1, r0, 1); r1 = __builtin_amdgcn_alignbyte(r2, r1, 1); r2 = r2 >> 8;
+        } else if (!d_is_boundary(sep)) {
+            return false;
+        }
+    }
+    start = dot - n1; end = pos; addr = a;
+    return true;
+}
+
 // Domain (ext:537-689). `j` is the first byte after a dot (anchor: label-char, '.', label-char). Only the LAST dot
 // of a maximal domain-char run owns the run; it validates the run as a whole.
 __device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* bloom, uint32_t min_labels, uint32_t j,
                            uint32_t& start, uint32_t& end) {
     uint32_t p = j, th = 2166136261u;
-    while (p < lg.len) {
+    bool open = true;  // last label not yet terminated
+    if (j + 8 <= lg.len) {
+        // the first 8 bytes of the last label in one load; most labels (com, net, css, html, ...) end inside it
+        uint2 w;
+        __builtin_memcpy(&w, lg.p + j, 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (open) {
+                const uint32_t c = ((k < 4 ? w.x : w.y) >> (8 * (k & 3))) & 0xFF;
+                if (!d_is_domain_char_fast(c)) open = false;
+                else {
+                    if (c == '.') return false;  // a later dot owns this run
+                    th = tld_hash_step(th, c);
+                    ++p;
+                }
+            }
+        }
+    }
+    while (open && p < lg.len) {
         uint32_t c = lg.at(p);
         if (!d_is_domain_char_fast(c)) break;
         if (c == '.') return false;  // a later dot owns this run
@@ -385,7 +448,8 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         const uint32_t a4 = i < n4 ? p.v4_list[i] : 0xFFFFFFFFu;
         if (a4 != 0xFFFFFFFFu) {
             uint32_t s, e, a;
-            if (val_ipv4(lg, a4, s, e, a)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV4 << 24); c.v4 = a; emit = true; }
+            const bool wide = a4 >= 4 && a4 + 16 <= lg.len;
+            if (wide ? val_ipv4_fast(lg.p, a4, s, e, a) : val_ipv4(lg, a4, s, e, a)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV4 << 24); c.v4 = a; emit = true; }
         }
         cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     }
@@ -429,13 +493,13 @@ __global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
     LogView lg{p.log, p.len};
     ChunkWriter<Candidate, CAND_CHUNK> cw;
     const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
-    uint32_t n = min(p.counters->n_rare, p.rare_cap);
+    uint32_t n = min(p.counters->n_tok, p.tok_cap);
     for (uint32_t base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
         uint32_t i = base + threadIdx.x;
         RareAnchor ra{0, 0xFF};
-        if (i < n) ra = p.rare[i];
+        if (i < n) ra = p.tok[i];
         const uint32_t kind = ra.len_kind & 0xFF, tl = ra.len_kind >> 8;
-        if (__ballot(kind == RARE_TOK) == 0) continue;  // IPv6 / e-mail anchors are handled by k_validate
+        if (__ballot(kind == RARE_TOK) == 0) continue;  // only chunk padding in this batch
         // a token can yield up to four items: hash, Bitcoin, Ethereum, Monero are independent extractors
         for (int which = 0; which < 4; ++which) {
             bool em = false;
@@ -728,7 +792,80 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->hits_true, cw.total);
 }
 
+// k_pack — compacts the chunk-allocated hit list into dense FinalHit records (the layout the C ABI hands out) and
+// resolves pattern ids to data offsets, so the host does no per-hit work. Pattern results follow
+// Database::lookup_string_uncached (database.rs:911-981): the literal id counts only if it has a data mapping, then
+// the glob ids in ascending order; a literal without mapping and no glob is NotFound.
+__global__ __launch_bounds__(256) void k_pack(PackParams p) {
+    const uint32_t n = min(p.counters->n_hits, p.hit_cap);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t lane = lane_id();
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        Hit h{};
+        h.kind = 0xFF;
+        if (i < n) h = p.hits[i];
+        bool valid = h.kind != 0xFF;
+        uint32_t nid = 0, lit_off = 0xFFFFFFFFu;
+        if (valid && h.kind == 3) {
+            if (h.a != 0xFFFFFFFFu && h.a < p.n_lit) lit_off = p.lit_offsets[h.a];
+            nid = (lit_off != 0xFFFFFFFFu ? 1u : 0u) + h.n_globs;
+            if (nid == 0) valid = false;
+        }
+        // dense slot for the record: one atomic per wave
+        const uint64_t vm = __ballot(valid);
+        if (vm == 0) continue;
+        uint32_t slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(&p.counters->n_final, (uint32_t)__popcll(vm));
+        slot0 = __builtin_amdgcn_readfirstlane(slot0);
+        const uint32_t slot = slot0 + (uint32_t)__popcll(vm & lanemask_lt());
+        // side-array space for pattern ids: wave exclusive scan of nid, one atomic per wave
+        uint32_t scan = valid ? nid : 0u;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)scan, off);
+            if ((int)lane >= off) scan += t;
+        }
+        const uint32_t total = (uint32_t)__shfl((int)scan, 63);
+        uint32_t ids0 = 0;
+        if (total) {
+            if (lane == 0) ids0 = atomicAdd(&p.counters->n_final_ids, total);
+            ids0 = __builtin_amdgcn_readfirstlane(ids0);
+        }
+        if (valid) {
+            const uint32_t my_ids = ids0 + scan - nid;
+            FinalHit f{};
+            f.start = h.start;
+            f.end = (uint64_t)h.start + (h.len_type & 0xFFFFFF);
+            f.item_type = (uint8_t)(h.len_type >> 24);
+            f.kind = h.kind;
+            f.prefix_len = h.prefix_len;
+            if (h.kind == 2) f.data_offset = h.a;
+            else {
+                f.n_ids = nid;
+                f.ids_index = my_ids;
+                uint32_t w = my_ids;
+                if (lit_off != 0xFFFFFFFFu) {
+                    if (w < p.out_ids_cap) { p.out_ids[w] = h.a; p.out_offs[w] = (long long)lit_off; }
+                    ++w;
+                }
+                for (uint32_t k = 0; k < h.n_globs; ++k, ++w) {
+                    const uint32_t pid = (h.ids_off + k < p.ids_cap) ? p.ids[h.ids_off + k] : 0u;
+                    if (w < p.out_ids_cap) {
+                        p.out_ids[w] = pid;
+                        p.out_offs[w] = pid < p.n_glob ? (long long)p.glob_offsets[pid] : -1ll;
+                    }
+                }
+            }
+            if (slot < p.out_cap) p.out[slot] = f;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launch wrappers
+void launch_pack(const PackParams& p, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, stream, p);
+}
 void launch_validate(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_validate, dim3(grid), dim3(256), 0, stream, p, db);
 }

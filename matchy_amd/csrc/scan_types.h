@@ -88,7 +88,8 @@ constexpr uint32_t TLD_BLOOM_WORDS = TLD_BLOOM_BITS / 32;
 struct ScanCounters {
     unsigned long long lines;        // '\n' bytes
     uint32_t n_cand;                 // candidates appended (may exceed capacity → overflow)
-    uint32_t n_rare;
+    uint32_t n_rare;                 // IPv6 / e-mail anchors
+    uint32_t n_tok;                  // long-token anchors (hash / crypto candidates)
     uint32_t n_v4;                   // IPv4 anchors (first dot of a digit run that follows a boundary)
     uint32_t n_dom;                  // domain anchors (first byte of a label that follows a dot)
     uint32_t n_hits;
@@ -96,7 +97,9 @@ struct ScanCounters {
     uint32_t error;                  // bit0: glob result list overflow, bit1: glob star-stack overflow
     uint32_t cand_true;              // candidates really written (n_cand counts chunk-allocated slots incl. padding)
     uint32_t hits_true;
-    uint32_t pad;
+    uint32_t n_final;                // dense final hit records written by k_pack
+    uint32_t n_final_ids;            // entries of the pattern-id / data-offset side arrays
+    uint32_t pad[2];
 };
 
 struct TokParams {
@@ -108,8 +111,10 @@ struct TokParams {
     uint32_t n_segs;
     Candidate* cands;
     uint32_t cand_cap;
-    RareAnchor* rare;
+    RareAnchor* rare;         // IPv6 / e-mail anchors
     uint32_t rare_cap;
+    RareAnchor* tok;          // long-token anchors
+    uint32_t tok_cap;
     uint32_t* v4_list;        // anchor positions written by k_anchor, consumed by k_validate
     uint32_t v4_cap;
     uint32_t* dom_list;
@@ -126,6 +131,33 @@ struct LookupParams {
     uint32_t hit_cap;
     uint32_t* ids;
     uint32_t ids_cap;
+    ScanCounters* counters;
+};
+
+// Final hit record, bit-identical to matchy_scan_hit_t in include/matchy_amd.h (checked by static_assert in capi.cpp).
+struct FinalHit {
+    uint64_t start, end;
+    uint8_t item_type, kind, prefix_len, pad;
+    uint32_t data_offset;
+    uint32_t n_ids;
+    uint32_t ids_index;
+};
+
+// k_pack: compacts the chunked hit list into dense FinalHit records and resolves pattern ids to data offsets.
+struct PackParams {
+    const Hit* hits;
+    uint32_t hit_cap;
+    const uint32_t* ids;        // glob ids written by k_lookup
+    uint32_t ids_cap;
+    const uint32_t* lit_offsets;   // literal pattern id -> data offset (0xFFFFFFFF = no mapping), n_lit entries
+    uint32_t n_lit;
+    const uint32_t* glob_offsets;  // glob pattern id -> data offset, n_glob entries (PatternDataMappings)
+    uint32_t n_glob;
+    FinalHit* out;
+    uint32_t out_cap;
+    uint32_t* out_ids;
+    long long* out_offs;
+    uint32_t out_ids_cap;
     ScanCounters* counters;
 };
 
