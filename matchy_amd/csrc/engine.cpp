@@ -206,6 +206,7 @@ void Scanner::ensure_capacity(uint32_t len) {
     if (cands_.n < want_c) { cands_.alloc(want_c); hits_.alloc(std::max<size_t>(1024, want_c / 4)); ids_.alloc(std::max<size_t>(1024, want_c / 4)); }
     if (rare_.n < want_r) rare_.alloc(want_r);
     if (tok_.n < want_r) tok_.alloc(want_r);
+    if (heavy_.n < want_r) heavy_.alloc(want_r);
     if (final_.n < hits_.n) { final_.alloc(hits_.n); }
     if (final_ids_.n < hits_.n + ids_.n) { final_ids_.alloc(hits_.n + ids_.n); final_offs_.alloc(hits_.n + ids_.n); }
     size_t want_a = std::max<size_t>(4096, (size_t)len / 32);
@@ -227,6 +228,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.cands = cands_.p; tp.cand_cap = (uint32_t)cands_.n;
     tp.rare = rare_.p; tp.rare_cap = (uint32_t)rare_.n;
     tp.tok = tok_.p; tp.tok_cap = (uint32_t)tok_.n;
+    tp.heavy = heavy_.p; tp.heavy_cap = (uint32_t)heavy_.n;
     tp.v4_list = v4_list_.p; tp.v4_cap = (uint32_t)v4_list_.n;
     tp.dom_list = dom_list_.p; tp.dom_cap = (uint32_t)dom_list_.n;
     tp.counters = counters_.p;
@@ -235,10 +237,10 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     if (profile_) MXY_HIP(hipEventRecord(ev_[0], stream));
     launch_anchor(tp, ddb_->view, grid_tok, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[1], stream));
-    if (flags_ & (EX_IPV4 | EX_DOMAINS | EX_IPV6 | EX_EMAILS)) launch_validate(tp, ddb_->view, n_cu_ * 8, stream);
+    launch_validate(tp, ddb_->view, n_cu_ * 8, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
     bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
-    if (rare_possible) launch_rare(tp, ddb_->view, n_cu_ * 4, stream);
+    if (rare_possible) launch_rare(tp, ddb_->view, n_cu_, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
     if (lookup) {
         LookupParams lp{};
@@ -270,13 +272,14 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
         MXY_HIP(hipStreamSynchronize(stream));
         const ScanCounters& c = host_counters_;
-        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_v4 > v4_list_.n || c.n_dom > dom_list_.n;
+        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_v4 > v4_list_.n || c.n_dom > dom_list_.n;
         if (!over) break;
         if (single_) throw HipError{"lookup_one: work buffers overflow"};
         // grow and run again: the kernels count past the capacity without writing, so the counts are exact demands
         if (c.n_cand > cands_.n) cands_.alloc((size_t)c.n_cand + c.n_cand / 4 + 1024);
         if (c.n_rare > rare_.n) rare_.alloc((size_t)c.n_rare + c.n_rare / 4 + 1024);
         if (c.n_tok > tok_.n) tok_.alloc((size_t)c.n_tok + c.n_tok / 4 + 1024);
+        if (c.n_heavy > heavy_.n) heavy_.alloc((size_t)c.n_heavy + c.n_heavy / 4 + 1024);
         if (c.n_v4 > v4_list_.n) v4_list_.alloc((size_t)c.n_v4 + c.n_v4 / 4 + 1024);
         if (c.n_dom > dom_list_.n) dom_list_.alloc((size_t)c.n_dom + c.n_dom / 4 + 1024);
         if (c.n_hits > hits_.n || hits_.n < cands_.n / 4) hits_.alloc(std::max<size_t>((size_t)c.n_hits + c.n_hits / 4 + 1024, cands_.n / 4));
@@ -289,6 +292,9 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     const ScanCounters& c = host_counters_;
     if (c.error & 1) throw HipError{"scan: a candidate matched more than MAX_GLOB_RESULTS glob patterns"};
     if (c.error & 2) throw HipError{"scan: a glob pattern nests more than MAX_GLOB_STARS '*' segments"};
+    if (!single_ && getenv("MATCHY_AMD_TRACE"))
+        fprintf(stderr, "[matchy_amd] lines=%llu n_v4=%u n_dom=%u n_rare=%u n_tok=%u n_heavy=%u n_cand=%u (true %u) n_hits=%u (true %u) n_ids=%u final=%u\n",
+                c.lines, c.n_v4, c.n_dom, c.n_rare, c.n_tok, c.n_heavy, c.n_cand, c.cand_true, c.n_hits, c.hits_true, c.n_ids, c.n_final);
     out.lines = c.lines; out.n_cand = single_ ? c.n_cand : c.cand_true;
     out.n_hits = !last_lookup_ ? 0 : (single_ ? c.hits_true : c.n_final);
     if (profile_) {

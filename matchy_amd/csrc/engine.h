@@ -116,7 +116,7 @@ private:
     std::shared_ptr<DeviceDb> ddb_;
     uint32_t flags_, min_labels_;
     DevBuf<Candidate> cands_;
-    DevBuf<RareAnchor> rare_, tok_;
+    DevBuf<RareAnchor> rare_, tok_, heavy_;
     DevBuf<FinalHit> final_;
     DevBuf<uint32_t> final_ids_;
     DevBuf<long long> final_offs_;

@@ -264,7 +264,7 @@ __device__ bool val_email(const LogView& lg, const DevDb& db, uint32_t at, uint3
 }
 
 // ---- SHA-256 (one 64-byte block at a time), Keccak-f[1600], base58, bech32 — rare path, scratch arrays are fine.
-__device__ void d_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
+__device__ __noinline__ void d_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
     const uint32_t K[64] = {
         0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
         0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
@@ -301,7 +301,7 @@ __device__ void d_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
     for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
 }
 
-__device__ void d_keccak_f(uint64_t st[25]) {
+__device__ __noinline__ void d_keccak_f(uint64_t st[25]) {
     const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
                              0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
                              0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
@@ -350,7 +350,7 @@ __device__ int d_b58_val(uint32_t c) {
     return -1;
 }
 // bs58::decode(..).into_vec(): out is big-endian, length returned (0 on invalid character); n <= 110 -> <= 96 bytes
-__device__ uint32_t d_base58_decode(const uint8_t* s, uint32_t n, uint8_t out[112]) {
+__device__ __noinline__ uint32_t d_base58_decode(const uint8_t* s, uint32_t n, uint8_t out[112]) {
     uint8_t num[96];
     uint32_t nlen = 0, zeros = 0;
     bool leading = true;
@@ -483,48 +483,73 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         }
         cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     }
+    // Long tokens: hex hashes are decided here; the checksum validators (Base58Check, Bech32, EIP-55, Monero) need
+    // SHA-256 / Keccak and hundreds of registers, so tokens that pass their cheap prefix tests go to the `heavy` list
+    // for k_rare. A token made of non-boundary bytes may contain high bytes; every accepted form is pure ASCII, so the
+    // reference's from_utf8 precondition is implied by the per-symbol checks.
+    ChunkWriter<RareAnchor, RARE_CHUNK> hw;
+    const RareAnchor SH{0xFFFFFFFFu, 0xFFu};
+    const uint32_t nt = min(p.counters->n_tok, p.tok_cap);
+    for (uint32_t base = blockIdx.x * blockDim.x; base < nt; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        RareAnchor ra{0, 0xFF};
+        if (i < nt) ra = p.tok[i];
+        const bool live = (ra.len_kind & 0xFF) == RARE_TOK;
+        const uint32_t tl = ra.len_kind >> 8;
+        const uint8_t* s = lg.p + (live ? ra.pos : 0);
+        // hashes: token length 32/40/64/96/128 and all hex (ext:1212-1250)
+        {
+            Candidate c{0, 0, 0, 0};
+            bool emit = false;
+            if (live && (p.flags & EX_HASHES)) {
+                const int ht = tl == 32 ? IT_MD5 : tl == 40 ? IT_SHA1 : tl == 64 ? IT_SHA256 : tl == 96 ? IT_SHA384 : tl == 128 ? IT_SHA512 : -1;
+                if (ht >= 0 && all_hex(lg, ra.pos, tl)) { c.start = ra.pos; c.len_type = tl | ((uint32_t)ht << 24); emit = true; }
+            }
+            cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+        }
+        // a token can yield several items: hash, Bitcoin, Ethereum and Monero are independent extractors
+        {
+            uint32_t hk = 0;
+            if (live && (p.flags & EX_BITCOIN) && tl >= 26 && tl <= 62) {
+                if (s[0] == 'b' && s[1] == 'c' && s[2] == '1') hk = HEAVY_BECH32;
+                else if (s[0] == '1' || s[0] == '3') hk = HEAVY_B58;
+            }
+            hw.append(hk != 0, RareAnchor{ra.pos, (tl << 8) | hk}, p.heavy, p.heavy_cap, &p.counters->n_heavy, SH);
+            hk = 0;
+            if (live && (p.flags & EX_ETHEREUM) && tl == 42 && s[0] == '0' && s[1] == 'x') hk = HEAVY_ETH;
+            if (live && (p.flags & EX_MONERO) && tl >= 90 && tl <= 110 && (s[0] == '4' || s[0] == '8')) hk = HEAVY_XMR;
+            hw.append(hk != 0, RareAnchor{ra.pos, (tl << 8) | hk}, p.heavy, p.heavy_cap, &p.counters->n_heavy, SH);
+        }
+    }
+    hw.pad_rest(p.heavy, p.heavy_cap, SH);
     cw.pad_rest(p.cands, p.cand_cap, SC);
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
 }
 
-// k_rare — stage A3: token validators (hex hashes, Base58Check, Bech32, EIP-55, Monero): rare in logs and heavy in
-// registers, one lane per token anchor of the rare list.
+// k_rare — stage A3: checksum validators (Base58Check, Bech32, EIP-55, Monero): very rare in logs and heavy in
+// registers, one lane per entry of the `heavy` list written by k_validate.
 __global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
     LogView lg{p.log, p.len};
     ChunkWriter<Candidate, CAND_CHUNK> cw;
     const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
-    uint32_t n = min(p.counters->n_tok, p.tok_cap);
+    const uint32_t n = min(p.counters->n_heavy, p.heavy_cap);
     for (uint32_t base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
-        uint32_t i = base + threadIdx.x;
+        const uint32_t i = base + threadIdx.x;
         RareAnchor ra{0, 0xFF};
-        if (i < n) ra = p.tok[i];
+        if (i < n) ra = p.heavy[i];
         const uint32_t kind = ra.len_kind & 0xFF, tl = ra.len_kind >> 8;
-        if (__ballot(kind == RARE_TOK) == 0) continue;  // only chunk padding in this batch
-        // a token can yield up to four items: hash, Bitcoin, Ethereum, Monero are independent extractors
-        for (int which = 0; which < 4; ++which) {
-            bool em = false;
-            Candidate ct{0, 0, 0, 0};
-            if (kind == RARE_TOK) {
-                const uint8_t* s = lg.p + ra.pos;
-                int ty = -1;
-                // a token made of non-boundary bytes may contain high bytes; every accepted form is pure ASCII,
-                // so the reference's from_utf8 precondition is implied by the per-symbol checks
-                if (which == 0 && (p.flags & EX_HASHES)) {
-                    // hashes: token length 32/40/64/96/128 and all hex (ext:1212-1250)
-                    int ht = tl == 32 ? IT_MD5 : tl == 40 ? IT_SHA1 : tl == 64 ? IT_SHA256 : tl == 96 ? IT_SHA384 : tl == 128 ? IT_SHA512 : -1;
-                    if (ht >= 0 && all_hex(lg, ra.pos, tl)) ty = ht;
-                } else if (which == 1 && (p.flags & EX_BITCOIN) && tl >= 26 && tl <= 62) {
-                    if (s[0] == 'b' && s[1] == 'c' && s[2] == '1') { if (val_btc_bech32(s, tl)) ty = IT_BITCOIN; }
-                    else if (s[0] == '1' || s[0] == '3') { if (val_btc_base58(s, tl)) ty = IT_BITCOIN; }
-                } else if (which == 2 && (p.flags & EX_ETHEREUM) && tl == 42 && s[0] == '0' && s[1] == 'x') {
-                    if (val_eth(s)) ty = IT_ETHEREUM;
-                } else if (which == 3 && (p.flags & EX_MONERO) && tl >= 90 && tl <= 110 && (s[0] == '4' || s[0] == '8')) {
-                    if (val_monero(s, tl)) ty = IT_MONERO;
-                }
-                if (ty >= 0) { ct.start = ra.pos; ct.len_type = tl | ((uint32_t)ty << 24); em = true; }
-            }
-            cw.append(em, ct, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+        bool em = false;
+        Candidate ct{0, 0, 0, 0};
+        if (kind != 0xFF) {
+            const uint8_t* s = lg.p + ra.pos;
+            int ty = -1;
+            if (kind == HEAVY_BECH32) { if (val_btc_bech32(s, tl)) ty = IT_BITCOIN; }
+            else if (kind == HEAVY_B58) { if (val_btc_base58(s, tl)) ty = IT_BITCOIN; }
+            else if (kind == HEAVY_ETH) { if (val_eth(s)) ty = IT_ETHEREUM; }
+            else if (kind == HEAVY_XMR) { if (val_monero(s, tl)) ty = IT_MONERO; }
+            if (ty >= 0) { ct.start = ra.pos; ct.len_type = tl | ((uint32_t)ty << 24); em = true; }
         }
+        cw.append(em, ct, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     }
     cw.pad_rest(p.cands, p.cand_cap, SC);
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);

@@ -26,7 +26,7 @@ struct Candidate {
 };
 
 // Anchors that need the rare-path validators (IPv6, e-mail, hash / crypto tokens), 8 bytes.
-enum RareKind : uint32_t { RARE_V6 = 0, RARE_AT = 1, RARE_TOK = 2 };
+enum RareKind : uint32_t { RARE_V6 = 0, RARE_AT = 1, RARE_TOK = 2, HEAVY_B58 = 3, HEAVY_BECH32 = 4, HEAVY_ETH = 5, HEAVY_XMR = 6 };
 struct RareAnchor {
     uint32_t pos;       // RARE_V6: index of the 2nd ':' of a "::"; RARE_AT: index of '@'; RARE_TOK: token start
     uint32_t len_kind;  // RareKind in bits 0..7, token length in bits 8..31
@@ -99,7 +99,8 @@ struct ScanCounters {
     uint32_t hits_true;
     uint32_t n_final;                // dense final hit records written by k_pack
     uint32_t n_final_ids;            // entries of the pattern-id / data-offset side arrays
-    uint32_t pad[2];
+    uint32_t n_heavy;                // tokens that need a checksum validator (Base58Check, Bech32, EIP-55, Monero)
+    uint32_t pad[1];
 };
 
 struct TokParams {
@@ -115,6 +116,8 @@ struct TokParams {
     uint32_t rare_cap;
     RareAnchor* tok;          // long-token anchors
     uint32_t tok_cap;
+    RareAnchor* heavy;        // tokens that passed the cheap prefilters of k_validate and need k_rare
+    uint32_t heavy_cap;
     uint32_t* v4_list;        // anchor positions written by k_anchor, consumed by k_validate
     uint32_t v4_cap;
     uint32_t* dom_list;
