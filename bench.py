@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--config", default="c2", help="indicator mix (tools/synth.py): c2 = 100K mixed IoCs")
     ap.add_argument("--cpu-lines", type=int, default=3_000_000, help="lines of the same log timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--extract-flags", type=int, default=0, help="diagnostics only: MATCHY_EXTRACT_* bit mask (0 = what the DB needs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -48,15 +49,16 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import matchy_amd as M
+    from matchy_amd import sharding
     from tools import synth
 
     cfg = synth.config(args.config)
     blob = synth.build_db(cfg)
     db = M.Database(blob)
-    scanner = M.Scanner(db, device=local_rank, profile=True)
+    scanner = M.Scanner(db, extract_flags=args.extract_flags, device=local_rank, profile=True)
 
     # ---- synthetic batch: this rank's line block, generated on the host, uploaded once
-    first_line = rank * args.lines
+    first_line = sharding.block_for_rank(rank, world, args.lines).first_line
     cap = args.lines * 200 + (1 << 20)
     host = torch.empty(cap, dtype=torch.uint8)
     nbytes = synth.make_log_into(cfg, first_line, args.lines, host.data_ptr(), cap)
@@ -77,9 +79,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sharding.barrier(dist, world, torch.cuda.synchronize)
 
     for _ in range(args.warmup):
         counts = step()
@@ -95,24 +95,36 @@ def main():
         tok_ms.append(t["anchor"]); look_ms.append(t["lookup"]); rare_ms.append(t["rare"]); val_ms.append(t["validate"])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        tb = torch.tensor([float(nbytes), float(counts[0])], dtype=torch.float64, device=dev)
-        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
-        total_bytes, total_lines = float(tb[0].item()), float(tb[1].item())
-    else:
-        total_bytes, total_lines = float(nbytes), float(counts[0])
+    agg = sharding.aggregate(dist, world, dev, elapsed, nbytes, counts[0], counts[2], counts[1])
+    elapsed = agg["elapsed_s"]
+    total_bytes, total_lines = float(agg["bytes"]), float(agg["lines"])
 
     ms_per_step = elapsed / args.steps * 1e3
     value = total_bytes / (elapsed / args.steps) / 1e9
-    avg_tok = sum(tok_ms) / len(tok_ms)
-    achieved = nbytes / (avg_tok * 1e-3) / 1e9  # algorithmic bytes of one k_anchor launch = len(log)
+    # Roofline: the unit of work is the log byte, read once: algorithmic bytes per launch = len(log) for
+    # every kernel of the pass (each launch covers the whole batch). `roofline` is the DOMINANT (slowest) kernel,
+    # timed live with HIP events on the launch stream; `roofline_pipeline` prices the sum of all kernels of one pass.
+    kern = {"k_anchor": sum(tok_ms) / len(tok_ms), "k_validate": sum(val_ms) / len(val_ms),
+            "k_rare": sum(rare_ms) / len(rare_ms), "k_lookup+k_pack": sum(look_ms) / len(look_ms)}
+    dom_name = max(kern, key=kern.get)
+    achieved = nbytes / (kern[dom_name] * 1e-3) / 1e9
+    pipe_ms = sum(kern.values())
+    pipe_achieved = nbytes / (pipe_ms * 1e-3) / 1e9
+    traffic = None
+    tr_note = None
+    try:
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/prof.sh; FETCH_SIZE x2 on gfx950)
+        tj = json.load(open(ROOT / "profiles" / "r01_traffic.json"))
+        if tj.get("bytes_per_gpu") == nbytes:
+            key = {"k_anchor": "mxy::k_anchor", "k_validate": "mxy::k_validate", "k_rare": "mxy::k_rare", "k_lookup+k_pack": "mxy::k_lookup<false>"}[dom_name]
+            traffic = tj["kernels"][key]["hbm_bytes"]
+            tr_note = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
+    except Exception:
+        pass
 
     cpu = None
     parity = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:
         # ---- CPU baseline: the oracle ("port" of the reference CPU path) on a bounded sample of the SAME log,
         # all host cores, newline-aligned chunks + 10 000-entry per-thread LRU like `matchy match` defaults.
         from oracle import oracle
@@ -154,11 +166,13 @@ def main():
                                    f"{args.lines} nginx-style lines per GPU",
                        "lines_per_gpu": args.lines, "bytes_per_gpu": nbytes, "sharding": "line-block per GPU, DB replicated, no collective"},
             "lines_per_s": round(total_lines / (elapsed / args.steps), 1),
-            "candidates_per_step": counts[1],
-            "hits_per_step": counts[2],
-            "kernel_ms": {"k_anchor": round(avg_tok, 4), "k_validate": round(sum(val_ms) / len(val_ms), 4), "k_rare": round(sum(rare_ms) / len(rare_ms), 4), "k_lookup": round(sum(look_ms) / len(look_ms), 4)},
+            "candidates_per_step": agg["candidates"],
+            "hits_per_step": agg["hits"],
+            "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel": "k_anchor", "algorithmic_bytes_per_launch": nbytes},
+                         "traffic": traffic, "kernel": dom_name, "algorithmic_bytes_per_launch": nbytes, "traffic_source": tr_note},
+            "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(pipe_achieved / HBM_PEAK_GBS, 4), "kernels_ms": round(pipe_ms, 4)},
             "cpu_baseline": cpu,
             "parity_vs_oracle": parity,
         }

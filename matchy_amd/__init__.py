@@ -109,7 +109,7 @@ def lib():
         "matchy_item_type_name": (cp, [C.c_uint8]),
         "matchy_scanner_create": (vp, [vp, C.c_uint32, C.c_int32]),
         "matchy_scanner_free": (None, [vp]),
-        "matchy_scanner_scan": (C.c_int32, [vp, cp, C.c_size_t, C.POINTER(_ScanResult)]),
+        "matchy_scanner_scan": (C.c_int32, [vp, vp, C.c_size_t, C.POINTER(_ScanResult)]),
         "matchy_scanner_scan_device": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_uint32, C.POINTER(_ScanResult)]),
         "matchy_scan_result_free": (None, [C.POINTER(_ScanResult)]),
         "matchy_scan_hit_to_json": (vp, [vp, C.POINTER(_ScanResult), C.c_size_t, cp, cp]),
@@ -329,6 +329,14 @@ class Scanner:
     def scan(self, data: bytes) -> ScanResult:
         raw = _ScanResult()
         rc = lib().matchy_scanner_scan(self._h, bytes(data), len(data), C.byref(raw))
+        if rc != 0:
+            raise RuntimeError(f"matchy_scanner_scan failed: rc={rc} {last_error()}")
+        return ScanResult(self, raw)
+
+    def scan_ptr(self, host_ptr: int, nbytes: int) -> ScanResult:
+        """Like scan() for a host buffer given by address (e.g. numpy / torch CPU storage) — no Python-side copy."""
+        raw = _ScanResult()
+        rc = lib().matchy_scanner_scan(self._h, host_ptr, nbytes, C.byref(raw))
         if rc != 0:
             raise RuntimeError(f"matchy_scanner_scan failed: rc={rc} {last_error()}")
         return ScanResult(self, raw)
