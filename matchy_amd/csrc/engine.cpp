@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -117,6 +118,36 @@ void DeviceDb::upload(const DbImage& img, int dev) {
     view.v4_start_node = v4_start;
     view.has_ip = img.has_ip;
     bytes_uploaded = nodes.size() * sizeof(uint2);
+    {
+        // First-level table for IPv4: the outcome of the first 16 steps of SearchTree::lookup_v4 (tree.rs:46-90) for
+        // every 16-bit prefix, so a lookup is one table load plus the (usually 1-3) remaining levels instead of ~18
+        // dependent node loads. Entry: x = kind | prefix_len << 8 (kind 0 continue at node y, 1 not found,
+        // 2 found with data offset y).
+        std::vector<uint2> l1(65536, make_uint2(1u, 0u));
+        if (img.node_count > 0) {
+            for (uint32_t v = 0; v < 65536; ++v) {
+                uint32_t node = v4_start;
+                uint2 e = make_uint2(0u, 0u);
+                bool done = false;
+                for (int bi = 0; bi < 16 && !done; ++bi) {
+                    const uint2 nd = nodes[node];
+                    const uint32_t rec = ((v >> (15 - bi)) & 1) ? nd.y : nd.x;
+                    if (rec == img.node_count) { e = make_uint2(1u, 0u); done = true; }
+                    else if (rec < img.node_count) node = rec;
+                    else {
+                        const uint32_t off = rec - img.node_count;
+                        e = off < 16 ? make_uint2(1u, 0u) : make_uint2(2u | ((uint32_t)(bi + 1) << 8), off - 16);
+                        done = true;
+                    }
+                }
+                if (!done) e = make_uint2(0u, node);
+                l1[v] = e;
+            }
+        }
+        ip_l1.upload(l1);
+        view.ip_l1 = ip_l1.p;
+        bytes_uploaded += l1.size() * sizeof(uint2);
+    }
     if (img.has_literal) {
         std::vector<LitSlot> slots;
         uint32_t mask;
@@ -268,12 +299,16 @@ void Scanner::ensure_pinned(size_t bytes) {
 }
 
 void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode) {
+    const bool trace = !single_ && getenv("MATCHY_AMD_TRACE");
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     for (int attempt = 0; attempt < 6; ++attempt) {
         MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
         MXY_HIP(hipStreamSynchronize(stream));
         const ScanCounters& c = host_counters_;
         bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_v4 > v4_list_.n || c.n_dom > dom_list_.n;
         if (!over) break;
+        if (trace) fprintf(stderr, "[matchy_amd] work buffers overflow (attempt %d): regrow and rescan\n", attempt);
         if (single_) throw HipError{"lookup_one: work buffers overflow"};
         // grow and run again: the kernels count past the capacity without writing, so the counts are exact demands
         if (c.n_cand > cands_.n) cands_.alloc((size_t)c.n_cand + c.n_cand / 4 + 1024);
@@ -292,7 +327,8 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     const ScanCounters& c = host_counters_;
     if (c.error & 1) throw HipError{"scan: a candidate matched more than MAX_GLOB_RESULTS glob patterns"};
     if (c.error & 2) throw HipError{"scan: a glob pattern nests more than MAX_GLOB_STARS '*' segments"};
-    if (!single_ && getenv("MATCHY_AMD_TRACE"))
+    const double t_counters = since();
+    if (trace)
         fprintf(stderr, "[matchy_amd] lines=%llu n_v4=%u n_dom=%u n_rare=%u n_tok=%u n_heavy=%u n_cand=%u (true %u) n_hits=%u (true %u) n_ids=%u final=%u\n",
                 c.lines, c.n_v4, c.n_dom, c.n_rare, c.n_tok, c.n_heavy, c.n_cand, c.cand_true, c.n_hits, c.hits_true, c.n_ids, c.n_final);
     out.lines = c.lines; out.n_cand = single_ ? c.n_cand : c.cand_true;
@@ -334,6 +370,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         MXY_HIP(hipMemcpyAsync(out.cands.data(), cands_.p, (size_t)c.n_cand * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
     }
     MXY_HIP(hipStreamSynchronize(stream));
+    if (trace) fprintf(stderr, "[matchy_amd] fetch: counters after %.3f ms, records after %.3f ms\n", t_counters, since());
     // drop the padding slots of partially filled chunks
     if (get_raw) {
         const Hit* ph = (const Hit*)pinned_;

@@ -58,7 +58,7 @@ struct DevBuf {
 struct DeviceDb {
     int device = 0;
     DevDb view{};
-    DevBuf<uint2> ip_nodes;
+    DevBuf<uint2> ip_nodes, ip_l1;
     DevBuf<LitSlot> lit_slots;
     DevBuf<uint8_t> lit_pool, pg, psl_pool;
     DevBuf<uint32_t> lit2pat_off, lit2pat, bloom;

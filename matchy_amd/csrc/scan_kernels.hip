@@ -558,18 +558,22 @@ __global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
 // ------------------------------------------------------------------------------------------------ stage B: lookups
 // SearchTree::lookup_v4 / lookup_v6 (tree:46-125). Returns record (> node_count) or 0 for "not found".
 __device__ bool trie_v4(const DevDb& db, uint32_t addr, uint32_t& data_off, uint32_t& prefix) {
-    uint32_t node = db.ip_version == 6 ? db.v4_start_node : 0;
-    uint32_t depth = 0;
-    for (int bi = 0; bi < 32; ++bi) {
+    // levels 0..15 come from the first-level table (DeviceDb::upload), the rest is the reference's walk
+    const uint2 e = db.ip_l1[addr >> 16];
+    const uint32_t kind = e.x & 0xFF;
+    if (kind == 1) return false;
+    if (kind == 2) { data_off = e.y; prefix = e.x >> 8; return true; }
+    uint32_t node = e.y;
+    for (int bi = 16; bi < 32; ++bi) {
         uint2 nd = db.ip_nodes[node];
         uint32_t rec = ((addr >> (31 - bi)) & 1) ? nd.y : nd.x;
         if (rec == db.node_count) return false;
-        if (rec < db.node_count) { node = rec; ++depth; }
+        if (rec < db.node_count) node = rec;
         else {
             uint32_t off = rec - db.node_count;
             if (off < 16) return false;  // reference: MmdbError -> lookup error; treated as not found (never produced by builders)
             data_off = off - 16;
-            prefix = depth + 1;  // tree:76-80: depth counts from 96 in v6 trees and 96 is subtracted again
+            prefix = (uint32_t)bi + 1;  // tree:76-80: depth counts from 96 in v6 trees and 96 is subtracted again
             return true;
         }
     }

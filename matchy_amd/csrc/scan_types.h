@@ -52,6 +52,7 @@ struct PslSlot { uint64_t hash; uint32_t off; uint32_t len; };              // l
 struct DevDb {
     // IP tree, re-laid out as one uint2 {left,right} per node (records widened to 32 bit, host byte order)
     const uint2* ip_nodes;
+    const uint2* ip_l1;      // 65536 entries: outcome of the first 16 IPv4 levels (x = kind | prefix << 8, y = node / data offset)
     uint32_t node_count;
     uint32_t ip_version;     // 4 or 6
     uint32_t v4_start_node;  // node reached after the 96 zero-bit steps of tree.rs:258-277 (v6 trees)
