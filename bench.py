@@ -82,8 +82,8 @@ def main():
         sharding.barrier(dist, world, torch.cuda.synchronize)
 
     # one-time runtime initialisation (pinned result buffer, the runtime's D2H engine set-up shows up as one slow copy
-    # within the first three scans) is part of set-up, like the upload of the batch; then the W warm-up steps
-    for _ in range(3):
+    # within the first few scans) is part of set-up, like the upload of the batch; then the W warm-up steps
+    for _ in range(10):
         counts = step()
     for _ in range(args.warmup):
         counts = step()

@@ -114,6 +114,89 @@ __device__ inline bool d_valid_utf8(const uint8_t* s, uint32_t n) {
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------ IPv4
+// IPv4 dotted-quad rules (ext:813-869, 1120-1179) on a 20-byte window held in registers: q = bytes [dot-4, dot+12),
+// t4 = bytes [dot+12, dot+16), `dot` = position of the first dot of the run. Emits iff the maximal [0-9.] run around
+// the dot is a valid dotted quad delimited by boundaries (N1).
+__device__ __forceinline__ bool d_ipv4_from_window(uint4 q, uint32_t t4, uint32_t dot, uint32_t& start, uint32_t& end, uint32_t& addr) {
+    // first octet: digits at dot-1, dot-2, dot-3 (right to left), then a boundary
+    const uint32_t b3 = q.x >> 24, b2 = (q.x >> 16) & 0xFF, b1 = (q.x >> 8) & 0xFF, b0 = q.x & 0xFF;
+    if (!d_is_digit(b3)) return false;
+    const bool g2 = d_is_digit(b2), g1 = g2 && d_is_digit(b1);
+    const uint32_t n1 = 1u + g2 + g1;
+    const uint32_t before = g1 ? b0 : g2 ? b1 : b2;
+    if (!d_is_boundary(before)) return false;
+    const uint32_t first = g1 ? b1 : g2 ? b2 : b3;
+    uint32_t a = g1 ? (b1 - 48) * 100 + (b2 - 48) * 10 + (b3 - 48) : g2 ? (b2 - 48) * 10 + (b3 - 48) : (b3 - 48);
+    if (a > 255 || (n1 > 1 && first == '0')) return false;
+    // r0..r2 = the 12 bytes after the dot
+    uint32_t r0 = __builtin_amdgcn_alignbyte(q.z, q.y, 1), r1 = __builtin_amdgcn_alignbyte(q.w, q.z, 1), r2 = __builtin_amdgcn_alignbyte(t4, q.w, 1);
+    uint32_t pos = dot + 1;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const uint32_t c0 = r0 & 0xFF, c1 = (r0 >> 8) & 0xFF, c2 = (r0 >> 16) & 0xFF, c3 = r0 >> 24;
+        if (!d_is_digit(c0)) return false;
+        const bool h1 = d_is_digit(c1), h2 = h1 && d_is_digit(c2);
+        const uint32_t n = 1u + h1 + h2;
+        const uint32_t v = h2 ? (c0 - 48) * 100 + (c1 - 48) * 10 + (c2 - 48) : h1 ? (c0 - 48) * 10 + (c1 - 48) : (c0 - 48);
+        if (v > 255 || (h1 && c0 == '0')) return false;
+        const uint32_t sep = h2 ? c3 : h1 ? c2 : c1;
+        a = (a << 8) | v;
+        pos += n;
+        if (o < 2) {
+            if (sep != '.') return false;
+            pos += 1;
+            // drop n + 1 bytes: first n (1..3), then one more
+            r0 = __builtin_amdgcn_alignbyte(r1, r0, n); r1 = __builtin_amdgcn_alignbyte(r2, r1, n); r2 = __builtin_amdgcn_alignbyte(0u, r2, n);
+            r0 = __builtin_amdgcn_alignbyte(r1, r0, 1); r1 = __builtin_amdgcn_alignbyte(r2, r1, 1); r2 = r2 >> 8;
+        } else if (!d_is_boundary(sep)) {
+            return false;
+        }
+    }
+    start = dot - n1; end = pos; addr = a;
+    return true;
+}
+// The same with two wide global loads; callers make sure [dot-4, dot+16) lies inside the buffer.
+__device__ __forceinline__ bool val_ipv4_fast(const uint8_t* log, uint32_t dot, uint32_t& start, uint32_t& end, uint32_t& addr) {
+    uint4 q;
+    uint32_t t4;
+    __builtin_memcpy(&q, log + dot - 4, 16);   // unaligned global_load_dwordx4 (unaligned access mode is on for gfx9+)
+    __builtin_memcpy(&t4, log + dot + 12, 4);
+    return d_ipv4_from_window(q, t4, dot, start, end, addr);
+}
+
+// IPv4 (ext:813-869, 1120-1179). `dot` is the first dot of a maximal [0-9.] run whose first octet has 1-3 digits and
+// is preceded by a boundary or the buffer start (anchor rule). The whole run must parse as a dotted quad and be
+// followed by a boundary or the end of the buffer.
+__device__ inline bool val_ipv4(const LogView& lg, uint32_t dot, uint32_t& start, uint32_t& end, uint32_t& addr) {
+    uint32_t s = dot;
+    while (s > 0 && dot - s < 3 && d_is_digit(lg.at(s - 1))) --s;
+    if (s == dot) return false;
+    if (s > 0 && !d_is_boundary(lg.at(s - 1))) return false;
+    uint32_t pos = s, a = 0;
+    for (int idx = 0; idx < 4; ++idx) {
+        uint32_t v = 0, digits = 0, first = 0;
+        while (pos < lg.len && digits < 3) {
+            uint32_t c = lg.at(pos);
+            if (!d_is_digit(c)) break;
+            if (digits == 0) first = c;
+            v = v * 10 + (c - '0');
+            ++pos;
+            ++digits;
+        }
+        if (digits == 0 || v > 255) return false;
+        if (digits > 1 && first == '0') return false;
+        a = (a << 8) | v;
+        if (idx < 3) {
+            if (pos >= lg.len || lg.at(pos) != '.') return false;
+            ++pos;
+        }
+    }
+    if (pos < lg.len && !d_is_boundary(lg.at(pos))) return false;
+    start = s; end = pos; addr = a;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ PSL
 __device__ inline bool psl_contains(const DevDb& db, uint64_t h, const uint8_t* s, uint32_t n) {
     uint32_t slot = (uint32_t)h & db.psl_mask;

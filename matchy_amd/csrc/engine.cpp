@@ -147,6 +147,41 @@ void DeviceDb::upload(const DbImage& img, int dev) {
         ip_l1.upload(l1);
         view.ip_l1 = ip_l1.p;
         bytes_uploaded += l1.size() * sizeof(uint2);
+        // /24 occupancy bitmap (2 MiB): bit v is clear iff lookup_v4 of every address under prefix v ends in "not found"
+        // within the first 24 levels. The streaming kernel drops such candidates right after validation (they are still
+        // counted), so only addresses that can hit reach k_lookup. Built by one depth-first walk of the top 24 levels.
+        std::vector<uint32_t> bm(1u << 19, 0u);
+        if (img.node_count > 0) {
+            auto set_range = [&](uint32_t first, uint32_t count) {
+                for (uint32_t v = first; v < first + count;) {
+                    if ((v & 31) == 0 && v + 32 <= first + count) { bm[v >> 5] = 0xFFFFFFFFu; v += 32; }
+                    else { bm[v >> 5] |= 1u << (v & 31); ++v; }
+                }
+            };
+            struct Frame { uint32_t node, prefix, depth; };
+            std::vector<Frame> st;
+            st.push_back({v4_start, 0u, 0u});
+            while (!st.empty()) {
+                const Frame f = st.back();
+                st.pop_back();
+                const uint2 nd = nodes[f.node];
+                for (uint32_t bit = 0; bit < 2; ++bit) {
+                    const uint32_t rec = bit ? nd.y : nd.x;
+                    const uint32_t depth = f.depth + 1;                       // levels consumed
+                    const uint32_t prefix = f.prefix | (bit << (24 - depth));  // left-aligned in 24 bits
+                    if (rec == img.node_count) continue;
+                    if (rec < img.node_count) {
+                        if (depth == 24) set_range(prefix, 1);
+                        else st.push_back({rec, prefix, depth});
+                    } else if (rec - img.node_count >= 16) {
+                        set_range(prefix, 1u << (24 - depth));
+                    }
+                }
+            }
+        }
+        ip_bm24.upload(bm);
+        view.ip_bm24 = ip_bm24.p;
+        bytes_uploaded += bm.size() * 4;
     }
     if (img.has_literal) {
         std::vector<LitSlot> slots;
@@ -254,6 +289,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters), stream));
     TokParams tp{};
     tp.log = dptr; tp.len = len; tp.flags = flags_; tp.min_labels = min_labels_;
+    tp.filter_v4 = lookup ? 1u : 0u;
     if (const char* dbg = getenv("MATCHY_AMD_DEBUG")) tp.debug = (uint32_t)atoi(dbg);
     tp.n_segs = (uint32_t)(((uint64_t)len + 1 + SEG_BYTES - 1) / SEG_BYTES);
     tp.cands = cands_.p; tp.cand_cap = (uint32_t)cands_.n;

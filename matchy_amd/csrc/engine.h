@@ -59,6 +59,7 @@ struct DeviceDb {
     int device = 0;
     DevDb view{};
     DevBuf<uint2> ip_nodes, ip_l1;
+    DevBuf<uint32_t> ip_bm24;
     DevBuf<LitSlot> lit_slots;
     DevBuf<uint8_t> lit_pool, pg, psl_pool;
     DevBuf<uint32_t> lit2pat_off, lit2pat, bloom;

@@ -1,20 +1,26 @@
 // k_anchor — stage A1 of the `matchy match` hot path on gfx950: the streaming pass over the log.
 //
 // One wavefront owns one 16 KiB segment at a time (grid-stride). Per 1 KiB block:
-//   * every lane loads 16 contiguous log bytes (one coalesced global_load_dwordx4 per lane = 1 KiB per wave),
-//   * bytes become class bytes through a 256-entry LDS table and are staged in LDS (one ds_write_b128 per lane),
-//   * 4 super-rows of 256 bytes: each lane owns one dword of class bytes (4 positions); with the previous dword and
-//     three v_alignbyte it has the classes of positions j-4..j for its 4 positions and evaluates every anchor
+//   * every lane loads 16 contiguous log bytes (one coalesced global_load_dwordx4 per lane = 1 KiB per wave; the next
+//     block's load is issued before the current block is processed),
+//   * the raw bytes go to a per-wave circular LDS window (RAW_BYTES) so that anchors can be validated later without
+//     touching HBM again; bytes become class bytes through a 256-entry LDS table and are staged in LDS as well,
+//   * 4 super-rows of 256 bytes: each lane owns one dword of class bytes (4 positions); with the neighbouring dwords
+//     and v_alignbyte it has the classes of positions j-4..j+4 for its 4 positions and evaluates every anchor
 //     pattern for all 4 at once (SWAR: shifts + ands, result in bit 0 of each byte); lanes with a hit are compacted
 //     with ballot + v_mbcnt (wavefront ballot / prefix-sum) into per-type LDS rings,
-//   * rings are moved to the global anchor lists 64 entries at a time through wave-private chunks
-//     (one atomic per 1024 anchors, coalesced 256-byte stores).
+//   * when a ring holds 64 anchors the whole wave processes them, one anchor per lane, from the LDS window:
+//     IPv4 anchors are fully validated (dotted-quad rules) and leave as candidates; domain anchors pass a cheap
+//     prefilter (last label ends within 8 bytes at a boundary and is some public suffix's last label — Bloom filter)
+//     and the survivors leave as anchor positions for k_validate. Lists are written through wave-private chunks
+//     (one atomic per chunk, coalesced stores).
 // Tokens long enough to be hashes / crypto addresses (>= 26 bytes) are found without per-byte work: the ballot of
 // "my dword has no boundary byte" gives one bit per dword, five set bits in a row below a token end are necessary
 // for such a token, and only then is the exact length computed.
 //
 // Anchor rules (exact-coverage arguments in DESIGN.md §Anchors; differential-tested against oracle/):
-//   IPv4    '.' at j preceded by 1-3 digits preceded by a boundary / buffer start  (ext:1120-1179, 813-869)
+//   IPv4    '.' at j preceded by 1-3 digits preceded by a boundary / buffer start, followed by 1-3 digits and '.'
+//                                                                                    (ext:1120-1179, 813-869)
 //   domain  byte that can start a PSL last label at j, '.' at j-1, label byte at j-2 (ext:537-628)
 //   IPv6    "::" ending at j, no third ':' before it                                (ext:1044-1116)
 //   e-mail  '@' at j                                                                 (ext:1182-1196)
@@ -27,45 +33,144 @@ constexpr int AW = 4;                   // waves per workgroup
 constexpr uint32_t BLK_BYTES = 1024;    // bytes per wave iteration
 constexpr uint32_t CS_PREFIX = 16;      // class bytes kept in front of the block (the last 4 are used)
 constexpr uint32_t QCAP = 128;          // ring entries per wave and type
+constexpr uint32_t RAW_BYTES = 4096;    // raw-byte window per wave (circular, block granular)
+constexpr uint32_t RAW_DW = RAW_BYTES / 4;
+constexpr uint32_t V4_CHUNK = 64;       // IPv4 candidates that pass the /24 bitmap are sparse: small chunks
+static_assert(SEG_BYTES % RAW_BYTES == 0 && RAW_BYTES % BLK_BYTES == 0, "window wraps on block edges inside a segment");
 
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Move `n` (<= 64) ring entries to the global list through the wave's chunk writer.
-template <class T, uint32_t CHUNK>
-__device__ __forceinline__ void flush_ring(const T* ring, uint32_t& head, uint32_t n, ChunkWriter<T, CHUNK>& cw, T* out, uint32_t cap,
-                                           uint32_t* counter, const T& sentinel) {
+// (cur << k) with the top k bits of prev shifted in at the bottom: bit i = "dword i-k", across the super-row edge
+__device__ __forceinline__ uint64_t shl_carry(uint64_t cur, uint64_t prev, int k) { return (cur << k) | (prev >> (64 - k)); }
+
+// n_dw + 1 dwords of the circular window starting at absolute byte position `a`, shifted so that byte `a` is byte 0
+template <int N>
+__device__ __forceinline__ void raw_read(const uint32_t* raw32, uint32_t a, uint32_t (&out)[N]) {
+    const uint32_t i0 = a >> 2, sh = a & 3;
+    uint32_t w[N + 1];
+#pragma unroll
+    for (int i = 0; i <= N; ++i) w[i] = raw32[(i0 + i) & (RAW_DW - 1)];
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
+}
+
+struct WaveCtx {
+    const TokParams* p;
+    const uint32_t* raw32;
+    const uint32_t* bloom;
+    const uint32_t* bm24;
+    uint32_t res_lo, res_hi;   // absolute byte range currently held by the raw window
+};
+
+// IPv4 anchors are processed in two steps so that the one global load of the pipeline (the /24 occupancy bitmap of
+// the database, DevDb::ip_bm24) has a whole ring period to arrive: drain_v4 validates up to 64 anchors, one per lane,
+// from the LDS window and issues the bitmap load; commit_v4 (called by the next drain, or at the end) appends the
+// candidates whose /24 holds database entries. Valid candidates that cannot hit are only counted.
+struct PendingV4 {
+    Candidate c{0, 0, 0, 0};
+    uint32_t word = 0;
+    bool ok = false;       // lane holds a validated candidate
+    uint32_t n_valid = 0;  // per-lane count of validated candidates (reduced into ScanCounters::cand_true at the end)
+};
+
+__device__ __forceinline__ void commit_v4(PendingV4& pd, const WaveCtx& cx, ChunkWriter<Candidate, V4_CHUNK>& cw) {
+    const TokParams& p = *cx.p;
+    const bool emit = pd.ok && ((pd.word >> ((pd.c.v4 >> 8) & 31)) & 1);
+    cw.append(emit, pd.c, p.cands, p.cand_cap, &p.counters->n_cand, Candidate{0, 0xFFFFFFFFu, 0, 0});
+    pd.ok = false;
+}
+
+__device__ __forceinline__ void drain_v4(const uint32_t* ring, uint32_t& head, uint32_t n, const WaveCtx& cx, PendingV4& pd,
+                                         ChunkWriter<Candidate, V4_CHUNK>& cw) {
     const uint32_t lane = lane_id();
+    const TokParams& p = *cx.p;
+    commit_v4(pd, cx, cw);
     __builtin_amdgcn_wave_barrier();
-    T v = sentinel;
-    if (lane < n) v = ring[(head + lane) & (QCAP - 1)];
-    cw.append(lane < n, v, out, cap, counter, sentinel);
+    if (lane < n) {
+        const uint32_t dot = ring[(head + lane) & (QCAP - 1)];
+        uint32_t s = 0, e = 0, a = 0;
+        bool ok;
+        if (dot >= cx.res_lo + 4 && dot + 16 <= cx.res_hi) {
+            uint32_t w[5];
+            raw_read<5>(cx.raw32, dot - 4, w);
+            ok = d_ipv4_from_window(make_uint4(w[0], w[1], w[2], w[3]), w[4], dot, s, e, a);
+        } else if (dot >= 4 && dot + 16 <= p.len) {
+            ok = val_ipv4_fast(p.log, dot, s, e, a);          // window not resident (segment / block edge): HBM
+        } else {
+            ok = val_ipv4(LogView{p.log, p.len}, dot, s, e, a);  // buffer edge
+        }
+        if (ok) {
+            pd.c.start = s; pd.c.len_type = (e - s) | ((uint32_t)IT_IPV4 << 24); pd.c.v4 = a;
+            pd.ok = true;
+            pd.n_valid += 1;
+            pd.word = p.filter_v4 ? cx.bm24[a >> 13] : 0xFFFFFFFFu;
+        }
+    }
     head += n;
     __builtin_amdgcn_wave_barrier();
 }
 
-// (cur << k) with the top k bits of prev shifted in at the bottom: bit i = "dword i-k", across the super-row edge
-__device__ __forceinline__ uint64_t shl_carry(uint64_t cur, uint64_t prev, int k) { return (cur << k) | (prev >> (64 - k)); }
+// Prefilter up to 64 domain anchors (first byte of the last label), one per lane; survivors go to the domain list.
+// Mirrors the first steps of val_domain (scan_kernels.hip): a '.' inside the label means a later dot owns the run, the
+// run must end at a boundary, and the label must be the last label of some public suffix. Undecidable cases (label
+// longer than 8 bytes, bytes not resident) are kept.
+__device__ __forceinline__ void drain_dom(const uint32_t* ring, uint32_t& head, uint32_t n, const WaveCtx& cx,
+                                          ChunkWriter<uint32_t, ANCHOR_CHUNK>& cw) {
+    const uint32_t lane = lane_id();
+    const TokParams& p = *cx.p;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t j = 0xFFFFFFFFu;
+    bool keep = false;
+    if (lane < n) {
+        j = ring[(head + lane) & (QCAP - 1)];
+        keep = true;
+        if (j >= cx.res_lo && j + 8 <= cx.res_hi && !(p.debug & 2)) {
+            uint32_t w[2];
+            raw_read<2>(cx.raw32, j, w);
+            uint32_t th = 2166136261u, stop = 0;
+            bool open = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (open) {
+                    const uint32_t c = ((k < 4 ? w[0] : w[1]) >> (8 * (k & 3))) & 0xFF;
+                    if (!d_is_domain_char_fast(c)) { open = false; stop = c; }
+                    else if (c == '.') { open = false; keep = false; stop = ' '; }
+                    else th = tld_hash_step(th, c);
+                }
+            }
+            if (keep && !open) {
+                const uint32_t bit = tld_hash_bit(th);
+                keep = d_is_boundary(stop) && ((cx.bloom[bit >> 5] >> (bit & 31)) & 1);
+            }
+        }
+    }
+    cw.append(keep, j, p.dom_list, p.dom_cap, &p.counters->n_dom, 0xFFFFFFFFu);
+    head += n;
+    __builtin_amdgcn_wave_barrier();
+}
 
 __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     __shared__ uint8_t ctab[256];
-    __shared__ __attribute__((aligned(16))) uint32_t cstage[AW][(CS_PREFIX + BLK_BYTES) / 4];
+    __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t cstage[AW][(CS_PREFIX + BLK_BYTES) / 4 + 4];  // + look-ahead dword
+    __shared__ __attribute__((aligned(16))) uint32_t rawst[AW][RAW_DW];
     __shared__ uint32_t q_v4[AW][QCAP];
     __shared__ uint32_t q_dom[AW][QCAP];
-    __shared__ uint2 q_misc[AW][QCAP];
-    __shared__ uint2 q_tok[AW][QCAP];
 
     ctab[threadIdx.x] = (uint8_t)(class_of(threadIdx.x) | (((db.tld_first[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1) ? C_TLD1 : 0));
+    for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += AW * 64) bloom[i] = db.tld_bloom[i];
     __syncthreads();
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t gw = blockIdx.x * AW + wave, nw = gridDim.x * AW;
     uint32_t* cs32 = cstage[wave];
+    uint32_t* raw32 = rawst[wave];
+    // the dword after the block is not staged yet when the block's last dword is examined: "anything" (all class bits)
+    if (lane == 0) cs32[(CS_PREFIX + BLK_BYTES) / 4] = 0xFFFFFFFFu;
     uint32_t* rv4 = q_v4[wave];
     uint32_t* rdom = q_dom[wave];
-    uint2* rmisc = q_misc[wave];
-    uint2* rtok = q_tok[wave];
     const uint32_t len = p.len;
     const bool en_v4 = (p.flags & EX_IPV4) != 0, en_dom = (p.flags & EX_DOMAINS) != 0;
     const bool en_v6 = (p.flags & EX_IPV6) != 0, en_at = (p.flags & EX_EMAILS) != 0;
@@ -76,13 +181,36 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
 
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t nl_count = 0;                       // per-lane '\n' count, reduced once at the end
-    uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0, mh = 0, mt = 0, kh = 0, kt = 0;  // ring heads / tails (wave-uniform)
-    ChunkWriter<uint32_t, ANCHOR_CHUNK> cw_v4, cw_dom;
+    uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0;   // ring heads / tails (wave-uniform)
+    uint32_t v4_old = 0, dom_old = 0;            // block start of the oldest ring entry (valid while the ring is non-empty)
+    ChunkWriter<Candidate, V4_CHUNK> cw_cand;
+    ChunkWriter<uint32_t, ANCHOR_CHUNK> cw_dom;
     ChunkWriter<uint2, RARE_CHUNK> cw_misc, cw_tok;  // rare anchors are sparse: small chunks keep the lists dense
-    const uint32_t S32 = 0xFFFFFFFFu;
     const uint2 S64 = make_uint2(0xFFFFFFFFu, 0xFFu);
     uint2* rare_out = reinterpret_cast<uint2*>(p.rare);
     uint2* tok_out = reinterpret_cast<uint2*>(p.tok);
+    WaveCtx cx{&p, raw32, bloom, db.ip_bm24, 0u, 0u};
+    PendingV4 pend;
+
+    // 16 bytes of block `b` for this lane; positions >= len read as ' ' (a boundary, like the end of the buffer)
+    auto load_block = [&](uint32_t b, uint32_t (&w)[4]) {
+        const uint32_t pos0 = b + lane * 16;
+        if (pos0 + 16 <= len) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p.log + pos0);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const uint32_t q = pos0 + k * 4 + bb;
+                    x |= (q < len ? (uint32_t)p.log[q] : (uint32_t)' ') << (8 * bb);
+                }
+                w[k] = x;
+            }
+        }
+    };
 
     for (uint32_t seg = gw; seg < p.n_segs; seg += nw) {
         const uint32_t seg_start = seg * SEG_BYTES;
@@ -110,25 +238,18 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             }
         }
 
+        uint32_t nx[4];
+        load_block(seg_start, nx);
         for (uint32_t blk = seg_start; blk < seg_end; blk += BLK_BYTES) {
-            // ---- stage 1 KiB: coalesced 16 B per lane, bytes -> class bytes
-            const uint32_t pos0 = blk + lane * 16;
-            uint32_t wv[4];
-            if (pos0 + 16 <= len) {
-                uint4 v = *reinterpret_cast<const uint4*>(p.log + pos0);
-                wv[0] = v.x; wv[1] = v.y; wv[2] = v.z; wv[3] = v.w;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t x = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        uint32_t q = pos0 + k * 4 + b;
-                        x |= (q < len ? (uint32_t)p.log[q] : (uint32_t)' ') << (8 * b);
-                    }
-                    wv[k] = x;
-                }
+            // ---- anchors whose look-back bytes are about to be overwritten in the raw window leave first
+            if (blk >= seg_start + RAW_BYTES - BLK_BYTES) {
+                const uint32_t lim = blk - (RAW_BYTES - BLK_BYTES);   // entries of blocks <= lim expire
+                if (v4t != v4h && v4_old <= lim) drain_v4(rv4, v4h, v4t - v4h, cx, pend, cw_cand);
+                if (dt != dh && dom_old <= lim) drain_dom(rdom, dh, dt - dh, cx, cw_dom);
             }
+            // ---- stage 1 KiB: raw bytes into the window, bytes -> class bytes; prefetch the next block
+            uint32_t wv[4] = {nx[0], nx[1], nx[2], nx[3]};
+            if (blk + BLK_BYTES < seg_end) load_block(blk + BLK_BYTES, nx);
             uint32_t cv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -138,8 +259,11 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                 nl_count += __popc(cv[k] & (C_NL * LSB));
             }
             __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<uint4*>(&raw32[((blk & (RAW_BYTES - 1)) >> 2) + lane * 4]) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
             *reinterpret_cast<uint4*>(&cs32[CS_PREFIX / 4 + lane * 4]) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
             __builtin_amdgcn_wave_barrier();
+            cx.res_hi = blk + BLK_BYTES;
+            cx.res_lo = cx.res_hi - seg_start > RAW_BYTES ? cx.res_hi - RAW_BYTES : seg_start;
 
             // ---- 4 super-rows of 256 bytes: every lane owns one dword of class bytes (4 positions) and evaluates the
             // anchor patterns for its 4 positions at once (SWAR on bit 0 of each byte)
@@ -162,13 +286,20 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                             rdom[(dt + mbcnt64(m)) & (QCAP - 1)] = pos + ((uint32_t)(__ffs((int)f) - 1) >> 3);
                             f &= f - 1;
                         }
+                        if (dt == dh) dom_old = blk;
                         dt += (uint32_t)__popcll(m);
-                        if (dt - dh >= 64) flush_ring(rdom, dh, 64u, cw_dom, p.dom_list, p.dom_cap, &p.counters->n_dom, S32);
+                        if (dt - dh >= 64) { drain_dom(rdom, dh, 64u, cx, cw_dom); dom_old = blk; }
                     }
                 }
                 if (en_v4) {
                     // '.' at j (bit 2), digit at j-1 (bit 1), then boundary | digit,boundary | digit,digit,boundary
                     uint32_t f = (A >> 2) & (A1 >> 1) & (A2 | ((A2 >> 1) & (A3 | ((A3 >> 1) & P)))) & LSB;
+                    // ... and followed by a second octet and a second dot: digit, then '.' | digit,'.' | digit,digit,'.'
+                    // (necessary for a dotted quad; drops "HTTP/1.1", "Mozilla/5.0", "Safari/537.36" style anchors)
+                    const uint32_t N = cs32[d + 1];
+                    const uint32_t F1 = __builtin_amdgcn_alignbyte(N, A, 1), F2 = __builtin_amdgcn_alignbyte(N, A, 2),
+                                   F3 = __builtin_amdgcn_alignbyte(N, A, 3);
+                    f &= (F1 >> 1) & ((F2 >> 2) | ((F2 >> 1) & ((F3 >> 2) | ((F3 >> 1) & (N >> 2)))));
                     for (;;) {
                         const uint64_t m = __ballot(f != 0);
                         if (!m) break;
@@ -176,8 +307,9 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                             rv4[(v4t + mbcnt64(m)) & (QCAP - 1)] = pos + ((uint32_t)(__ffs((int)f) - 1) >> 3);
                             f &= f - 1;
                         }
+                        if (v4t == v4h) v4_old = blk;
                         v4t += (uint32_t)__popcll(m);
-                        if (v4t - v4h >= 64) flush_ring(rv4, v4h, 64u, cw_v4, p.v4_list, p.v4_cap, &p.counters->n_v4, S32);
+                        if (v4t - v4h >= 64) { drain_v4(rv4, v4h, 64u, cx, pend, cw_cand); v4_old = blk; }
                     }
                 }
                 if (en_rare_row) {
@@ -188,13 +320,14 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                     for (;;) {
                         const uint64_t m = __ballot(f != 0);
                         if (!m) break;
-                        if (f) {
+                        uint2 v = S64;
+                        const bool has = f != 0;
+                        if (has) {
                             const uint32_t bit = (uint32_t)(__ffs((int)f) - 1);
-                            rmisc[(mt + mbcnt64(m)) & (QCAP - 1)] = make_uint2(pos + (bit >> 3), (bit & 7) ? (uint32_t)RARE_AT : (uint32_t)RARE_V6);
+                            v = make_uint2(pos + (bit >> 3), (bit & 7) ? (uint32_t)RARE_AT : (uint32_t)RARE_V6);
                             f &= f - 1;
                         }
-                        mt += (uint32_t)__popcll(m);
-                        if (mt - mh >= 64) flush_ring(rmisc, mh, 64u, cw_misc, rare_out, p.rare_cap, &p.counters->n_rare, S64);
+                        cw_misc.append(has, v, rare_out, p.rare_cap, &p.counters->n_rare, S64);
                     }
                 }
                 if (en_tok) {
@@ -218,12 +351,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                         const uint32_t j = pos + ((uint32_t)(__ffs((int)low) - 1) >> 3);
                         const uint32_t tl = (uint32_t)((int32_t)j - 1 - lb);
                         const bool tok = cand && ((tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128);
-                        const uint64_t m = __ballot(tok);
-                        if (m) {
-                            if (tok) rtok[(kt + mbcnt64(m)) & (QCAP - 1)] = make_uint2(j - tl, (uint32_t)RARE_TOK | (tl << 8));
-                            kt += (uint32_t)__popcll(m);
-                            if (kt - kh >= 64) flush_ring(rtok, kh, 64u, cw_tok, tok_out, p.tok_cap, &p.counters->n_tok, S64);
-                        }
+                        cw_tok.append(tok, make_uint2(j - tl, (uint32_t)RARE_TOK | (tl << 8)), tok_out, p.tok_cap, &p.counters->n_tok, S64);
                     }
                     // carry: last boundary byte of this super-row, and its Z bits
                     const uint64_t nz = ~Z;
@@ -240,16 +368,22 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             if (lane == 0) cs32[CS_PREFIX / 4 - 1] = cs32[(CS_PREFIX + BLK_BYTES) / 4 - 1];
             __builtin_amdgcn_wave_barrier();
         }
+        // the next segment of this wave is not contiguous: finish the rings while their bytes are still in the window
+        if (dt != dh) drain_dom(rdom, dh, dt - dh, cx, cw_dom);
+        if (v4t != v4h) drain_v4(rv4, v4h, v4t - v4h, cx, pend, cw_cand);
     }
-    // drain what is left in the rings, then mark the unused tail of every open chunk
-    if (dt != dh) flush_ring(rdom, dh, dt - dh, cw_dom, p.dom_list, p.dom_cap, &p.counters->n_dom, S32);
-    if (v4t != v4h) flush_ring(rv4, v4h, v4t - v4h, cw_v4, p.v4_list, p.v4_cap, &p.counters->n_v4, S32);
-    if (mt != mh) flush_ring(rmisc, mh, mt - mh, cw_misc, rare_out, p.rare_cap, &p.counters->n_rare, S64);
-    if (kt != kh) flush_ring(rtok, kh, kt - kh, cw_tok, tok_out, p.tok_cap, &p.counters->n_tok, S64);
-    cw_dom.pad_rest(p.dom_list, p.dom_cap, S32);
-    cw_v4.pad_rest(p.v4_list, p.v4_cap, S32);
+    commit_v4(pend, cx, cw_cand);
+    // mark the unused tail of every open chunk
+    cw_dom.pad_rest(p.dom_list, p.dom_cap, 0xFFFFFFFFu);
+    cw_cand.pad_rest(p.cands, p.cand_cap, Candidate{0, 0xFFFFFFFFu, 0, 0});
     cw_misc.pad_rest(rare_out, p.rare_cap, S64);
     cw_tok.pad_rest(tok_out, p.tok_cap, S64);
+    {
+        uint32_t nv = pend.n_valid;  // validated IPv4 candidates, listed or not
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nv += __shfl_down(nv, off);
+        if (lane == 0 && nv) atomicAdd(&p.counters->cand_true, nv);
+    }
     // line count: wave reduction of the per-lane counts, one atomic per wave
     unsigned long long lines = nl_count;
 #pragma unroll

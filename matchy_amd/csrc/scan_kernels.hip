@@ -23,82 +23,29 @@ namespace mxy {
 
 
 // ------------------------------------------------------------------------------------------------ stage A validators
-// IPv4 (ext:813-869, 1120-1179). `dot` is the first dot of a maximal [0-9.] run whose first octet has 1-3 digits and
-// is preceded by a boundary or the buffer start (anchor rule). The whole run must parse as a dotted quad and be
-// followed by a boundary or the end of the buffer.
-__device__ bool val_ipv4(const LogView& lg, uint32_t dot, uint32_t& start, uint32_t& end, uint32_t& addr) {
-    uint32_t s = dot;
-    while (s > 0 && dot - s < 3 && d_is_digit(lg.at(s - 1))) --s;
-    if (s == dot) return false;
-    if (s > 0 && !d_is_boundary(lg.at(s - 1))) return false;
-    uint32_t pos = s, a = 0;
-    for (int idx = 0; idx < 4; ++idx) {
-        uint32_t v = 0, digits = 0, first = 0;
-        while (pos < lg.len && digits < 3) {
-            uint32_t c = lg.at(pos);
-            if (!d_is_digit(c)) break;
-            if (digits == 0) first = c;
-            v = v * 10 + (c - '0');
-            ++pos;
-            ++digits;
-        }
-        if (digits == 0 || v > 255) return false;
-        if (digits > 1 && first == '0') return false;
-        a = (a << 8) | v;
-        if (idx < 3) {
-            if (pos >= lg.len || lg.at(pos) != '.') return false;
-            ++pos;
-        }
+// Backward byte reader over log[.., pos): 8 bytes per load, the next 8 prefetched while the current ones are consumed,
+// so the dependent-load chain of a right-to-left walk is one L1/L2 round trip per 8 bytes instead of one per byte.
+struct BackReader {
+    const uint8_t* p;
+    uint32_t pos;   // next() returns p[pos - 1]
+    uint32_t cb;    // cur holds p[cb, cb + 8), shifted so that the unread bytes [cb, cb + k) sit at the top
+    uint32_t k;
+    uint64_t cur, nxt;
+    __device__ __forceinline__ static uint64_t load8(const uint8_t* a) { uint64_t v; __builtin_memcpy(&v, a, 8); return v; }
+    __device__ __forceinline__ void init(const uint8_t* base, uint32_t q) {
+        p = base; pos = q; cb = 0; k = 0; cur = 0; nxt = 0;
+        if (q >= 16) { cb = q - 8; k = 8; cur = load8(p + cb); nxt = load8(p + cb - 8); }
     }
-    if (pos < lg.len && !d_is_boundary(lg.at(pos))) return false;
-    start = s; end = pos; addr = a;
-    return true;
-}
-
-// Same rules with two wide loads instead of ~17 dependent byte loads: the 20 bytes [dot-4, dot+16) are fetched at once
-// and parsed in registers. Callers use it only when that window lies inside the buffer.
-__device__ bool val_ipv4_fast(const uint8_t* log, uint32_t dot, uint32_t& start, uint32_t& end, uint32_t& addr) {
-    uint4 q;
-    uint32_t t4;
-    __builtin_memcpy(&q, log + dot - 4, 16);   // unaligned global_load_dwordx4 (unaligned access mode is on for gfx9+)
-    __builtin_memcpy(&t4, log + dot + 12, 4);
-    // first octet: digits at dot-1, dot-2, dot-3 (right to left), then a boundary
-    const uint32_t b3 = q.x >> 24, b2 = (q.x >> 16) & 0xFF, b1 = (q.x >> 8) & 0xFF, b0 = q.x & 0xFF;
-    if (!d_is_digit(b3)) return false;
-    const bool g2 = d_is_digit(b2), g1 = g2 && d_is_digit(b1);
-    const uint32_t n1 = 1u + g2 + g1;
-    const uint32_t before = g1 ? b0 : g2 ? b1 : b2;
-    if (!d_is_boundary(before)) return false;
-    const uint32_t first = g1 ? b1 : g2 ? b2 : b3;
-    uint32_t a = g1 ? (b1 - 48) * 100 + (b2 - 48) * 10 + (b3 - 48) : g2 ? (b2 - 48) * 10 + (b3 - 48) : (b3 - 48);
-    if (a > 255 || (n1 > 1 && first == '0')) return false;
-    // r0..r2 = the 12 bytes after the dot
-    uint32_t r0 = __builtin_amdgcn_alignbyte(q.z, q.y, 1), r1 = __builtin_amdgcn_alignbyte(q.w, q.z, 1), r2 = __builtin_amdgcn_alignbyte(t4, q.w, 1);
-    uint32_t pos = dot + 1;
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        const uint32_t c0 = r0 & 0xFF, c1 = (r0 >> 8) & 0xFF, c2 = (r0 >> 16) & 0xFF, c3 = r0 >> 24;
-        if (!d_is_digit(c0)) return false;
-        const bool h1 = d_is_digit(c1), h2 = h1 && d_is_digit(c2);
-        const uint32_t n = 1u + h1 + h2;
-        const uint32_t v = h2 ? (c0 - 48) * 100 + (c1 - 48) * 10 + (c2 - 48) : h1 ? (c0 - 48) * 10 + (c1 - 48) : (c0 - 48);
-        if (v > 255 || (h1 && c0 == '0')) return false;
-        const uint32_t sep = h2 ? c3 : h1 ? c2 : c1;
-        a = (a << 8) | v;
-        pos += n;
-        if (o < 2) {
-            if (sep != '.') return false;
-            pos += 1;
-            // drop n + 1 bytes: first n (1..3), then one more
-            r0 = __builtin_amdgcn_alignbyte(r1, r0, n); r1 = __builtin_amdgcn_alignbyte(r2, r1, n); r2 = __builtin_amdgcn_alignbyte(0u, r2, n);
-            r0 = __builtin_amdgcn_alignbyte(r1, r0, 1); r1 = __builtin_amdgcn_alignbyte(r2, r1, 1); r2 = r2 >> 8;
-        } else if (!d_is_boundary(sep)) {
-            return false;
-        }
+    __device__ __forceinline__ uint32_t next() {
+        --pos;
+        if (pos < 16) return p[pos];  // the first bytes of the buffer: plain loads (no read before the buffer)
+        if (k == 0) { cur = nxt; cb -= 8; k = 8; nxt = cb >= 8 ? load8(p + cb - 8) : 0ull; }
+        const uint32_t c = (uint32_t)(cur >> 56);
+        cur <<= 8;
+        --k;
+        return c;
     }
-    start = dot - n1; end = pos; addr = a;
-    return true;
-}
+};
 
 // Domain (ext:537-689). `j` is the first byte after a dot (anchor: label-char, '.', label-char). Only the LAST dot
 // of a maximal domain-char run owns the run; it validates the run as a whole.
@@ -106,6 +53,7 @@ __device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* b
                            uint32_t& start, uint32_t& end) {
     uint32_t p = j, th = 2166136261u;
     bool open = true;  // last label not yet terminated
+    uint32_t stop_c = 0x100;  // byte that ended the run on the right (0x100 = buffer end)
     if (j + 8 <= lg.len) {
         // the first 8 bytes of the last label in one load; most labels (com, net, css, html, ...) end inside it
         uint2 w;
@@ -114,7 +62,7 @@ __device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* b
         for (int k = 0; k < 8; ++k) {
             if (open) {
                 const uint32_t c = ((k < 4 ? w.x : w.y) >> (8 * (k & 3))) & 0xFF;
-                if (!d_is_domain_char_fast(c)) open = false;
+                if (!d_is_domain_char_fast(c)) { open = false; stop_c = c; }
                 else {
                     if (c == '.') return false;  // a later dot owns this run
                     th = tld_hash_step(th, c);
@@ -125,27 +73,29 @@ __device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* b
     }
     while (open && p < lg.len) {
         uint32_t c = lg.at(p);
-        if (!d_is_domain_char_fast(c)) break;
+        if (!d_is_domain_char_fast(c)) { stop_c = c; break; }
         if (c == '.') return false;  // a later dot owns this run
         th = tld_hash_step(th, c);
         ++p;
     }
     uint32_t e = p;
     if (e - j > db.max_tld_len) return false;
+    if (stop_c != 0x100 && !d_is_boundary(stop_c)) return false;  // boundary (or buffer end) after the run (ext:600-606)
     uint32_t bit = tld_hash_bit(th);
     if (!((bloom[bit >> 5] >> (bit & 31)) & 1)) return false;  // last label is no suffix's last label -> no PSL hit possible
     // walk back to the run start: PSL probes at dots (first hit suffices), label rules of is_valid_domain (ext:637-689)
     uint64_t rh = psl_hash_init();
     bool found = false, bad = false, high = false;
     uint32_t labels = 1, cur = 0, last_c = 0;
-    uint32_t q = e;
-    while (q > 0) {
-        uint32_t c = lg.at(q - 1);
-        if (!d_is_domain_char_fast(c)) break;
-        --q;
+    uint32_t first_c = 0x100;  // byte in front of the run (0x100 = buffer start)
+    BackReader br;
+    br.init(lg.p, e);
+    while (br.pos > 0) {
+        uint32_t c = br.next();
+        if (!d_is_domain_char_fast(c)) { first_c = c; ++br.pos; break; }
         if (c == '.') {
             if (cur == 0 || last_c == '-') bad = true;
-            if (!found && !bad) found = psl_contains(db, psl_hash_finish(rh), lg.p + q + 1, e - q - 1);
+            if (!found && !bad) found = psl_contains(db, psl_hash_finish(rh), lg.p + br.pos + 1, e - br.pos - 1);
             ++labels;
             cur = 0;
         } else {
@@ -156,11 +106,10 @@ __device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* b
         rh = psl_hash_step(rh, (uint8_t)c);
         last_c = c;
     }
-    uint32_t s = q;
+    uint32_t s = br.pos;
     if (cur == 0 || last_c == '-') bad = true;  // leftmost label empty / starts with '-'
     if (bad || !found || labels < min_labels) return false;
-    if (s > 0 && !d_is_boundary(lg.at(s - 1))) return false;
-    if (e < lg.len && !d_is_boundary(lg.at(e))) return false;
+    if (first_c != 0x100 && !d_is_boundary(first_c)) return false;
     if (high && !d_valid_utf8(lg.p + s, e - s)) return false;
     start = s; end = e;
     return true;

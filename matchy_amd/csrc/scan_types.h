@@ -52,6 +52,7 @@ struct PslSlot { uint64_t hash; uint32_t off; uint32_t len; };              // l
 struct DevDb {
     // IP tree, re-laid out as one uint2 {left,right} per node (records widened to 32 bit, host byte order)
     const uint2* ip_nodes;
+    const uint32_t* ip_bm24; // 2^24 bits: bit v set iff the first 24 IPv4 levels for prefix v do not end in "not found"
     const uint2* ip_l1;      // 65536 entries: outcome of the first 16 IPv4 levels (x = kind | prefix << 8, y = node / data offset)
     uint32_t node_count;
     uint32_t ip_version;     // 4 or 6
@@ -109,7 +110,8 @@ struct TokParams {
     uint32_t len;
     uint32_t flags;           // ExtractFlags
     uint32_t min_labels;
-    uint32_t debug;           // profiling only: bit0 = drop anchors instead of validating them
+    uint32_t debug;           // profiling only
+    uint32_t filter_v4;       // 1: IPv4 candidates whose /24 has no database entry are counted but not listed (lookup scans)
     uint32_t n_segs;
     Candidate* cands;
     uint32_t cand_cap;
