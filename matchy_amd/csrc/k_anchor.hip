@@ -151,10 +151,19 @@ __device__ __forceinline__ void drain_dom(const uint32_t* ring, uint32_t& head, 
     __builtin_amdgcn_wave_barrier();
 }
 
+// value of lane-1 / lane+1 (DPP wave shift: no LDS traffic); lane 0 / lane 63 get `edge`
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+// index (0..3) of the highest non-zero byte of a word whose bytes are 0 or 1
+__device__ __forceinline__ uint32_t top_byte(uint32_t x) { return (31u - (uint32_t)__clz((int)x)) >> 3; }
+
 __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     __shared__ uint8_t ctab[256];
     __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
-    __shared__ __attribute__((aligned(16))) uint32_t cstage[AW][(CS_PREFIX + BLK_BYTES) / 4 + 4];  // + look-ahead dword
     __shared__ __attribute__((aligned(16))) uint32_t rawst[AW][RAW_DW];
     __shared__ uint32_t q_v4[AW][QCAP];
     __shared__ uint32_t q_dom[AW][QCAP];
@@ -165,10 +174,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t gw = blockIdx.x * AW + wave, nw = gridDim.x * AW;
-    uint32_t* cs32 = cstage[wave];
     uint32_t* raw32 = rawst[wave];
-    // the dword after the block is not staged yet when the block's last dword is examined: "anything" (all class bits)
-    if (lane == 0) cs32[(CS_PREFIX + BLK_BYTES) / 4] = 0xFFFFFFFFu;
     uint32_t* rv4 = q_v4[wave];
     uint32_t* rdom = q_dom[wave];
     const uint32_t len = p.len;
@@ -216,19 +222,19 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         const uint32_t seg_start = seg * SEG_BYTES;
         // positions 0..len are scanned: position `len` (padding, class "boundary") closes a trailing token
         const uint32_t seg_end = min(seg_start + SEG_BYTES, len + 1);
-        if (lane == 0) {
-            uint32_t pre = C_B * LSB;  // before the buffer: boundary
-            if (seg_start) {
-                pre = 0;
-                for (uint32_t k = 0; k < 4; ++k) pre |= (uint32_t)ctab[p.log[seg_start - 4 + k]] << (8 * k);
-            }
-            cs32[CS_PREFIX / 4 - 1] = pre;
+        // classes of the 4 bytes in front of the segment (before the buffer: boundary), wave-uniform
+        uint32_t carryP = C_B * LSB;
+        if (seg_start) {
+            carryP = 0;
+            for (uint32_t k = 0; k < 4; ++k) carryP |= (uint32_t)ctab[p.log[seg_start - 4 + k]] << (8 * k);
+            carryP = __builtin_amdgcn_readfirstlane(carryP);
         }
         // token state carried along the segment: position of the last boundary byte seen, and the boundary-free bits
-        // of the previous super-row's dwords. At a segment start nothing is known about the dwords before it, so they
-        // are taken as boundary-free (more exact checks, never fewer) and lastB comes from a 256-byte look-back.
+        // of the previous block's dwords (Zp[k] bit L = dword k of lane L). At a segment start nothing is known about
+        // the dwords before it, so they are taken as boundary-free (more exact checks, never fewer) and lastB comes
+        // from a 256-byte look-back.
         int32_t lastB = -1;
-        uint64_t Zprev = ~0ull;
+        uint64_t Zp[4] = {~0ull, ~0ull, ~0ull, ~0ull};
         if (en_tok && seg_start) {
             lastB = (int32_t)seg_start - 257;  // "far": a token reaching back this far is longer than 128 bytes
             for (uint32_t base = seg_start - 256; base < seg_start; base += 64) {
@@ -247,126 +253,147 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                 if (v4t != v4h && v4_old <= lim) drain_v4(rv4, v4h, v4t - v4h, cx, pend, cw_cand);
                 if (dt != dh && dom_old <= lim) drain_dom(rdom, dh, dt - dh, cx, cw_dom);
             }
-            // ---- stage 1 KiB: raw bytes into the window, bytes -> class bytes; prefetch the next block
+            // ---- this lane's 16 bytes: raw bytes into the window, bytes -> class bytes; prefetch the next block
             uint32_t wv[4] = {nx[0], nx[1], nx[2], nx[3]};
             if (blk + BLK_BYTES < seg_end) load_block(blk + BLK_BYTES, nx);
-            uint32_t cv[4];
+            // X[0] = classes of the 4 bytes before this lane's bytes, X[1..4] = its own 16, X[5] = the 4 after
+            uint32_t X[6];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                uint32_t x = wv[k];
-                cv[k] = (uint32_t)ctab[x & 0xFF] | ((uint32_t)ctab[(x >> 8) & 0xFF] << 8) | ((uint32_t)ctab[(x >> 16) & 0xFF] << 16) |
-                        ((uint32_t)ctab[x >> 24] << 24);
-                nl_count += __popc(cv[k] & (C_NL * LSB));
+                const uint32_t x = wv[k];
+                X[k + 1] = (uint32_t)ctab[x & 0xFF] | ((uint32_t)ctab[(x >> 8) & 0xFF] << 8) | ((uint32_t)ctab[(x >> 16) & 0xFF] << 16) |
+                           ((uint32_t)ctab[x >> 24] << 24);
+                nl_count += __popc(X[k + 1] & (C_NL * LSB));
             }
             __builtin_amdgcn_wave_barrier();
             *reinterpret_cast<uint4*>(&raw32[((blk & (RAW_BYTES - 1)) >> 2) + lane * 4]) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-            *reinterpret_cast<uint4*>(&cs32[CS_PREFIX / 4 + lane * 4]) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
             __builtin_amdgcn_wave_barrier();
             cx.res_hi = blk + BLK_BYTES;
             cx.res_lo = cx.res_hi - seg_start > RAW_BYTES ? cx.res_hi - RAW_BYTES : seg_start;
+            X[0] = from_prev_lane(X[4], carryP);
+            // the bytes after lane 63's are in the next block: "anything" (all class bits) keeps the look-ahead test of
+            // the IPv4 anchor conservative there
+            X[5] = from_next_lane(X[1], 0xFFFFFFFFu);
+            carryP = (uint32_t)__builtin_amdgcn_readlane((int)X[4], 63);
+            const uint32_t pos0 = blk + lane * 16;
 
-            // ---- 4 super-rows of 256 bytes: every lane owns one dword of class bytes (4 positions) and evaluates the
-            // anchor patterns for its 4 positions at once (SWAR on bit 0 of each byte)
+            // ---- every anchor pattern for the lane's 16 positions (SWAR on bit 0 of each byte, 4 dwords); the flags of
+            // dword k go to bit k of each byte: bit (8 b + k) <-> position 4 k + b
+            uint32_t Fd = 0, F4 = 0, Fm = 0, bl[4], A1s[4];
 #pragma unroll
-            for (uint32_t sr = 0; sr < 4; ++sr) {
-                const uint32_t d = CS_PREFIX / 4 + sr * 64 + lane;
-                const uint32_t A = cs32[d], P = cs32[d - 1];
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t A = X[k + 1], P = X[k], N = X[k + 2];
                 const uint32_t A1 = __builtin_amdgcn_alignbyte(A, P, 3);  // classes of positions pos-1 .. pos+2
                 const uint32_t A2 = __builtin_amdgcn_alignbyte(A, P, 2);  // pos-2 .. pos+1
                 const uint32_t A3 = __builtin_amdgcn_alignbyte(A, P, 1);  // pos-3 .. pos
-                const uint32_t sr_base = blk + sr * 256;
-                const uint32_t pos = sr_base + lane * 4;
-                if (en_dom) {
-                    // TLD1 at j (bit 7), '.' at j-1 (bit 2), label byte at j-2 (bit 5)
-                    uint32_t f = (A >> 7) & (A1 >> 2) & (A2 >> 5) & LSB;
-                    for (;;) {
-                        const uint64_t m = __ballot(f != 0);
-                        if (!m) break;
-                        if (f) {
-                            rdom[(dt + mbcnt64(m)) & (QCAP - 1)] = pos + ((uint32_t)(__ffs((int)f) - 1) >> 3);
-                            f &= f - 1;
-                        }
-                        if (dt == dh) dom_old = blk;
-                        dt += (uint32_t)__popcll(m);
-                        if (dt - dh >= 64) { drain_dom(rdom, dh, 64u, cx, cw_dom); dom_old = blk; }
-                    }
-                }
+                bl[k] = A & LSB;
+                A1s[k] = A1;
+                // domain: TLD1 at j (bit 7), '.' at j-1 (bit 2), label byte at j-2 (bit 5)
+                if (en_dom) Fd |= ((A >> 7) & (A1 >> 2) & (A2 >> 5) & LSB) << k;
                 if (en_v4) {
                     // '.' at j (bit 2), digit at j-1 (bit 1), then boundary | digit,boundary | digit,digit,boundary
                     uint32_t f = (A >> 2) & (A1 >> 1) & (A2 | ((A2 >> 1) & (A3 | ((A3 >> 1) & P)))) & LSB;
                     // ... and followed by a second octet and a second dot: digit, then '.' | digit,'.' | digit,digit,'.'
                     // (necessary for a dotted quad; drops "HTTP/1.1", "Mozilla/5.0", "Safari/537.36" style anchors)
-                    const uint32_t N = cs32[d + 1];
                     const uint32_t F1 = __builtin_amdgcn_alignbyte(N, A, 1), F2 = __builtin_amdgcn_alignbyte(N, A, 2),
                                    F3 = __builtin_amdgcn_alignbyte(N, A, 3);
                     f &= (F1 >> 1) & ((F2 >> 2) | ((F2 >> 1) & ((F3 >> 2) | ((F3 >> 1) & (N >> 2)))));
-                    for (;;) {
-                        const uint64_t m = __ballot(f != 0);
-                        if (!m) break;
-                        if (f) {
-                            rv4[(v4t + mbcnt64(m)) & (QCAP - 1)] = pos + ((uint32_t)(__ffs((int)f) - 1) >> 3);
-                            f &= f - 1;
-                        }
-                        if (v4t == v4h) v4_old = blk;
-                        v4t += (uint32_t)__popcll(m);
-                        if (v4t - v4h >= 64) { drain_v4(rv4, v4h, 64u, cx, pend, cw_cand); v4_old = blk; }
-                    }
+                    F4 |= f << k;
                 }
-                if (en_rare_row) {
-                    // "::" ending at j without a third ':' (bit 3 -> flag bit 0); '@' at j (bit 4 -> flag bit 1)
-                    uint32_t f = 0;
-                    if (en_v6) f |= (A >> 3) & (A1 >> 3) & ~(A2 >> 3) & LSB;
-                    if (en_at) f |= (A >> 3) & (LSB << 1);
-                    for (;;) {
-                        const uint64_t m = __ballot(f != 0);
-                        if (!m) break;
-                        uint2 v = S64;
-                        const bool has = f != 0;
-                        if (has) {
-                            const uint32_t bit = (uint32_t)(__ffs((int)f) - 1);
-                            v = make_uint2(pos + (bit >> 3), (bit & 7) ? (uint32_t)RARE_AT : (uint32_t)RARE_V6);
-                            f &= f - 1;
-                        }
-                        cw_misc.append(has, v, rare_out, p.rare_cap, &p.counters->n_rare, S64);
+                // "::" ending at j without a third ':' (bit 3) -> flag bits 0..3; '@' at j (bit 4) -> flag bits 4..7
+                if (en_v6) Fm |= ((A >> 3) & (A1 >> 3) & ~(A2 >> 3) & LSB) << k;
+                if (en_at) Fm |= ((A >> 4) & LSB) << (4 + k);
+            }
+            if (en_dom) {
+                for (;;) {
+                    const uint64_t m = __ballot(Fd != 0);
+                    if (!m) break;
+                    if (Fd) {
+                        const uint32_t bit = (uint32_t)(__ffs((int)Fd) - 1);
+                        rdom[(dt + mbcnt64(m)) & (QCAP - 1)] = pos0 + ((bit & 7) << 2) + (bit >> 3);
+                        Fd &= Fd - 1;
                     }
-                }
-                if (en_tok) {
-                    // Z: one bit per dword of this super-row, set when the dword holds no boundary byte.
-                    const uint32_t bl = A & LSB;
-                    const uint64_t Z = __ballot(bl == 0);
-                    // A token of >= 26 bytes that ends in dword i leaves dwords i-1..i-5 boundary-free (necessary).
-                    const uint64_t C5 = shl_carry(Z, Zprev, 1) & shl_carry(Z, Zprev, 2) & shl_carry(Z, Zprev, 3) & shl_carry(Z, Zprev, 4) &
-                                        shl_carry(Z, Zprev, 5);
-                    // Only the lowest boundary byte of a dword can close a long token; it must follow a non-boundary byte.
-                    const uint32_t low = bl & (0u - bl);
-                    const bool cand = (low & ~A1) != 0 && ((C5 >> lane) & 1);
-                    const uint64_t cm = __ballot(cand);
-                    if (cm) {
-                        // exact length: last boundary before my dword = highest boundary byte of the nearest lower dword
-                        // that has one (this super-row), else the carried lastB
-                        const uint64_t mlt = ~Z & lt_mask;
-                        const uint32_t e = mlt ? (uint32_t)(63 - __clzll((unsigned long long)mlt)) : 0u;
-                        const uint32_t Ae = (uint32_t)__shfl((int)bl, (int)e);
-                        const int32_t lb = mlt ? (int32_t)(sr_base + e * 4 + ((31u - (uint32_t)__clz((int)Ae)) >> 3)) : lastB;
-                        const uint32_t j = pos + ((uint32_t)(__ffs((int)low) - 1) >> 3);
-                        const uint32_t tl = (uint32_t)((int32_t)j - 1 - lb);
-                        const bool tok = cand && ((tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128);
-                        cw_tok.append(tok, make_uint2(j - tl, (uint32_t)RARE_TOK | (tl << 8)), tok_out, p.tok_cap, &p.counters->n_tok, S64);
-                    }
-                    // carry: last boundary byte of this super-row, and its Z bits
-                    const uint64_t nz = ~Z;
-                    if (nz) {
-                        const uint32_t e = (uint32_t)(63 - __clzll((unsigned long long)nz));
-                        const uint32_t Ae = (uint32_t)__builtin_amdgcn_readlane((int)bl, (int)e);
-                        lastB = (int32_t)(sr_base + e * 4 + ((31u - (uint32_t)__clz((int)Ae)) >> 3));
-                    }
-                    Zprev = Z;
+                    if (dt == dh) dom_old = blk;
+                    dt += (uint32_t)__popcll(m);
+                    if (dt - dh >= 64) { drain_dom(rdom, dh, 64u, cx, cw_dom); dom_old = blk; }
                 }
             }
-            // keep the last 4 class bytes as the next block's prefix
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) cs32[CS_PREFIX / 4 - 1] = cs32[(CS_PREFIX + BLK_BYTES) / 4 - 1];
-            __builtin_amdgcn_wave_barrier();
+            if (en_v4) {
+                for (;;) {
+                    const uint64_t m = __ballot(F4 != 0);
+                    if (!m) break;
+                    if (F4) {
+                        const uint32_t bit = (uint32_t)(__ffs((int)F4) - 1);
+                        rv4[(v4t + mbcnt64(m)) & (QCAP - 1)] = pos0 + ((bit & 7) << 2) + (bit >> 3);
+                        F4 &= F4 - 1;
+                    }
+                    if (v4t == v4h) v4_old = blk;
+                    v4t += (uint32_t)__popcll(m);
+                    if (v4t - v4h >= 64) { drain_v4(rv4, v4h, 64u, cx, pend, cw_cand); v4_old = blk; }
+                }
+            }
+            if (en_rare_row) {
+                for (;;) {
+                    const uint64_t m = __ballot(Fm != 0);
+                    if (!m) break;
+                    uint2 v = S64;
+                    const bool has = Fm != 0;
+                    if (has) {
+                        const uint32_t bit = (uint32_t)(__ffs((int)Fm) - 1);
+                        v = make_uint2(pos0 + ((bit & 3) << 2) + (bit >> 3), (bit & 4) ? (uint32_t)RARE_AT : (uint32_t)RARE_V6);
+                        Fm &= Fm - 1;
+                    }
+                    cw_misc.append(has, v, rare_out, p.rare_cap, &p.counters->n_rare, S64);
+                }
+            }
+            if (en_tok) {
+                // Z[k]: bit L set when dword k of lane L holds no boundary byte (dword index in the block = 4 L + k)
+                uint64_t Z[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Z[k] = __ballot(bl[k] == 0);
+                // A token of >= 26 bytes that ends in dword i leaves dwords i-1..i-5 boundary-free (necessary); only the
+                // lowest boundary byte of a dword can close a long token and it must follow a non-boundary byte.
+                uint32_t ck = 4;  // dword of this lane that may close a long token (at most one can)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint64_t c5 = ~0ull;
+#pragma unroll
+                    for (int t = 1; t <= 5; ++t) {
+                        int idx = k - t, sh = 0;
+                        while (idx < 0) { idx += 4; ++sh; }
+                        c5 &= sh ? shl_carry(Z[idx], Zp[idx], sh) : Z[idx];
+                    }
+                    const uint32_t low = bl[k] & (0u - bl[k]);
+                    if ((low & ~A1s[k]) != 0 && ((c5 >> lane) & 1)) ck = k;
+                }
+                const uint64_t anyB = ~(Z[0] & Z[1] & Z[2] & Z[3]);  // lanes with at least one boundary byte
+                const uint64_t cm = __ballot(ck < 4);
+                if (cm) {
+                    // exact length: the last boundary before the closing dword is the highest boundary byte of the
+                    // nearest lower lane that has one (the 5 dwords in between are free), else the carried lastB
+                    const uint32_t hb = bl[3] ? 12 + top_byte(bl[3]) : bl[2] ? 8 + top_byte(bl[2]) : bl[1] ? 4 + top_byte(bl[1]) : top_byte(bl[0] | 1u);
+                    const uint64_t mlt = anyB & lt_mask;
+                    const uint32_t e = mlt ? (uint32_t)(63 - __clzll((unsigned long long)mlt)) : 0u;
+                    const uint32_t hbe = (uint32_t)__shfl((int)hb, (int)e);
+                    const int32_t lb = mlt ? (int32_t)(blk + e * 16 + hbe) : lastB;
+                    const uint32_t blk_k = ck == 0 ? bl[0] : ck == 1 ? bl[1] : ck == 2 ? bl[2] : bl[3];
+                    const uint32_t low = blk_k & (0u - blk_k);
+                    const uint32_t j = pos0 + (ck & 3) * 4 + (low ? ((uint32_t)(__ffs((int)low) - 1) >> 3) : 0u);
+                    const uint32_t tl = (uint32_t)((int32_t)j - 1 - lb);
+                    const bool tok = ck < 4 && ((tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128);
+                    cw_tok.append(tok, make_uint2(j - tl, (uint32_t)RARE_TOK | (tl << 8)), tok_out, p.tok_cap, &p.counters->n_tok, S64);
+                }
+                // carry: last boundary byte of this block (scalar: the highest lane with a boundary), and the Z bits
+                if (anyB) {
+                    const uint32_t e = (uint32_t)(63 - __clzll((unsigned long long)anyB));
+                    const uint32_t s3 = (uint32_t)__builtin_amdgcn_readlane((int)bl[3], (int)e), s2 = (uint32_t)__builtin_amdgcn_readlane((int)bl[2], (int)e);
+                    const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)bl[1], (int)e), s0 = (uint32_t)__builtin_amdgcn_readlane((int)bl[0], (int)e);
+                    const uint32_t hbs = s3 ? 12 + top_byte(s3) : s2 ? 8 + top_byte(s2) : s1 ? 4 + top_byte(s1) : top_byte(s0 | 1u);
+                    lastB = (int32_t)(blk + e * 16 + hbs);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Zp[k] = Z[k];
+            }
         }
         // the next segment of this wave is not contiguous: finish the rings while their bytes are still in the window
         if (dt != dh) drain_dom(rdom, dh, dt - dh, cx, cw_dom);
