@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <unordered_set>
 
 #include "hashes.h"
 
@@ -92,6 +93,27 @@ PslHost* load_psl() {
         h->bloom[bit >> 5] |= 1u << (bit & 31);
         h->max_tld_len = std::max<uint32_t>(h->max_tld_len, (uint32_t)ll);
         if (ll) h->tld_first[last[0] >> 5] |= 1u << (last[0] & 31);
+    }
+    // exact table of short last labels; flag 1 = the label by itself is a suffix ("com"), unlike e.g. "ck" (only "*.ck")
+    h->tld_tab.assign(1u << TLD_TAB_BITS, make_uint2(0u, 0u));
+    std::unordered_set<std::string> whole(h->suffixes.begin(), h->suffixes.end());
+    for (const std::string& s : h->suffixes) {
+        size_t dot = s.rfind('.');
+        std::string l = dot == std::string::npos ? s : s.substr(dot + 1);
+        if (l.empty() || l.size() > 7) continue;
+        uint8_t k[8] = {0};
+        memcpy(k, l.data(), l.size());
+        uint32_t lo, hi;
+        memcpy(&lo, k, 4);
+        memcpy(&hi, k + 4, 4);
+        const uint32_t flags = 0x80u | (whole.count(l) ? 1u : 0u);
+        uint32_t slot = tld_tab_slot(lo, hi);
+        for (;;) {
+            uint2& e = h->tld_tab[slot];
+            if ((e.y >> 24) == 0) { e = make_uint2(lo, hi | (flags << 24)); break; }
+            if (e.x == lo && (e.y & 0xFFFFFFu) == hi) break;  // same label from another suffix
+            slot = (slot + 1) & ((1u << TLD_TAB_BITS) - 1);
+        }
     }
     return h;
 }
@@ -246,6 +268,8 @@ void DeviceDb::upload(const DbImage& img, int dev) {
     bloom.upload(psl.bloom);
     view.psl_slots = psl_slots.p; view.psl_mask = psl.mask; view.psl_pool = psl_pool.p; view.tld_bloom = bloom.p;
     view.max_tld_len = psl.max_tld_len;
+    tld_tab.upload(psl.tld_tab);
+    view.tld_tab = tld_tab.p;
     for (int k = 0; k < 8; ++k) view.tld_first[k] = psl.tld_first[k];
     bytes_uploaded += psl.slots.size() * sizeof(PslSlot) + psl.pool.size() + psl.bloom.size() * 4;
 }

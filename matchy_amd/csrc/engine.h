@@ -32,6 +32,7 @@ struct PslHost {
     std::vector<PslSlot> slots;
     std::vector<uint8_t> pool;
     std::vector<uint32_t> bloom;
+    std::vector<uint2> tld_tab;   // exact table of the last labels of <= 7 bytes (see DevDb::tld_tab)
     uint32_t mask = 0, max_tld_len = 0;
     uint32_t tld_first[8] = {0};
     static const PslHost& get();  // throws std::runtime_error if the container cannot be found
@@ -60,6 +61,7 @@ struct DeviceDb {
     DevDb view{};
     DevBuf<uint2> ip_nodes, ip_l1;
     DevBuf<uint32_t> ip_bm24;
+    DevBuf<uint2> tld_tab;
     DevBuf<LitSlot> lit_slots;
     DevBuf<uint8_t> lit_pool, pg, psl_pool;
     DevBuf<uint32_t> lit2pat_off, lit2pat, bloom;

@@ -65,6 +65,10 @@ MXY_HD uint64_t fx_u32(uint32_t v) { return rotl64((uint64_t)v * 0xf1357aea2e62a
 
 // PSL hashing: suffixes are hashed from their LAST byte to their first so that a right-to-left walk over a
 // domain can extend the hash one label at a time.
+// slot of a last label of <= 7 bytes (packed little-endian in lo / the low 24 bits of hi) in the exact TLD table
+constexpr uint32_t TLD_TAB_BITS = 11;
+MXY_HD uint32_t tld_tab_slot(uint32_t lo, uint32_t hi24) { return ((lo ^ (hi24 * 0x9E3779B1u)) * 0x85EBCA6Bu) >> (32 - TLD_TAB_BITS); }
+
 MXY_HD uint64_t psl_hash_init() { return 0xcbf29ce484222325ULL; }
 MXY_HD uint64_t psl_hash_step(uint64_t h, uint8_t b) { return (h ^ b) * 0x100000001b3ULL; }
 MXY_HD uint64_t psl_hash_finish(uint64_t h) { h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ULL; h ^= h >> 32; return h; }

@@ -47,16 +47,57 @@ struct BackReader {
     }
 };
 
+// Right-to-left walk over the domain-char run that ends at `e` (ext:537-689): label rules of is_valid_domain
+// (ext:637-689) and the public-suffix test. With HASH the reverse PSL hash is kept and the device PSL table is probed at
+// every dot until a suffix is found (find_valid_tld_suffix_bytes, ext:1671-1692: dots right-to-left, first hit wins);
+// without it the caller already knows that the last label alone is a public suffix, so the first dot decides.
+template <bool HASH>
+__device__ __forceinline__ bool domain_walk_back(const LogView& lg, const DevDb& db, uint32_t min_labels, uint32_t e,
+                                                  uint32_t& start) {
+    uint64_t rh = psl_hash_init();
+    bool found = false, bad = false, high = false;
+    uint32_t labels = 1, cur = 0, last_c = 0;
+    uint32_t first_c = 0x100;  // byte in front of the run (0x100 = buffer start)
+    BackReader br;
+    br.init(lg.p, e);
+    while (br.pos > 0) {
+        uint32_t c = br.next();
+        if (!d_is_domain_char_fast(c)) { first_c = c; ++br.pos; break; }
+        if (c == '.') {
+            if (cur == 0 || last_c == '-') bad = true;
+            if (HASH) { if (!found && !bad) found = psl_contains(db, psl_hash_finish(rh), lg.p + br.pos + 1, e - br.pos - 1); }
+            else if (!bad) found = true;
+            ++labels;
+            cur = 0;
+        } else {
+            if (cur == 0 && c == '-') bad = true;  // label ends with '-'
+            ++cur;
+            high |= c >= 0x80;
+        }
+        if (HASH) rh = psl_hash_step(rh, (uint8_t)c);
+        last_c = c;
+    }
+    const uint32_t s = br.pos;
+    if (cur == 0 || last_c == '-') bad = true;  // leftmost label empty / starts with '-'
+    if (bad || !found || labels < min_labels) return false;
+    if (first_c != 0x100 && !d_is_boundary(first_c)) return false;
+    if (high && !d_valid_utf8(lg.p + s, e - s)) return false;
+    start = s;
+    return true;
+}
+
 // Domain (ext:537-689). `j` is the first byte after a dot (anchor: label-char, '.', label-char). Only the LAST dot
-// of a maximal domain-char run owns the run; it validates the run as a whole.
-__device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* bloom, uint32_t min_labels, uint32_t j,
-                           uint32_t& start, uint32_t& end) {
+// of a maximal domain-char run owns the run; it validates the run as a whole. `tldtab` is the LDS copy of
+// DevDb::tld_tab (exact table of the last labels of <= 7 bytes), `bloom` covers the longer ones.
+__device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* bloom, const uint2* tldtab, uint32_t min_labels,
+                           uint32_t j, uint32_t& start, uint32_t& end) {
     uint32_t p = j, th = 2166136261u;
     bool open = true;  // last label not yet terminated
     uint32_t stop_c = 0x100;  // byte that ended the run on the right (0x100 = buffer end)
-    if (j + 8 <= lg.len) {
+    uint2 w = make_uint2(0u, 0u);
+    const bool wide = j + 8 <= lg.len;
+    if (wide) {
         // the first 8 bytes of the last label in one load; most labels (com, net, css, html, ...) end inside it
-        uint2 w;
         __builtin_memcpy(&w, lg.p + j, 8);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -78,39 +119,28 @@ __device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* b
         th = tld_hash_step(th, c);
         ++p;
     }
-    uint32_t e = p;
-    if (e - j > db.max_tld_len) return false;
+    const uint32_t e = p, ll = e - j;
+    if (ll > db.max_tld_len) return false;
     if (stop_c != 0x100 && !d_is_boundary(stop_c)) return false;  // boundary (or buffer end) after the run (ext:600-606)
-    uint32_t bit = tld_hash_bit(th);
-    if (!((bloom[bit >> 5] >> (bit & 31)) & 1)) return false;  // last label is no suffix's last label -> no PSL hit possible
-    // walk back to the run start: PSL probes at dots (first hit suffices), label rules of is_valid_domain (ext:637-689)
-    uint64_t rh = psl_hash_init();
-    bool found = false, bad = false, high = false;
-    uint32_t labels = 1, cur = 0, last_c = 0;
-    uint32_t first_c = 0x100;  // byte in front of the run (0x100 = buffer start)
-    BackReader br;
-    br.init(lg.p, e);
-    while (br.pos > 0) {
-        uint32_t c = br.next();
-        if (!d_is_domain_char_fast(c)) { first_c = c; ++br.pos; break; }
-        if (c == '.') {
-            if (cur == 0 || last_c == '-') bad = true;
-            if (!found && !bad) found = psl_contains(db, psl_hash_finish(rh), lg.p + br.pos + 1, e - br.pos - 1);
-            ++labels;
-            cur = 0;
-        } else {
-            if (cur == 0 && c == '-') bad = true;  // label ends with '-'
-            ++cur;
-            high |= c >= 0x80;
+    bool alone = false;  // the last label by itself is a public suffix: the first dot of the walk decides
+    if (wide && ll <= 7) {
+        // exact: a last label that no suffix ends with can never pass the PSL test
+        const uint32_t lo = ll >= 4 ? w.x : (w.x & ((1u << (8 * ll)) - 1u));
+        const uint32_t hi = ll > 4 ? (w.y & ((1u << (8 * (ll - 4))) - 1u)) : 0u;
+        uint32_t slot = tld_tab_slot(lo, hi);
+        for (;;) {
+            const uint2 t = tldtab[slot];
+            if ((t.y >> 24) == 0) return false;
+            if (t.x == lo && (t.y & 0xFFFFFFu) == hi) { alone = (t.y >> 24) & 1; break; }
+            slot = (slot + 1) & ((1u << TLD_TAB_BITS) - 1);
         }
-        rh = psl_hash_step(rh, (uint8_t)c);
-        last_c = c;
+    } else {
+        const uint32_t bit = tld_hash_bit(th);
+        if (!((bloom[bit >> 5] >> (bit & 31)) & 1)) return false;  // last label is no suffix's last label -> no PSL hit possible
     }
-    uint32_t s = br.pos;
-    if (cur == 0 || last_c == '-') bad = true;  // leftmost label empty / starts with '-'
-    if (bad || !found || labels < min_labels) return false;
-    if (first_c != 0x100 && !d_is_boundary(first_c)) return false;
-    if (high && !d_valid_utf8(lg.p + s, e - s)) return false;
+    uint32_t s;
+    const bool ok = alone ? domain_walk_back<false>(lg, db, min_labels, e, s) : domain_walk_back<true>(lg, db, min_labels, e, s);
+    if (!ok) return false;
     start = s; end = e;
     return true;
 }
@@ -383,7 +413,9 @@ __device__ bool val_eth(const uint8_t* a) {  // ext:1328-1361, 1840-1892: "0x" +
 // the dependent byte loads hit L2: anchors of one wave lie within a few KiB of each other).
 __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
+    __shared__ uint2 tldtab[1u << TLD_TAB_BITS];
     for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += blockDim.x) bloom[i] = db.tld_bloom[i];
+    for (uint32_t i = threadIdx.x; i < (1u << TLD_TAB_BITS); i += blockDim.x) tldtab[i] = db.tld_tab[i];
     __syncthreads();
     LogView lg{p.log, p.len};
     ChunkWriter<Candidate, CAND_CHUNK> cw;
@@ -410,7 +442,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         const uint32_t ad = i < nd ? p.dom_list[i] : 0xFFFFFFFFu;
         if (ad != 0xFFFFFFFFu) {
             uint32_t s, e;
-            if (val_domain(lg, db, bloom, p.min_labels, ad, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true; }
+            if (val_domain(lg, db, bloom, tldtab, p.min_labels, ad, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true; }
         }
         cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     }

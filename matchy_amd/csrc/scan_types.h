@@ -81,6 +81,9 @@ struct DevDb {
     const uint8_t* psl_pool;
     const uint32_t* tld_bloom;    // TLD_BLOOM_WORDS words: bloom over the LAST labels of all suffixes
     uint32_t max_tld_len;
+    // exact open-addressing table (1 << TLD_TAB_BITS slots) of the last labels of <= 7 bytes: x = bytes 0..3, y = bytes
+    // 4..6 | flags << 24 (0x80 occupied, 0x01 the label alone is a public suffix); slot = tld_tab_slot(x, y & 0xFFFFFF)
+    const uint2* tld_tab;
     uint32_t tld_first[8];        // 256-bit set: bytes that start the last label of at least one suffix
 };
 
