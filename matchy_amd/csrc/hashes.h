@@ -56,8 +56,35 @@ MXY_HD uint64_t xxh64_fetch(Fetch f, size_t len, uint64_t seed) {
     return h;
 }
 
+// XXH64 over contiguous memory: 8- and 4-byte lanes are read with one (unaligned) load each. Host and gfx950 are
+// little-endian, which is the byte order XXH64 specifies for its lanes.
 MXY_HD uint64_t xxh64(const uint8_t* p, size_t len, uint64_t seed) {
-    return xxh64_fetch([p](size_t o) { return p[o]; }, len, seed);
+    const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL,
+                   P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
+    auto rd64 = [&](size_t o) { uint64_t v; __builtin_memcpy(&v, p + o, 8); return v; };
+    auto rd32 = [&](size_t o) { uint32_t v; __builtin_memcpy(&v, p + o, 4); return (uint64_t)v; };
+    auto round = [&](uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl64(acc, 31); return acc * P1; };
+    auto merge = [&](uint64_t acc, uint64_t val) { val = round(0, val); acc ^= val; return acc * P1 + P4; };
+    size_t q = 0;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        const size_t limit = len - 32;
+        do {
+            v1 = round(v1, rd64(q)); v2 = round(v2, rd64(q + 8)); v3 = round(v3, rd64(q + 16)); v4 = round(v4, rd64(q + 24));
+            q += 32;
+        } while (q <= limit);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = merge(h, v1); h = merge(h, v2); h = merge(h, v3); h = merge(h, v4);
+    } else {
+        h = seed + P5;
+    }
+    h += (uint64_t)len;
+    while (q + 8 <= len) { h ^= round(0, rd64(q)); h = rotl64(h, 27) * P1 + P4; q += 8; }
+    if (q + 4 <= len) { h ^= rd32(q) * P1; h = rotl64(h, 23) * P2 + P3; q += 4; }
+    while (q < len) { h ^= (uint64_t)p[q] * P5; h = rotl64(h, 11) * P1; ++q; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
 }
 
 // rustc-hash 2.x (64-bit): hash = (hash + x) * K, finish = rotl(hash, 26). See DESIGN.md (unverified vs crate source).

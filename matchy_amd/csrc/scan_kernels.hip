@@ -36,6 +36,10 @@ struct BackReader {
         p = base; pos = q; cb = 0; k = 0; cur = 0; nxt = 0;
         if (q >= 16) { cb = q - 8; k = 8; cur = load8(p + cb); nxt = load8(p + cb - 8); }
     }
+    // same with the two words already loaded by the caller: c0 = p[q-8, q), c1 = p[q-16, q-8); needs q >= 16
+    __device__ __forceinline__ void init_pre(const uint8_t* base, uint32_t q, uint64_t c0, uint64_t c1) {
+        p = base; pos = q; cb = q - 8; k = 8; cur = c0; nxt = c1;
+    }
     __device__ __forceinline__ uint32_t next() {
         --pos;
         if (pos < 16) return p[pos];  // the first bytes of the buffer: plain loads (no read before the buffer)
@@ -51,15 +55,18 @@ struct BackReader {
 // (ext:637-689) and the public-suffix test. With HASH the reverse PSL hash is kept and the device PSL table is probed at
 // every dot until a suffix is found (find_valid_tld_suffix_bytes, ext:1671-1692: dots right-to-left, first hit wins);
 // without it the caller already knows that the last label alone is a public suffix, so the first dot decides.
+struct WalkInit {          // state of the walk after the bytes the caller has already consumed (none: the defaults)
+    uint64_t rh;
+    uint32_t cur = 0, last_c = 0;
+    bool high = false, bad = false;
+};
 template <bool HASH>
-__device__ __forceinline__ bool domain_walk_back(const LogView& lg, const DevDb& db, uint32_t min_labels, uint32_t e,
-                                                  uint32_t& start) {
-    uint64_t rh = psl_hash_init();
-    bool found = false, bad = false, high = false;
-    uint32_t labels = 1, cur = 0, last_c = 0;
+__device__ __forceinline__ bool domain_walk_back(const LogView& lg, const DevDb& db, uint32_t min_labels, uint32_t e, BackReader& br,
+                                                  const WalkInit& wi, uint32_t& start) {
+    uint64_t rh = wi.rh;
+    bool found = false, bad = wi.bad, high = wi.high;
+    uint32_t labels = 1, cur = wi.cur, last_c = wi.last_c;
     uint32_t first_c = 0x100;  // byte in front of the run (0x100 = buffer start)
-    BackReader br;
-    br.init(lg.p, e);
     while (br.pos > 0) {
         uint32_t c = br.next();
         if (!d_is_domain_char_fast(c)) { first_c = c; ++br.pos; break; }
@@ -139,15 +146,84 @@ __device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* b
         if (!((bloom[bit >> 5] >> (bit & 31)) & 1)) return false;  // last label is no suffix's last label -> no PSL hit possible
     }
     uint32_t s;
-    const bool ok = alone ? domain_walk_back<false>(lg, db, min_labels, e, s) : domain_walk_back<true>(lg, db, min_labels, e, s);
+    BackReader br;
+    br.init(lg.p, e);
+    WalkInit wi;
+    wi.rh = psl_hash_init();
+    const bool ok = alone ? domain_walk_back<false>(lg, db, min_labels, e, br, wi, s) : domain_walk_back<true>(lg, db, min_labels, e, br, wi, s);
     if (!ok) return false;
     start = s; end = e;
     return true;
 }
 
+// The same for an anchor whose surroundings were loaded ahead of time (k_validate software pipeline): w = log[j, j+8),
+// b0 = log[j-8, j), b1 = log[j-16, j-8). The common case — last label of <= 7 bytes that alone is a public suffix — is
+// decided from these registers plus further BackReader loads for names longer than 16 bytes; everything else takes
+// val_domain.
+__device__ __forceinline__ bool val_domain_pre(const LogView& lg, const DevDb& db, const uint32_t* bloom, const uint2* tldtab,
+                                               uint32_t min_labels, uint32_t j, uint2 w, uint64_t b0, uint64_t b1, uint32_t& start,
+                                               uint32_t& end) {
+    uint32_t ll = 8, stop_c = 0;
+    bool dot_inside = false;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        const uint32_t c = ((k < 4 ? w.x : w.y) >> (8 * (k & 3))) & 0xFF;
+        if (!d_is_domain_char_fast(c)) { ll = k; stop_c = c; dot_inside = false; }
+        else if (c == '.') dot_inside = true;   // only dots before the first non-domain byte count (reset above)
+    }
+    if (ll <= 7) {
+        if (dot_inside) return false;           // a later dot owns this run
+        if (!d_is_boundary(stop_c)) return false;
+        const uint32_t lo = ll >= 4 ? w.x : (w.x & ((1u << (8 * ll)) - 1u));
+        const uint32_t hi = ll > 4 ? (w.y & ((1u << (8 * (ll - 4))) - 1u)) : 0u;
+        uint32_t slot = tld_tab_slot(lo, hi);
+        bool alone = false;
+        for (;;) {
+            const uint2 t = tldtab[slot];
+            if ((t.y >> 24) == 0) return false;
+            if (t.x == lo && (t.y & 0xFFFFFFu) == hi) { alone = (t.y >> 24) & 1; break; }
+            slot = (slot + 1) & ((1u << TLD_TAB_BITS) - 1);
+        }
+        if (alone) {
+            const uint32_t lastc = ((ll > 4 ? hi : lo) >> (8 * ((ll - 1) & 3))) & 0xFF;
+            WalkInit wi;
+            wi.rh = 0;
+            wi.cur = ll;
+            wi.last_c = lo & 0xFF;
+            wi.high = ((lo | hi) & 0x80808080u) != 0;
+            wi.bad = lastc == '-';
+            BackReader br;
+            br.init_pre(lg.p, j, b0, b1);
+            uint32_t s;
+            if (!domain_walk_back<false>(lg, db, min_labels, j + ll, br, wi, s)) return false;
+            start = s; end = j + ll;
+            return true;
+        }
+    }
+    return val_domain(lg, db, bloom, tldtab, min_labels, j, start, end);
+}
+
 __device__ bool all_hex(const LogView& lg, uint32_t s, uint32_t n) {
     for (uint32_t k = 0; k < n; ++k) if (!d_is_hex(lg.at(s + k))) return false;
     return true;
+}
+// all four bytes of x are ASCII hex digits (SWAR; no carries cross bytes because every addend keeps bytes below 0x100)
+__device__ __forceinline__ bool hex4(uint32_t x) {
+    const uint32_t t = x & 0x7F7F7F7Fu, l = t | 0x20202020u;
+    const uint32_t dig = (t + 0x50505050u) & ~(t + 0x46464646u);   // >= '0' and not >= ':'
+    const uint32_t alp = (l + 0x1F1F1F1Fu) & ~(l + 0x19191919u);   // >= 'a' and not >= 'g' (case folded)
+    return (((dig | alp) & ~x) & 0x80808080u) == 0x80808080u;
+}
+// all_hex for the hash lengths (multiples of 8): independent 8-byte loads instead of a dependent byte-load chain
+__device__ __forceinline__ bool all_hex_wide(const uint8_t* p, uint32_t n) {
+    bool ok = true;
+#pragma unroll 4
+    for (uint32_t k = 0; k < n; k += 8) {
+        uint2 v;
+        __builtin_memcpy(&v, p + k, 8);
+        ok = ok && hex4(v.x) && hex4(v.y);
+    }
+    return ok;
 }
 
 
@@ -215,6 +291,26 @@ __device__ bool val_ipv6(const LogView& lg, uint32_t p2, uint32_t& start, uint32
     uint16_t seg[8];
     if (!d_parse_ipv6(c, n, seg)) return false;
     start = s; end = e;
+    return true;
+}
+
+// The same on an 80-byte window win[0..80) = log[p2-40, p2+40) held in LDS (k_validate): a run that reaches either
+// window edge is longer than 39 bytes and can never parse, so the window is exact.
+__device__ bool val_ipv6_win(const uint8_t* win, uint32_t p2, uint32_t& start, uint32_t& end) {
+    uint32_t s = 39;  // index of the first ':' of the "::"
+    while (s > 0) { uint32_t c = win[s - 1]; if (!d_is_hex(c) && c != ':') break; --s; }
+    if (s == 0) return false;
+    uint32_t e = 41;
+    while (e < 80) { uint32_t c = win[e]; if (!d_is_hex(c) && c != ':') break; ++e; }
+    if (e == 80) return false;
+    const uint32_t n = e - s;
+    if (n < 8 || n > 64) return false;
+    const uint8_t* c = win + s;
+    if ((c[0] == ':' && c[1] == ':') || (c[n - 2] == ':' && c[n - 1] == ':')) return false;
+    if (d_lower(c[0]) == 'f' && d_lower(c[1]) == 'e') { uint32_t x = d_lower(c[2]); if (x == '8' || x == '9' || x == 'a' || x == 'b') return false; }
+    uint16_t seg[8];
+    if (!d_parse_ipv6(c, n, seg)) return false;
+    start = p2 - 40 + s; end = p2 - 40 + e;
     return true;
 }
 
@@ -412,8 +508,12 @@ __device__ bool val_eth(const uint8_t* a) {  // ext:1328-1361, 1840-1892: "0x" +
 // k_validate — stage A2: one lane per IPv4 / domain anchor written by k_anchor (lean kernel, high occupancy;
 // the dependent byte loads hit L2: anchors of one wave lie within a few KiB of each other).
 __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
-    __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
-    __shared__ uint2 tldtab[1u << TLD_TAB_BITS];
+    // LDS: the TLD Bloom filter and the exact short-label table for the domain loop; the same bytes are reused
+    // afterwards as one 80-byte window per lane for the IPv6 validator
+    __shared__ __attribute__((aligned(16))) uint8_t smem[TLD_BLOOM_WORDS * 4 + (8u << TLD_TAB_BITS)];
+    static_assert(sizeof(smem) >= 256 * 80, "IPv6 windows alias the tables");
+    uint32_t* bloom = reinterpret_cast<uint32_t*>(smem);
+    uint2* tldtab = reinterpret_cast<uint2*>(smem + TLD_BLOOM_WORDS * 4);
     for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += blockDim.x) bloom[i] = db.tld_bloom[i];
     for (uint32_t i = threadIdx.x; i < (1u << TLD_TAB_BITS); i += blockDim.x) tldtab[i] = db.tld_tab[i];
     __syncthreads();
@@ -421,48 +521,44 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     ChunkWriter<Candidate, CAND_CHUNK> cw;
     const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t n4 = min(p.counters->n_v4, p.v4_cap);
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n4; base += stride) {
-        const uint32_t i = base + threadIdx.x;
-        Candidate c{0, 0, 0, 0};
-        bool emit = false;
-        const uint32_t a4 = i < n4 ? p.v4_list[i] : 0xFFFFFFFFu;
-        if (a4 != 0xFFFFFFFFu) {
-            uint32_t s, e, a;
-            const bool wide = a4 >= 4 && a4 + 16 <= lg.len;
-            if (wide ? val_ipv4_fast(lg.p, a4, s, e, a) : val_ipv4(lg, a4, s, e, a)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV4 << 24); c.v4 = a; emit = true; }
-        }
-        cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
-    }
+    // Domain anchors, software-pipelined: the anchor of the next iteration and the 24 bytes around it are loaded while
+    // the current one is validated, so the dependent chain list -> log bytes is off the critical path.
     const uint32_t nd = min(p.counters->n_dom, p.dom_cap);
-    for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
-        const uint32_t i = base + threadIdx.x;
-        Candidate c{0, 0, 0, 0};
-        bool emit = false;
-        const uint32_t ad = i < nd ? p.dom_list[i] : 0xFFFFFFFFu;
-        if (ad != 0xFFFFFFFFu) {
-            uint32_t s, e;
-            if (val_domain(lg, db, bloom, tldtab, p.min_labels, ad, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true; }
+    {
+        const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x;
+        auto anchor_at = [&](uint32_t i) { return i < nd ? p.dom_list[i] : 0xFFFFFFFFu; };
+        auto pre_ok = [&](uint32_t ad) { return ad != 0xFFFFFFFFu && ad >= 16 && ad + 8 <= lg.len; };
+        uint32_t ad_cur = anchor_at(i0), ad_nxt = anchor_at(i0 + stride);
+        uint2 w_cur = make_uint2(0u, 0u);
+        uint64_t b0_cur = 0, b1_cur = 0;
+        if (pre_ok(ad_cur)) {
+            __builtin_memcpy(&w_cur, lg.p + ad_cur, 8);
+            b0_cur = BackReader::load8(lg.p + ad_cur - 8);
+            b1_cur = BackReader::load8(lg.p + ad_cur - 16);
         }
-        cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
-    }
-    // IPv6 ("::") and e-mail ('@') anchors from the rare list
-    const uint32_t nr = min(p.counters->n_rare, p.rare_cap);
-    for (uint32_t base = blockIdx.x * blockDim.x; base < nr; base += stride) {
-        const uint32_t i = base + threadIdx.x;
-        RareAnchor ra{0, 0xFF};
-        if (i < nr) ra = p.rare[i];
-        const uint32_t kind = ra.len_kind & 0xFF;
-        Candidate c{0, 0, 0, 0};
-        bool emit = false;
-        if (kind == RARE_V6) {
-            uint32_t s, e;
-            if (val_ipv6(lg, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV6 << 24); emit = true; }
-        } else if (kind == RARE_AT) {
-            uint32_t s, e;
-            if (val_email(lg, db, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_EMAIL << 24); emit = true; }
+        for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
+            const uint32_t i = base + threadIdx.x;
+            // issue the loads of the next iteration
+            uint2 w_nxt = make_uint2(0u, 0u);
+            uint64_t b0_nxt = 0, b1_nxt = 0;
+            if (pre_ok(ad_nxt)) {
+                __builtin_memcpy(&w_nxt, lg.p + ad_nxt, 8);
+                b0_nxt = BackReader::load8(lg.p + ad_nxt - 8);
+                b1_nxt = BackReader::load8(lg.p + ad_nxt - 16);
+            }
+            const uint32_t ad_n2 = anchor_at(i + 2 * stride);
+            Candidate c{0, 0, 0, 0};
+            bool emit = false;
+            if (ad_cur != 0xFFFFFFFFu) {
+                uint32_t s, e;
+                const bool ok = pre_ok(ad_cur) ? val_domain_pre(lg, db, bloom, tldtab, p.min_labels, ad_cur, w_cur, b0_cur, b1_cur, s, e)
+                                               : val_domain(lg, db, bloom, tldtab, p.min_labels, ad_cur, s, e);
+                if (ok) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true; }
+            }
+            cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+            ad_cur = ad_nxt; ad_nxt = ad_n2;
+            w_cur = w_nxt; b0_cur = b0_nxt; b1_cur = b1_nxt;
         }
-        cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     }
     // Long tokens: hex hashes are decided here; the checksum validators (Base58Check, Bech32, EIP-55, Monero) need
     // SHA-256 / Keccak and hundreds of registers, so tokens that pass their cheap prefix tests go to the `heavy` list
@@ -482,16 +578,16 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         {
             Candidate c{0, 0, 0, 0};
             bool emit = false;
-            if (live && (p.flags & EX_HASHES)) {
+            if (live && (p.flags & EX_HASHES) && !(p.debug & 8)) {
                 const int ht = tl == 32 ? IT_MD5 : tl == 40 ? IT_SHA1 : tl == 64 ? IT_SHA256 : tl == 96 ? IT_SHA384 : tl == 128 ? IT_SHA512 : -1;
-                if (ht >= 0 && all_hex(lg, ra.pos, tl)) { c.start = ra.pos; c.len_type = tl | ((uint32_t)ht << 24); emit = true; }
+                if (ht >= 0 && all_hex_wide(s, tl)) { c.start = ra.pos; c.len_type = tl | ((uint32_t)ht << 24); emit = !(p.debug & 32); }
             }
             cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
         }
         // a token can yield several items: hash, Bitcoin, Ethereum and Monero are independent extractors
         {
             uint32_t hk = 0;
-            if (live && (p.flags & EX_BITCOIN) && tl >= 26 && tl <= 62) {
+            if (live && (p.flags & EX_BITCOIN) && tl >= 26 && tl <= 62 && !(p.debug & 16)) {
                 if (s[0] == 'b' && s[1] == 'c' && s[2] == '1') hk = HEAVY_BECH32;
                 else if (s[0] == '1' || s[0] == '3') hk = HEAVY_B58;
             }
@@ -501,6 +597,39 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
             if (live && (p.flags & EX_MONERO) && tl >= 90 && tl <= 110 && (s[0] == '4' || s[0] == '8')) hk = HEAVY_XMR;
             hw.append(hk != 0, RareAnchor{ra.pos, (tl << 8) | hk}, p.heavy, p.heavy_cap, &p.counters->n_heavy, SH);
         }
+    }
+    // IPv6 ("::") and e-mail ('@') anchors from the rare list. The IPv6 parser reads its bytes many times: each lane
+    // copies log[p2-40, p2+40) into its LDS window with five wide loads first.
+    __syncthreads();  // every wave of the block is done with the tables that the windows overwrite
+    uint8_t* win = smem + threadIdx.x * 80;
+    const uint32_t nr = min(p.counters->n_rare, p.rare_cap);
+    for (uint32_t base = blockIdx.x * blockDim.x; base < nr; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        RareAnchor ra{0, 0xFF};
+        if (i < nr) ra = p.rare[i];
+        const uint32_t kind = ra.len_kind & 0xFF;
+        Candidate c{0, 0, 0, 0};
+        bool emit = false;
+        if (kind == RARE_V6) {
+            uint32_t s, e;
+            bool ok;
+            if (ra.pos >= 40 && ra.pos + 40 <= lg.len) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    uint4 v;
+                    __builtin_memcpy(&v, lg.p + ra.pos - 40 + 16 * k, 16);
+                    *reinterpret_cast<uint4*>(win + 16 * k) = v;
+                }
+                ok = val_ipv6_win(win, ra.pos, s, e);
+            } else {
+                ok = val_ipv6(lg, ra.pos, s, e);
+            }
+            if (ok) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV6 << 24); emit = true; }
+        } else if (kind == RARE_AT) {
+            uint32_t s, e;
+            if (val_email(lg, db, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_EMAIL << 24); emit = true; }
+        }
+        cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     }
     hw.pad_rest(p.heavy, p.heavy_cap, SH);
     cw.pad_rest(p.cands, p.cand_cap, SC);
@@ -590,9 +719,17 @@ __device__ bool lit_lookup(const DevDb& db, const uint8_t* s, uint32_t n, uint32
             const uint8_t* q = db.lit_pool + e.str_off;
             uint32_t sl = (uint32_t)q[0] | ((uint32_t)q[1] << 8);
             if (sl == n) {
-                bool eq = true;
-                for (uint32_t k = 0; k < n; ++k) if (q[2 + k] != s[k]) { eq = false; break; }
-                if (eq) { pattern_id = e.pattern_id; return true; }
+                // 8 bytes per step, no early exit: the loads are independent of each other
+                uint64_t diff = 0;
+                uint32_t k = 0;
+                for (; k + 8 <= n; k += 8) {
+                    uint64_t x, y;
+                    __builtin_memcpy(&x, q + 2 + k, 8);
+                    __builtin_memcpy(&y, s + k, 8);
+                    diff |= x ^ y;
+                }
+                for (; k < n; ++k) diff |= (uint64_t)(q[2 + k] ^ s[k]);
+                if (diff == 0) { pattern_id = e.pattern_id; return true; }
             }
         }
         slot = (slot + 1) & db.lit_mask;
