@@ -1,0 +1,99 @@
+"""GPU tests at scale (-m gpu): dense / pathological inputs that overflow the work lists and force the regrow-and-rescan
+path, and the BASELINE configs[1] workload at a size that exercises the > 1 GiB host path, checked against the oracle
+and through size-independent properties (idempotence, sharding invariance, additivity of the line count)."""
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    import matchy_amd
+    matchy_amd.lib()
+    return matchy_amd
+
+
+# (the reference's domain pass is quadratic in the length of a dot-rich run, and so is the oracle: keep such runs short)
+DENSE = [
+    (b"1.1.1.1 ", 300_000), (b",1.1.,1.1.", 200_000), (b"10.20.30.40,", 150_000), (b"1.2.3.4.5 ", 100_000), (b"999.999.999.999 ", 60_000),
+    (b"a.com ", 300_000), (b"a.b.c.d.e.com/", 100_000), (b"x.html y.css z.js ", 100_000), (b"www.example.co.uk\n", 80_000),
+    (b"u@a.co ", 200_000), (b"@", 500_000), (b"::1 ", 300_000), (b" 2001:db8::1", 120_000), (b":", 700_000), (b".", 1_500), (b"a.", 1_000),
+    (b"5d41402abc4b2a76b9719d911017c592 ", 40_000), (b"a" * 26 + b" ", 50_000), (b"1" * 34 + b" ", 3_000), (b"0x" + b"ab" * 20 + b" ", 30_000),
+    (b"\n", 1_000_000), (b"x", 1_500_000), (b" ", 1_500_000),
+]
+
+
+def test_dense_pathological_inputs(M, oracle):
+    ex = M.Extractor()
+    for unit, reps in DENSE:
+        buf = unit * reps
+        got = ex.extract_from_chunk(buf)
+        want = oracle.extract(buf)
+        assert len(got) == len(want), (unit, len(got), len(want))
+        assert got == want, unit
+    ex.close()
+
+
+def test_raw_window_edges(M, oracle):
+    # candidates that straddle the 4 KiB wrap of the streaming kernel's LDS window and its 1 KiB blocks, at every offset
+    ex = M.Extractor()
+    payloads = [b"10.20.30.40", b"255.255.255.255", b"evil.example.com", b"a.io", b"2001:db8::8a2e:370:7334"]
+    for edge in (1024, 4096, 8192, 12288, 16384, 20480):
+        for pl in payloads:
+            for shift in range(0, len(pl) + 18):
+                pre = edge - shift + 8
+                buf = b"q" * (pre - 1) + b" " + pl + b" " + b"1.2.3.4 b.org " * 40
+                assert ex.extract_from_chunk(buf) == oracle.extract(buf), (edge, pl, shift)
+    ex.close()
+
+
+def _rebased(hits, base):
+    out = []
+    for h in hits:
+        h = dict(h)
+        h["start"] += base
+        h["end"] += base
+        out.append(h)
+    return out
+
+
+def test_full_size_parity_and_properties(M, oracle):
+    """6 M lines of the C2 log (> 1 GiB: scan_host cuts it into newline-aligned pieces) against the oracle, plus
+    idempotence and sharding invariance of the hit set."""
+    from matchy_amd import sharding
+    from tools import synth
+    cfg = synth.config("c2")
+    blob = synth.build_db(cfg)
+    lines = int(os.environ.get("MXY_SCALE_LINES", "6000000"))
+    log = synth.make_log(cfg, 0, lines)
+    assert lines < 6_000_000 or len(log) > (1 << 30)
+    db = M.Database(blob)
+    sc = M.Scanner(db)
+    res = sc.scan(log)
+    hits = res.hits()
+    stats = (res.lines, res.candidates, res.bytes)
+    res.close()
+    assert stats[0] == lines and stats[2] == len(log)
+    # oracle on the same bytes (all host cores, no cache: plain reference semantics)
+    odb = oracle.Database(blob)
+    want, _, st = odb.scan(log, threads=min(len(os.sched_getaffinity(0)), 16), cache=0, want_json=False)
+    assert (st.lines, st.candidates) == stats[:2]
+    assert len(hits) == len(want)
+    assert hits == want
+    # idempotence
+    res2 = sc.scan(log)
+    assert res2.hits() == hits
+    res2.close()
+    # sharding invariance (N4): three newline-aligned ranges, rebased and concatenated
+    parts = sharding.split_at_newlines(log, 3)
+    merged, nl = [], 0
+    for a, b in parts:
+        r = sc.scan(log[a:b])
+        merged += _rebased(r.hits(), a)
+        nl += r.lines
+        r.close()
+    assert nl == lines
+    assert merged == hits
+    sc.close(); db.close()
