@@ -216,4 +216,93 @@ void DbImage::build_lit2pat(std::vector<uint32_t>& off, std::vector<uint32_t>& i
     off[max_lit] = (uint32_t)ids.size();
 }
 
+bool DbImage::build_ac_dfa(std::vector<uint32_t>& next, std::vector<uint8_t>& cls, uint32_t& k, std::vector<uint32_t>& node_off,
+                           size_t max_bytes) const {
+    next.clear(); cls.assign(256, 0); node_off.clear(); k = 0;
+    if (!has_glob) return false;
+    const uint8_t* pg = bytes.data() + pg_off;
+    const uint32_t ac_start = rd32(pg + 20), ac_size = rd32(pg + 24);
+    if (ac_size < 20 || (size_t)ac_start + ac_size > pg_len) return false;
+    const uint8_t* ac = pg + ac_start;
+    // goto edges of one node, as find_ac_transition reads them (paraglob_offset.rs:1271-1353)
+    struct Edge { uint8_t ch; uint32_t target; };
+    auto edges_of = [&](uint32_t off, std::vector<Edge>& out) -> bool {
+        out.clear();
+        if ((size_t)off + 20 > ac_size) return false;
+        const uint32_t w0 = rd32(ac + off), kind = w0 & 0xFF, eo = rd32(ac + off + 12);
+        if (kind == 1) out.push_back({(uint8_t)((w0 >> 8) & 0xFF), eo});
+        else if (kind == 2) {
+            const uint32_t cnt = (w0 >> 16) & 0xFF;
+            if ((size_t)eo + (size_t)cnt * 8 > ac_size) return false;
+            int prev = -1;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint8_t c = ac[eo + i * 8];
+                if ((int)c <= prev) return false;  // the reader's early exit relies on sorted edges; refuse anything else
+                prev = c;
+                out.push_back({c, rd32(ac + eo + i * 8 + 4)});
+            }
+        } else if (kind == 3) {
+            if ((size_t)eo + 1024 > ac_size) return false;
+            for (uint32_t c = 0; c < 256; ++c) { const uint32_t t = rd32(ac + eo + c * 4); if (t) out.push_back({(uint8_t)c, t}); }
+        }
+        return true;
+    };
+    // breadth-first numbering of the reachable nodes
+    std::vector<uint32_t> state_of(ac_size / 4 + 1, 0xFFFFFFFFu), depth;
+    std::vector<Edge> flat, tmp;        // goto edges of all states, CSR by state
+    std::vector<size_t> edge_begin;
+    bool used[256] = {false};
+    node_off.push_back(0);
+    depth.push_back(0);
+    state_of[0] = 0;
+    for (size_t s = 0; s < node_off.size(); ++s) {
+        if (!edges_of(node_off[s], tmp)) return false;
+        for (const Edge& e : tmp) {
+            if ((e.target & 3) || (size_t)e.target + 20 > ac_size) return false;
+            used[e.ch] = true;
+            if (state_of[e.target / 4] == 0xFFFFFFFFu) {
+                state_of[e.target / 4] = (uint32_t)node_off.size();
+                node_off.push_back(e.target);
+                depth.push_back(depth[s] + 1);
+            }
+        }
+        edge_begin.push_back(flat.size());
+        flat.insert(flat.end(), tmp.begin(), tmp.end());
+    }
+    edge_begin.push_back(flat.size());
+    // byte classes: every byte that labels an edge is its own class; all the others share class 0 (they lead back to
+    // the root from every state). If all 256 values label edges there is no class 0 and classes are the byte values.
+    uint32_t n_used = 0;
+    for (int c = 0; c < 256; ++c) n_used += used[c];
+    if (n_used == 256) {
+        for (int c = 0; c < 256; ++c) cls[c] = (uint8_t)c;
+        k = 256;
+    } else {
+        k = 1;
+        for (int c = 0; c < 256; ++c) if (used[c]) cls[c] = (uint8_t)k++;
+    }
+    const size_t n = node_off.size();
+    if (n >= 0x7FFFFFFFu || n * (size_t)k * 4 > max_bytes) { next.clear(); return false; }
+    next.assign(n * (size_t)k, 0);
+    std::vector<uint8_t> has_out(n);
+    for (size_t s = 0; s < n; ++s) has_out[s] = ac[node_off[s] + 3] != 0;
+    // states are in breadth-first order, so a valid failure link (strictly shallower) is always resolved already
+    for (size_t s = 0; s < n; ++s) {
+        uint32_t* row = &next[s * k];
+        if (s == 0) {
+            for (uint32_t c = 0; c < k; ++c) row[c] = 0;
+        } else {
+            const uint32_t fo = rd32(ac + node_off[s] + 8);
+            if ((fo & 3) || fo / 4 >= state_of.size()) return false;
+            const uint32_t fs = state_of[fo / 4];
+            if (fs == 0xFFFFFFFFu || depth[fs] >= depth[s]) { next.clear(); return false; }
+            const uint32_t* frow = &next[(size_t)fs * k];
+            for (uint32_t c = 0; c < k; ++c) row[c] = frow[c] & 0x7FFFFFFFu;
+        }
+        for (size_t q = edge_begin[s]; q < edge_begin[s + 1]; ++q) row[cls[flat[q].ch]] = state_of[flat[q].target / 4];
+    }
+    for (size_t i = 0; i < next.size(); ++i) if (has_out[next[i]]) next[i] |= 0x80000000u;
+    return true;
+}
+
 }  // namespace mxy

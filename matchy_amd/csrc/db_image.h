@@ -51,6 +51,12 @@ struct DbImage {
     void build_ip_nodes(std::vector<uint2>& out, uint32_t& v4_start) const;
     void build_lit_table(std::vector<LitSlot>& slots, uint32_t& mask) const;
     void build_lit2pat(std::vector<uint32_t>& off, std::vector<uint32_t>& ids) const;
+    // Aho-Corasick automaton of the paraglob section flattened into a dense DFA (goto and failure links resolved):
+    // next[state * k + cls[byte]] = next state | 0x80000000 when that state has output literals; node_off[state] is the
+    // node's offset in the AC section. Returns false (nothing built) when the section is empty, malformed in a way the
+    // flattening does not handle, or the table would exceed `max_bytes`; the kernels then walk the stored nodes.
+    bool build_ac_dfa(std::vector<uint32_t>& next, std::vector<uint8_t>& cls, uint32_t& k, std::vector<uint32_t>& node_off,
+                      size_t max_bytes) const;
 };
 
 }  // namespace mxy

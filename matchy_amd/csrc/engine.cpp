@@ -238,6 +238,20 @@ void DeviceDb::upload(const DbImage& img, int dev) {
         view.wild_count = r32(60);
         view.glob_seg_off = r32(104);
         view.lit2pat_off = lit2pat_off.p; view.lit2pat = lit2pat.p; view.n_ac_lits = (uint32_t)off.size() - 1;
+        {
+            // one dependent load per text byte instead of a node + edge-list walk with failure links: the automaton as a
+            // dense table in HBM (there is room: a million literals need a few GB)
+            std::vector<uint32_t> nx, noff;
+            std::vector<uint8_t> cls;
+            uint32_t k = 0;
+            size_t limit = (size_t)8 << 30;
+            if (const char* env = getenv("MATCHY_AMD_DFA_MAX_MB")) limit = (size_t)atoll(env) << 20;
+            if (img.build_ac_dfa(nx, cls, k, noff, limit)) {
+                dfa.upload(nx); dfa_node.upload(noff); dfa_cls.upload(cls);
+                view.dfa = dfa.p; view.dfa_node = dfa_node.p; view.dfa_cls = dfa_cls.p; view.dfa_k = k;
+                bytes_uploaded += nx.size() * 4 + noff.size() * 4 + 256;
+            }
+        }
         bytes_uploaded += pv.size() + (off.size() + ids.size()) * 4;
     }
     {
@@ -337,6 +351,10 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         LookupParams lp{};
         lp.log = dptr; lp.len = len; lp.cands = cands_.p; lp.cand_cap = (uint32_t)cands_.n;
         lp.hits = hits_.p; lp.hit_cap = (uint32_t)hits_.n; lp.ids = ids_.p; lp.ids_cap = (uint32_t)ids_.n;
+        if (ddb_->view.has_glob) {
+            if (glob_work_.n < cands_.n / 8) glob_work_.alloc(cands_.n / 8);
+            lp.glob_work = glob_work_.p; lp.glob_work_cap = (uint32_t)glob_work_.n;
+        }
         lp.counters = counters_.p;
         launch_lookup(lp, ddb_->view, n_cu_ * 4, stream);
         PackParams pp{};
@@ -366,7 +384,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
         MXY_HIP(hipStreamSynchronize(stream));
         const ScanCounters& c = host_counters_;
-        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_v4 > v4_list_.n || c.n_dom > dom_list_.n;
+        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_v4 > v4_list_.n || c.n_dom > dom_list_.n;
         if (!over) break;
         if (trace) fprintf(stderr, "[matchy_amd] work buffers overflow (attempt %d): regrow and rescan\n", attempt);
         if (single_) throw HipError{"lookup_one: work buffers overflow"};
@@ -375,6 +393,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         if (c.n_rare > rare_.n) rare_.alloc((size_t)c.n_rare + c.n_rare / 4 + 1024);
         if (c.n_tok > tok_.n) tok_.alloc((size_t)c.n_tok + c.n_tok / 4 + 1024);
         if (c.n_heavy > heavy_.n) heavy_.alloc((size_t)c.n_heavy + c.n_heavy / 4 + 1024);
+        if (glob_work_.n && c.n_glob_work > glob_work_.n) glob_work_.alloc((size_t)c.n_glob_work + c.n_glob_work / 4 + 1024);
         if (c.n_v4 > v4_list_.n) v4_list_.alloc((size_t)c.n_v4 + c.n_v4 / 4 + 1024);
         if (c.n_dom > dom_list_.n) dom_list_.alloc((size_t)c.n_dom + c.n_dom / 4 + 1024);
         if (c.n_hits > hits_.n || hits_.n < cands_.n / 4) hits_.alloc(std::max<size_t>((size_t)c.n_hits + c.n_hits / 4 + 1024, cands_.n / 4));

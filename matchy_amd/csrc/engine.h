@@ -62,6 +62,8 @@ struct DeviceDb {
     DevBuf<uint2> ip_nodes, ip_l1;
     DevBuf<uint32_t> ip_bm24;
     DevBuf<uint2> tld_tab;
+    DevBuf<uint32_t> dfa, dfa_node;
+    DevBuf<uint8_t> dfa_cls;
     DevBuf<LitSlot> lit_slots;
     DevBuf<uint8_t> lit_pool, pg, psl_pool;
     DevBuf<uint32_t> lit2pat_off, lit2pat, bloom;
@@ -125,7 +127,7 @@ private:
     DevBuf<long long> final_offs_;
     DevBuf<uint32_t> v4_list_, dom_list_;
     DevBuf<Hit> hits_;
-    DevBuf<uint32_t> ids_;
+    DevBuf<uint32_t> ids_, glob_work_;
     DevBuf<ScanCounters> counters_;
     DevBuf<uint8_t> staging_;  // scan_host only
     void* pinned_ = nullptr;   // one pinned block: FinalHit[n] | u32 ids[m] | i64 offs[m]  (or Hit[n] for HITS_RAW)

@@ -837,7 +837,7 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const uint8_t* 
 }
 
 // Paraglob::find_all (pg:1028-1182): returns the sorted unique pattern ids in out[0..n)
-__device__ uint32_t glob_find_all(const DevDb& db, const uint8_t* text, uint32_t tn, uint32_t* out, uint32_t* err) {
+__device__ uint32_t glob_find_all(const DevDb& db, const uint8_t* cls, const uint8_t* text, uint32_t tn, uint32_t* out, uint32_t* err) {
     uint32_t n = 0;
     auto insert = [&](uint32_t id) {
         uint32_t k = 0;
@@ -866,50 +866,100 @@ __device__ uint32_t glob_find_all(const DevDb& db, const uint8_t* text, uint32_t
     }
     if (db.ac_size > 0 && tn > 0) {
         const uint8_t* ac = db.pg + db.ac_start;
-        uint32_t cur = 0;
-        for (uint32_t i = 0; i < tn; ++i) {
-            uint32_t ch = text[i];
-            for (;;) {
-                uint32_t nx = ac_transition(ac, db.ac_size, cur, ch);
-                if (nx != 0xFFFFFFFFu) { cur = nx; break; }
-                if (cur == 0) break;
-                if (cur + 20 > db.ac_size) break;
-                cur = ld32(ac + cur + 8);
+        // literals that end at node `cur` -> their patterns (run_ac_matching_into_static collects them per visited node)
+        auto outputs = [&](uint32_t cur) {
+            const uint32_t pc = ac[cur + 3];
+            if (!pc) return;
+            const uint32_t po = ld32(ac + cur + 16);
+            if (po + pc * 4 > db.ac_size) return;
+            for (uint32_t k = 0; k < pc; ++k) {
+                const uint32_t lit = ld32(ac + po + k * 4);
+                if (lit >= db.n_ac_lits) continue;
+                for (uint32_t q = db.lit2pat_off[lit]; q < db.lit2pat_off[lit + 1]; ++q) consider(db.lit2pat[q]);
             }
-            if (cur + 20 > db.ac_size) continue;
-            uint32_t pc = ac[cur + 3];
-            if (pc) {
-                uint32_t po = ld32(ac + cur + 16);
-                if (po + pc * 4 <= db.ac_size) {
-                    for (uint32_t k = 0; k < pc; ++k) {
-                        uint32_t lit = ld32(ac + po + k * 4);
-                        if (lit >= db.n_ac_lits) continue;
-                        for (uint32_t q = db.lit2pat_off[lit]; q < db.lit2pat_off[lit + 1]; ++q) consider(db.lit2pat[q]);
-                    }
+        };
+        if (db.dfa) {
+            // flattened automaton: one table load per byte, the text fetched 8 bytes at a time
+            uint32_t st = 0;
+            for (uint32_t i = 0; i < tn; i += 8) {
+                uint64_t w = 0;
+                const uint32_t m = min(8u, tn - i);
+                if (m == 8) __builtin_memcpy(&w, text + i, 8);
+                else for (uint32_t b = 0; b < m; ++b) w |= (uint64_t)text[i + b] << (8 * b);
+                for (uint32_t b = 0; b < m; ++b) {
+                    const uint32_t e = db.dfa[(size_t)st * db.dfa_k + cls[(uint32_t)w & 0xFF]];
+                    w >>= 8;
+                    st = e & 0x7FFFFFFFu;
+                    if (e >> 31) outputs(db.dfa_node[st]);
                 }
+            }
+        } else {
+            uint32_t cur = 0;
+            for (uint32_t i = 0; i < tn; ++i) {
+                uint32_t ch = text[i];
+                for (;;) {
+                    uint32_t nx = ac_transition(ac, db.ac_size, cur, ch);
+                    if (nx != 0xFFFFFFFFu) { cur = nx; break; }
+                    if (cur == 0) break;
+                    if (cur + 20 > db.ac_size) break;
+                    cur = ld32(ac + cur + 8);
+                }
+                if (cur + 20 > db.ac_size) continue;
+                outputs(cur);
             }
         }
     }
     return n;
 }
 
-// GLOB=false instantiation (databases without a PARAGLOB section) carries no glob state and stays register-lean.
+// true when the text reaches a state of the flattened AC automaton that has output literals (necessary for any glob
+// with a literal part to match)
+__device__ __forceinline__ bool ac_touches_output(const DevDb& db, const uint8_t* cls, const uint8_t* text, uint32_t tn) {
+    uint32_t st = 0, any = 0;
+    for (uint32_t i = 0; i < tn; i += 8) {
+        uint64_t w = 0;
+        const uint32_t m = min(8u, tn - i);
+        if (m == 8) __builtin_memcpy(&w, text + i, 8);
+        else for (uint32_t b = 0; b < m; ++b) w |= (uint64_t)text[i + b] << (8 * b);
+        for (uint32_t b = 0; b < m; ++b) {
+            const uint32_t e = db.dfa[(size_t)st * db.dfa_k + cls[(uint32_t)w & 0xFF]];
+            w >>= 8;
+            st = e & 0x7FFFFFFFu;
+            any |= e;
+        }
+    }
+    return (any >> 31) != 0;
+}
+
+// GLOB=false carries no glob state and stays register-lean: databases without a PARAGLOB section, and the first pass of
+// the two-pass lookup (p.ac_filter): IP and literal lookups plus one DFA walk per string candidate; candidates that
+// touch an AC output state are deferred to the GLOB=true pass through p.glob_work. GLOB=true does the full
+// Paraglob::find_all, over all candidates or (p.from_work) over the work list.
 template <bool GLOB>
 __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
-    uint32_t n = min(p.counters->n_cand, p.cand_cap);
+    __shared__ uint8_t cls[256];  // byte -> DFA class
+    cls[threadIdx.x] = db.dfa ? db.dfa_cls[threadIdx.x] : 0;
+    __syncthreads();
+    const uint32_t n = p.from_work ? min(p.counters->n_glob_work, p.glob_work_cap) : min(p.counters->n_cand, p.cand_cap);
     uint32_t stride = gridDim.x * blockDim.x;
     ChunkWriter<Hit, HIT_CHUNK> cw;
+    ChunkWriter<uint32_t, 64> ww;
     Hit SH{};
     SH.kind = 0xFF;
-    // loop bound is wave-uniform so that the chunk writer sees converged waves
+    // loop bound is wave-uniform so that the chunk writers see converged waves
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
         uint32_t i = base + threadIdx.x;
         Hit h{};
-        bool emit = false;
+        bool emit = false, defer = false;
         uint32_t globs[GLOB ? MAX_GLOB_RESULTS : 1];
         uint32_t ng = 0;
         Candidate c{0, 0xFFFFFFFFu, 0, 0};
-        if (i < n) c = p.cands[i];
+        if (p.from_work) {
+            const uint32_t idx = i < n ? p.glob_work[i] : 0xFFFFFFFFu;
+            if (idx != 0xFFFFFFFFu && idx < p.cand_cap) { c = p.cands[idx]; i = idx; }
+        } else if (i < n) {
+            c = p.cands[i];
+        }
         if (c.len_type != 0xFFFFFFFFu) {
             uint32_t type = c.len_type >> 24, tl = c.len_type & 0xFFFFFF;
             const uint8_t* text = p.log + c.start;
@@ -922,10 +972,13 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
                 uint32_t off, pfx;
                 if (db.has_ip && d_parse_ipv6(text, tl, seg) && trie_v6(db, seg, off, pfx)) { h.kind = 2; h.a = off; h.prefix_len = (uint8_t)pfx; emit = true; }
             } else {
-                uint32_t pid = 0xFFFFFFFFu;
-                if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q)) pid = q; }
-                if constexpr (GLOB) ng = glob_find_all(db, text, tl, globs, &p.counters->error);
-                if (pid != 0xFFFFFFFFu || ng) { h.kind = 3; h.a = pid; h.n_globs = (uint16_t)ng; emit = true; }
+                if (!GLOB && p.ac_filter && ac_touches_output(db, cls, text, tl)) defer = true;
+                else {
+                    uint32_t pid = 0xFFFFFFFFu;
+                    if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q)) pid = q; }
+                    if constexpr (GLOB) ng = glob_find_all(db, cls, text, tl, globs, &p.counters->error);
+                    if (pid != 0xFFFFFFFFu || ng) { h.kind = 3; h.a = pid; h.n_globs = (uint16_t)ng; emit = true; }
+                }
             }
         }
         if (GLOB && emit && ng) {
@@ -934,8 +987,10 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
             for (uint32_t k = 0; k < ng; ++k) if (io + k < p.ids_cap) p.ids[io + k] = globs[k];
         }
         cw.append(emit, h, p.hits, p.hit_cap, &p.counters->n_hits, SH);
+        if (!GLOB && p.ac_filter) ww.append(defer, i, p.glob_work, p.glob_work_cap, &p.counters->n_glob_work, 0xFFFFFFFFu);
     }
     cw.pad_rest(p.hits, p.hit_cap, SH);
+    if (!GLOB && p.ac_filter) ww.pad_rest(p.glob_work, p.glob_work_cap, 0xFFFFFFFFu);
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->hits_true, cw.total);
 }
 
@@ -1019,9 +1074,21 @@ void launch_validate(const TokParams& p, const DevDb& db, int grid, hipStream_t 
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_rare, dim3(grid), dim3(64), 0, stream, p, db);
 }
-void launch_lookup(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream) {
-    if (db.has_glob) hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(256), 0, stream, p, db);
-    else hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(256), 0, stream, p, db);
+void launch_lookup(const LookupParams& p_in, const DevDb& db, int grid, hipStream_t stream) {
+    LookupParams p = p_in;
+    p.ac_filter = 0; p.from_work = 0;
+    if (!db.has_glob) {
+        hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(256), 0, stream, p, db);
+    } else if (db.dfa && db.wild_count == 0 && p.glob_work && grid > 1) {
+        // two passes: lean lookup + AC prefilter for everything, the register-heavy glob matcher only for the few
+        // candidates that reach an AC output state (without literal hits no glob can match: pure wildcards aside)
+        p.ac_filter = 1;
+        hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(256), 0, stream, p, db);
+        p.ac_filter = 0; p.from_work = 1;
+        hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(256), 0, stream, p, db);
+    } else {
+        hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(256), 0, stream, p, db);
+    }
 }
 
 }  // namespace mxy

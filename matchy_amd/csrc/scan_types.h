@@ -72,6 +72,12 @@ struct DevDb {
     uint32_t patterns_off, pattern_count;
     uint32_t wild_off, wild_count;
     uint32_t glob_seg_off;
+    // dense DFA of the Aho-Corasick automaton (DbImage::build_ac_dfa), or null: next state = dfa[state * dfa_k +
+    // dfa_cls[byte]] (bit 31: that state has output literals), dfa_node[state] = its node offset in the AC section
+    const uint32_t* dfa;
+    const uint8_t* dfa_cls;
+    const uint32_t* dfa_node;
+    uint32_t dfa_k;
     const uint32_t* lit2pat_off;  // [n_ac_lits + 1]
     const uint32_t* lit2pat;
     uint32_t n_ac_lits;
@@ -105,7 +111,7 @@ struct ScanCounters {
     uint32_t n_final;                // dense final hit records written by k_pack
     uint32_t n_final_ids;            // entries of the pattern-id / data-offset side arrays
     uint32_t n_heavy;                // tokens that need a checksum validator (Base58Check, Bech32, EIP-55, Monero)
-    uint32_t pad[1];
+    uint32_t n_glob_work;            // candidates whose text reaches an output state of the AC automaton (glob work list)
 };
 
 struct TokParams {
@@ -140,6 +146,11 @@ struct LookupParams {
     uint32_t hit_cap;
     uint32_t* ids;
     uint32_t ids_cap;
+    // two-pass glob lookup: the lean pass (ac_filter = 1) lists the candidates that touch an AC output state in
+    // glob_work; the glob pass (from_work = 1) handles exactly those. Both 0: one pass over all candidates.
+    uint32_t* glob_work;
+    uint32_t glob_work_cap;
+    uint32_t ac_filter, from_work;
     ScanCounters* counters;
 };
 
