@@ -314,7 +314,6 @@ void Scanner::ensure_capacity(uint32_t len) {
     if (final_.n < hits_.n) { final_.alloc(hits_.n); }
     if (final_ids_.n < hits_.n + ids_.n) { final_ids_.alloc(hits_.n + ids_.n); final_offs_.alloc(hits_.n + ids_.n); }
     size_t want_a = std::max<size_t>(4096, (size_t)len / 32);
-    if (v4_list_.n < want_a) v4_list_.alloc(want_a);
     if (dom_list_.n < want_a) dom_list_.alloc(want_a);
 }
 
@@ -334,7 +333,6 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.rare = rare_.p; tp.rare_cap = (uint32_t)rare_.n;
     tp.tok = tok_.p; tp.tok_cap = (uint32_t)tok_.n;
     tp.heavy = heavy_.p; tp.heavy_cap = (uint32_t)heavy_.n;
-    tp.v4_list = v4_list_.p; tp.v4_cap = (uint32_t)v4_list_.n;
     tp.dom_list = dom_list_.p; tp.dom_cap = (uint32_t)dom_list_.n;
     tp.counters = counters_.p;
     int grid_tok = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * 8);
@@ -384,7 +382,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
         MXY_HIP(hipStreamSynchronize(stream));
         const ScanCounters& c = host_counters_;
-        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_v4 > v4_list_.n || c.n_dom > dom_list_.n;
+        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_dom > dom_list_.n;
         if (!over) break;
         if (trace) fprintf(stderr, "[matchy_amd] work buffers overflow (attempt %d): regrow and rescan\n", attempt);
         if (single_) throw HipError{"lookup_one: work buffers overflow"};
@@ -394,7 +392,6 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         if (c.n_tok > tok_.n) tok_.alloc((size_t)c.n_tok + c.n_tok / 4 + 1024);
         if (c.n_heavy > heavy_.n) heavy_.alloc((size_t)c.n_heavy + c.n_heavy / 4 + 1024);
         if (glob_work_.n && c.n_glob_work > glob_work_.n) glob_work_.alloc((size_t)c.n_glob_work + c.n_glob_work / 4 + 1024);
-        if (c.n_v4 > v4_list_.n) v4_list_.alloc((size_t)c.n_v4 + c.n_v4 / 4 + 1024);
         if (c.n_dom > dom_list_.n) dom_list_.alloc((size_t)c.n_dom + c.n_dom / 4 + 1024);
         if (c.n_hits > hits_.n || hits_.n < cands_.n / 4) hits_.alloc(std::max<size_t>((size_t)c.n_hits + c.n_hits / 4 + 1024, cands_.n / 4));
         if (c.n_ids > ids_.n) ids_.alloc((size_t)c.n_ids + c.n_ids / 4 + 1024);
@@ -408,8 +405,8 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     if (c.error & 2) throw HipError{"scan: a glob pattern nests more than MAX_GLOB_STARS '*' segments"};
     const double t_counters = since();
     if (trace)
-        fprintf(stderr, "[matchy_amd] lines=%llu n_v4=%u n_dom=%u n_rare=%u n_tok=%u n_heavy=%u n_cand=%u (true %u) n_hits=%u (true %u) n_ids=%u final=%u\n",
-                c.lines, c.n_v4, c.n_dom, c.n_rare, c.n_tok, c.n_heavy, c.n_cand, c.cand_true, c.n_hits, c.hits_true, c.n_ids, c.n_final);
+        fprintf(stderr, "[matchy_amd] lines=%llu n_dom=%u n_rare=%u n_tok=%u n_heavy=%u n_cand=%u (true %u) n_hits=%u (true %u) n_ids=%u glob_work=%u final=%u\n",
+                c.lines, c.n_dom, c.n_rare, c.n_tok, c.n_heavy, c.n_cand, c.cand_true, c.n_hits, c.hits_true, c.n_ids, c.n_glob_work, c.n_final);
     out.lines = c.lines; out.n_cand = single_ ? c.n_cand : c.cand_true;
     out.n_hits = !last_lookup_ ? 0 : (single_ ? c.hits_true : c.n_final);
     if (profile_) {

@@ -125,7 +125,7 @@ private:
     DevBuf<FinalHit> final_;
     DevBuf<uint32_t> final_ids_;
     DevBuf<long long> final_offs_;
-    DevBuf<uint32_t> v4_list_, dom_list_;
+    DevBuf<uint32_t> dom_list_;
     DevBuf<Hit> hits_;
     DevBuf<uint32_t> ids_, glob_work_;
     DevBuf<ScanCounters> counters_;

@@ -126,7 +126,7 @@ __device__ __forceinline__ void drain_dom(const uint32_t* ring, uint32_t& head, 
     if (lane < n) {
         j = ring[(head + lane) & (QCAP - 1)];
         keep = true;
-        if (j >= cx.res_lo && j + 8 <= cx.res_hi && !(p.debug & 2)) {
+        if (j >= cx.res_lo && j + 8 <= cx.res_hi) {
             uint32_t w[2];
             raw_read<2>(cx.raw32, j, w);
             uint32_t th = 2166136261u, stop = 0;

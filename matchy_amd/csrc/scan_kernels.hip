@@ -1,11 +1,13 @@
 // HIP kernels for the `matchy match` hot path on gfx950 (MI355X, wave64).
 //
-//   (k_anchor, stage A1, lives in k_anchor.hip: streaming pass that compacts anchors into per-type lists)
-//   k_validate  stage A2: one lane per IPv4 / domain anchor: dotted-quad parse; domain run + PSL + label rules.
-//   k_rare      stage A3: validators that are rare in logs and heavy in registers (IPv6 text, e-mail, hex hashes,
-//               Base58Check, Bech32, EIP-55, Monero) — one lane per anchor.
-//   k_lookup    stage B: one lane per candidate: MMDB trie walk / XXH64 literal probe / Aho-Corasick walk + glob
-//               verification, hits compacted with one atomic per wave.
+//   (k_anchor, stage A1, lives in k_anchor.hip: streaming pass; validates IPv4 itself, lists the other anchors)
+//   k_validate  stage A2: one lane per domain / IPv6 / e-mail anchor and per long token (hex hashes; prefix tests for
+//               the address formats).
+//   k_rare      stage A3: checksum validators that are rare in logs and heavy in registers (Base58Check, Bech32,
+//               EIP-55, Monero) — one lane per prefiltered token.
+//   k_lookup    stage B: one lane per candidate: MMDB trie walk / XXH64 literal probe / Aho-Corasick DFA + glob
+//               verification, hits compacted through wave-private chunks.
+//   k_pack      dense matchy_scan_hit_t records + pattern-id -> data-offset resolution.
 //
 // Semantics follow the reference CPU path; every rule cites the reference function it reproduces
 // (matchy-extractor/src/lib.rs = "ext", matchy-format/src/mmdb/tree.rs = "tree", matchy-literal-hash/src/lib.rs
@@ -505,8 +507,7 @@ __device__ bool val_eth(const uint8_t* a) {  // ext:1328-1361, 1840-1892: "0x" +
     return true;
 }
 
-// k_validate — stage A2: one lane per IPv4 / domain anchor written by k_anchor (lean kernel, high occupancy;
-// the dependent byte loads hit L2: anchors of one wave lie within a few KiB of each other).
+// k_validate — stage A2: one lane per domain / IPv6 / e-mail anchor and per long token written by k_anchor.
 __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     // LDS: the TLD Bloom filter and the exact short-label table for the domain loop; the same bytes are reused
     // afterwards as one 80-byte window per lane for the IPv6 validator
@@ -578,16 +579,16 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         {
             Candidate c{0, 0, 0, 0};
             bool emit = false;
-            if (live && (p.flags & EX_HASHES) && !(p.debug & 8)) {
+            if (live && (p.flags & EX_HASHES)) {
                 const int ht = tl == 32 ? IT_MD5 : tl == 40 ? IT_SHA1 : tl == 64 ? IT_SHA256 : tl == 96 ? IT_SHA384 : tl == 128 ? IT_SHA512 : -1;
-                if (ht >= 0 && all_hex_wide(s, tl)) { c.start = ra.pos; c.len_type = tl | ((uint32_t)ht << 24); emit = !(p.debug & 32); }
+                if (ht >= 0 && all_hex_wide(s, tl)) { c.start = ra.pos; c.len_type = tl | ((uint32_t)ht << 24); emit = true; }
             }
             cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
         }
         // a token can yield several items: hash, Bitcoin, Ethereum and Monero are independent extractors
         {
             uint32_t hk = 0;
-            if (live && (p.flags & EX_BITCOIN) && tl >= 26 && tl <= 62 && !(p.debug & 16)) {
+            if (live && (p.flags & EX_BITCOIN) && tl >= 26 && tl <= 62) {
                 if (s[0] == 'b' && s[1] == 'c' && s[2] == '1') hk = HEAVY_BECH32;
                 else if (s[0] == '1' || s[0] == '3') hk = HEAVY_B58;
             }

@@ -101,7 +101,7 @@ struct ScanCounters {
     uint32_t n_cand;                 // candidates appended (may exceed capacity → overflow)
     uint32_t n_rare;                 // IPv6 / e-mail anchors
     uint32_t n_tok;                  // long-token anchors (hash / crypto candidates)
-    uint32_t n_v4;                   // IPv4 anchors (first dot of a digit run that follows a boundary)
+    uint32_t reserved0;
     uint32_t n_dom;                  // domain anchors (first byte of a label that follows a dot)
     uint32_t n_hits;
     uint32_t n_ids;
@@ -130,9 +130,7 @@ struct TokParams {
     uint32_t tok_cap;
     RareAnchor* heavy;        // tokens that passed the cheap prefilters of k_validate and need k_rare
     uint32_t heavy_cap;
-    uint32_t* v4_list;        // anchor positions written by k_anchor, consumed by k_validate
-    uint32_t v4_cap;
-    uint32_t* dom_list;
+    uint32_t* dom_list;       // domain anchor positions written by k_anchor (after its prefilter), consumed by k_validate
     uint32_t dom_cap;
     ScanCounters* counters;
 };
