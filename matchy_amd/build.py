@@ -8,12 +8,14 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libmatchy_amd.so"
+BINDIR = PKG / "bin"
+CLI = BINDIR / "matchy"
 SOURCES = ["k_anchor.hip", "scan_kernels.hip", "engine.cpp", "db_image.cpp", "db_builder.cpp", "data_codec.cpp", "capi.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 def needs_build():
-    if not LIB.exists():
+    if not LIB.exists() or not CLI.exists():
         return True
     t = LIB.stat().st_mtime
     deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "matchy_amd.h", Path(__file__)]
@@ -47,6 +49,11 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc compilation failed")
     link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs, "-ldl", "-lpthread"]
     subprocess.run(link, check=True)
+    # the `matchy` command line (build / match) on top of the library
+    BINDIR.mkdir(exist_ok=True)
+    cli = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", str(CSRC / "cli_main.cpp"), "-o", str(CLI),
+           f"-L{LIBDIR}", "-lmatchy_amd", "-Wl,-rpath,$ORIGIN/../lib"]
+    subprocess.run(cli, check=True)
     return LIB
 
 

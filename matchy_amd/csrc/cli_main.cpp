@@ -1,0 +1,419 @@
+// `matchy` command line for the MI355X build: the two subcommands of the reference CLI that sit on the hot path
+// (crates/matchy/src/bin/matchy.rs:78-212):
+//
+//   matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-v]
+//   matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N]
+//
+// `match` prints one JSON object per match on stdout (same records as the reference's parallel path,
+// match_processor/parallel.rs:297-369: sorted keys, timestamp "0.000") and, with -s, the [INFO] statistics block on
+// stderr (commands/match_cmd.rs:514-581). Every batch is scanned on the GPU through the C ABI (matchy_scanner_scan);
+// there is no CPU scan path. Flags that only tune the reference's CPU thread pool (-j, --readers, --cache-size, -p,
+// --debug-routing) are accepted and ignored; -f/--follow and compressed inputs are not supported.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/matchy_amd.h"
+#include "data_codec.h"
+#include "db_builder.h"
+
+using namespace mxy;
+
+namespace {
+
+int usage() {
+    fprintf(stderr,
+            "usage:\n"
+            "  matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-v]\n"
+            "  matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N]\n");
+    return 2;
+}
+
+bool ends_with_ci(const std::string& s, const char* suf) {
+    size_t n = strlen(suf);
+    if (s.size() < n) return false;
+    for (size_t i = 0; i < n; ++i) if (tolower((unsigned char)s[s.size() - n + i]) != suf[i]) return false;
+    return true;
+}
+
+std::string fmt_num(unsigned long long v) {  // 1234567 -> "1,234,567" (bin/cli_utils.rs:143-153)
+    std::string s = std::to_string(v), out;
+    for (size_t i = 0; i < s.size(); ++i) {
+        if (i && (s.size() - i) % 3 == 0) out.push_back(',');
+        out.push_back(s[i]);
+    }
+    return out;
+}
+
+std::string trim(const std::string& s) {
+    size_t a = 0, b = s.size();
+    while (a < b && isspace((unsigned char)s[a])) ++a;
+    while (b > a && isspace((unsigned char)s[b - 1])) --b;
+    return s.substr(a, b - a);
+}
+
+// One CSV record (RFC 4180 quoting as the `csv` crate reads it by default: quotes, doubled quotes, embedded newlines).
+bool read_csv_record(std::istream& in, std::vector<std::string>& out) {
+    out.clear();
+    std::string cell;
+    bool quoted = false, any = false;
+    int ch;
+    while ((ch = in.get()) != EOF) {
+        any = true;
+        if (quoted) {
+            if (ch == '"') {
+                if (in.peek() == '"') { cell.push_back('"'); in.get(); }
+                else quoted = false;
+            } else cell.push_back((char)ch);
+        } else if (ch == '"' && cell.empty()) quoted = true;
+        else if (ch == ',') { out.push_back(cell); cell.clear(); }
+        else if (ch == '\n') { if (!cell.empty() && cell.back() == '\r') cell.pop_back(); out.push_back(cell); return true; }
+        else cell.push_back((char)ch);
+    }
+    if (!any) return false;
+    out.push_back(cell);
+    return true;
+}
+
+// CSV cell typing of the reference CLI (commands/build_cmd.rs:226-236): i64 -> Int32 (truncating), u64 -> Uint64,
+// f64 -> Double, true/false -> Bool, else String.
+DataValue csv_value(const std::string& v) {
+    errno = 0;
+    char* end = nullptr;
+    if (!v.empty() && !isspace((unsigned char)v[0])) {
+        long long i = strtoll(v.c_str(), &end, 10);
+        if (errno == 0 && end && *end == 0 && (isdigit((unsigned char)v[0]) || ((v[0] == '-' || v[0] == '+') && v.size() > 1 && isdigit((unsigned char)v[1]))))
+            return DataValue::Int32((int32_t)i);
+        errno = 0;
+        if (isdigit((unsigned char)v[0]) || (v[0] == '+' && v.size() > 1)) {
+            unsigned long long u = strtoull(v.c_str(), &end, 10);
+            if (errno == 0 && end && *end == 0) return DataValue::Uint64(u);
+        }
+        errno = 0;
+        double f = strtod(v.c_str(), &end);
+        if (errno == 0 && end && *end == 0 && end != v.c_str()) {
+            // Rust's f64::from_str accepts decimal / exponent forms, "inf", "infinity", "nan" (any case); it has no hex floats
+            bool hexish = v.find('x') != std::string::npos || v.find('X') != std::string::npos;
+            if (!hexish) return DataValue::Double(f);
+        }
+    }
+    if (v == "true" || v == "false") return DataValue::Bool(v == "true");
+    return DataValue::String(v);
+}
+
+bool add_inputs(DatabaseBuilder& b, const std::vector<std::string>& inputs, const std::string& format, bool verbose, std::string& err) {
+    size_t total = 0;
+    for (const std::string& path : inputs) {
+        std::ifstream in(path, std::ios::binary);
+        if (!in) { err = "Failed to open input file: " + path; return false; }
+        if (format == "text") {
+            std::string line;
+            bool first = true;
+            while (std::getline(in, line)) {
+                if (first) {
+                    first = false;
+                    size_t commas = 0;
+                    for (char c : line) commas += c == ',';
+                    if (commas >= 3)
+                        fprintf(stderr, "Warning: %s looks like CSV but you specified --format text.\nIf this is a CSV file, use --format csv instead.\n", path.c_str());
+                }
+                std::string entry = trim(line);
+                if (entry.empty() || entry[0] == '#') continue;
+                if (!b.add_entry(entry, DataValue::Map())) { err = "Failed to add entry '" + entry + "': " + b.error(); return false; }
+                ++total;
+            }
+        } else if (format == "csv") {
+            std::vector<std::string> hdr, rec;
+            if (!read_csv_record(in, hdr)) { err = "Failed to read CSV headers"; return false; }
+            int entry_col = -1;
+            for (size_t i = 0; i < hdr.size(); ++i) if (hdr[i] == "entry" || hdr[i] == "key") { entry_col = (int)i; break; }
+            if (entry_col < 0) {
+                err = "CSV must have an 'entry' or 'key' column. Found headers: ";
+                for (size_t i = 0; i < hdr.size(); ++i) err += (i ? ", " : "") + hdr[i];
+                return false;
+            }
+            size_t row = 1;
+            while (read_csv_record(in, rec)) {
+                ++row;
+                if (rec.size() == 1 && rec[0].empty()) continue;  // blank line
+                if ((size_t)entry_col >= rec.size()) { err = "Missing entry column at row " + std::to_string(row); return false; }
+                DataValue data = DataValue::Map();
+                for (size_t i = 0; i < hdr.size() && i < rec.size(); ++i)
+                    if ((int)i != entry_col && !rec[i].empty()) data.map[hdr[i]] = csv_value(rec[i]);
+                if (!b.add_entry(rec[entry_col], data)) {
+                    err = "Failed to add entry '" + rec[entry_col] + "' at row " + std::to_string(row) + ": " + b.error();
+                    return false;
+                }
+                ++total;
+            }
+        } else if (format == "json") {
+            // [{"key": "...", "data": {...}}, ...] with the CLI's number typing (bin/cli_utils.rs:203-236)
+            std::stringstream ss;
+            ss << in.rdbuf();
+            std::string text = ss.str(), perr;
+            DataValue doc;
+            if (!parse_json(text.data(), text.size(), NumberTyping::CLI, doc, perr)) { err = "Failed to parse JSON: " + perr; return false; }
+            if (doc.type != DataValue::ARRAY) { err = "Failed to parse JSON: expected an array of {key, data} objects"; return false; }
+            for (size_t i = 0; i < doc.arr.size(); ++i) {
+                const DataValue& item = doc.arr[i];
+                auto k = item.type == DataValue::MAP ? item.map.find("key") : item.map.end();
+                if (item.type != DataValue::MAP || k == item.map.end() || k->second.type != DataValue::STRING) {
+                    err = "Missing 'key' field at index " + std::to_string(i);
+                    return false;
+                }
+                DataValue data = DataValue::Map();
+                auto d = item.map.find("data");
+                if (d != item.map.end()) {
+                    if (d->second.type != DataValue::MAP) { err = "Expected JSON object for data at index " + std::to_string(i); return false; }
+                    data = d->second;
+                }
+                if (!b.add_entry(k->second.str, data)) {
+                    err = "Failed to add entry '" + k->second.str + "' at index " + std::to_string(i) + ": " + b.error();
+                    return false;
+                }
+                ++total;
+            }
+        } else {
+            err = "Unknown format: " + format + ". Use 'text', 'csv' or 'json'";
+            return false;
+        }
+    }
+    if (verbose) printf("  Total: %zu entries\n", total);
+    return true;
+}
+
+int cmd_build(int argc, char** argv) {
+    std::vector<std::string> inputs;
+    std::string out, format = "text", dbtype, desc, lang = "en";
+    bool verbose = false;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&](const char* name) -> const char* { if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", name); exit(2); } return argv[++i]; };
+        if (a == "-o" || a == "--output") out = next("-o");
+        else if (a == "-f" || a == "--format") format = next("-f");
+        else if (a == "-t" || a == "--database-type") dbtype = next("-t");
+        else if (a == "-d" || a == "--description") desc = next("-d");
+        else if (a == "--desc-lang") lang = next("--desc-lang");
+        else if (a == "-v" || a == "--verbose" || a == "--debug") verbose = true;
+        else if (a == "-i" || a == "--case-insensitive") { fprintf(stderr, "Error: case-insensitive databases are not supported by this build\n"); return 1; }
+        else if (!a.empty() && a[0] == '-' && a != "-") { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
+        else inputs.push_back(a);
+    }
+    if (inputs.empty() || out.empty()) return usage();
+    DatabaseBuilder b;
+    if (!dbtype.empty()) b.set_database_type(dbtype);
+    if (!desc.empty()) b.set_description(lang, desc);
+    if (const char* e = getenv("MATCHY_BUILD_EPOCH")) b.set_build_epoch(strtoull(e, nullptr, 10));  // reproducible builds
+    std::string err;
+    if (!add_inputs(b, inputs, format, verbose, err)) { fprintf(stderr, "Error: %s\n", err.c_str()); return 1; }
+    std::vector<uint8_t> blob;
+    if (!b.build(blob)) { fprintf(stderr, "Error: %s\n", b.error().c_str()); return 1; }
+    (void)chmod(out.c_str(), 0644);  // a previous build left the file read-only
+    FILE* f = fopen(out.c_str(), "wb");
+    if (!f || fwrite(blob.data(), 1, blob.size(), f) != blob.size()) { fprintf(stderr, "Error: Failed to write %s\n", out.c_str()); if (f) fclose(f); return 1; }
+    fclose(f);
+    (void)chmod(out.c_str(), 0444);  // the reference marks databases read-only (build_cmd.rs:15-35, 364-371)
+    printf("\xE2\x9C\x93 Database built: %s\n", out.c_str());
+    if (verbose) {
+        const BuildStats& st = b.stats();
+        printf("  IP entries: %zu, literals: %zu, globs: %zu, tree nodes: %u (%d-bit records), size: %zu bytes\n", st.ip_entries,
+               st.literal_entries, st.glob_entries, st.node_count, st.record_size, blob.size());
+    }
+    return 0;
+}
+
+// --extractors=ip,domain / -crypto,-hash ... (bin/matchy.rs:124-131): returns the MATCHY_EXTRACT_* mask, 0 = auto
+bool parse_extractors(const std::string& spec, uint32_t auto_mask, uint32_t& mask, std::string& err) {
+    struct { const char* name; uint32_t bits; } names[] = {
+        {"ipv4", MATCHY_EXTRACT_IPV4}, {"ipv6", MATCHY_EXTRACT_IPV6}, {"ip", MATCHY_EXTRACT_IPV4 | MATCHY_EXTRACT_IPV6}, {"ips", MATCHY_EXTRACT_IPV4 | MATCHY_EXTRACT_IPV6},
+        {"domain", MATCHY_EXTRACT_DOMAINS}, {"domains", MATCHY_EXTRACT_DOMAINS}, {"email", MATCHY_EXTRACT_EMAILS}, {"emails", MATCHY_EXTRACT_EMAILS},
+        {"hash", MATCHY_EXTRACT_HASHES}, {"hashes", MATCHY_EXTRACT_HASHES}, {"bitcoin", MATCHY_EXTRACT_BITCOIN}, {"ethereum", MATCHY_EXTRACT_ETHEREUM},
+        {"monero", MATCHY_EXTRACT_MONERO}, {"crypto", MATCHY_EXTRACT_BITCOIN | MATCHY_EXTRACT_ETHEREUM | MATCHY_EXTRACT_MONERO},
+    };
+    uint32_t enable = 0, disable = 0;
+    std::stringstream ss(spec);
+    std::string tok;
+    while (std::getline(ss, tok, ',')) {
+        tok = trim(tok);
+        if (tok.empty()) continue;
+        bool neg = tok[0] == '-';
+        std::string n = neg ? tok.substr(1) : tok;
+        for (auto& c : n) c = (char)tolower((unsigned char)c);
+        uint32_t bits = 0;
+        for (auto& e : names) if (n == e.name) bits = e.bits;
+        if (!bits) { err = "Unknown extractor: " + n; return false; }
+        (neg ? disable : enable) |= bits;
+    }
+    mask = (enable ? enable : auto_mask) & ~disable;
+    return true;
+}
+
+struct Totals {
+    unsigned long long lines = 0, lines_with_matches = 0, matches = 0, candidates = 0, bytes = 0;
+};
+
+// Scan one newline-aligned batch, print its matches, update the totals. `base` = file offset of the batch.
+bool scan_batch(matchy_scanner_t* sc, const uint8_t* data, size_t len, const std::string& source, bool json, Totals& t) {
+    if (!len) return true;
+    matchy_scan_result_t r;
+    memset(&r, 0, sizeof(r));
+    if (matchy_scanner_scan(sc, data, len, &r) != MATCHY_SUCCESS) {
+        fprintf(stderr, "[ERROR] scan failed: %s\n", matchy_amd_last_error());
+        return false;
+    }
+    t.lines += r.lines; t.candidates += r.candidates; t.bytes += len; t.matches += r.n_hits;
+    // lines with matches: hits come sorted by offset; a new line starts when a '\n' lies between two hit starts
+    size_t prev = (size_t)-1;
+    for (size_t i = 0; i < r.n_hits; ++i) {
+        const size_t s = (size_t)r.hits[i].start;
+        if (prev == (size_t)-1 || memchr(data + prev, '\n', s - prev)) ++t.lines_with_matches;
+        prev = s;
+        if (json) {
+            char* line = matchy_scan_hit_to_json(sc, &r, i, data, source.c_str());
+            if (line) { fputs(line, stdout); fputc('\n', stdout); matchy_free_string(line); }
+        }
+    }
+    matchy_scan_result_free(&r);
+    return true;
+}
+
+bool process_input(matchy_scanner_t* sc, const std::string& path, size_t batch_bytes, bool json, Totals& t) {
+    int fd = path == "-" ? 0 : open(path.c_str(), O_RDONLY);
+    if (fd < 0) { fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), strerror(errno)); return false; }
+    if (ends_with_ci(path, ".gz")) { fprintf(stderr, "[ERROR] Failed to process %s: compressed inputs are not supported by this build\n", path.c_str()); if (fd) close(fd); return false; }
+    const std::string source = path == "-" ? "stdin" : path;
+    std::vector<uint8_t> buf(batch_bytes + 16);
+    size_t have = 0;
+    bool ok = true;
+    for (;;) {
+        if (have == buf.size() - 16) buf.resize(buf.size() * 2);  // a single line longer than the batch: grow
+        ssize_t n = read(fd, buf.data() + have, buf.size() - 16 - have);
+        if (n < 0) { fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), strerror(errno)); ok = false; break; }
+        have += (size_t)n;
+        if (n == 0) { ok = scan_batch(sc, buf.data(), have, source, json, t); break; }
+        if (have < batch_bytes) continue;
+        // newline-aligned cut like FileReader::next_batch (processing/mod.rs:206-251): scan up to the last '\n', carry the rest
+        const void* nl = memrchr(buf.data(), '\n', have);
+        if (!nl) continue;
+        const size_t cut = (const uint8_t*)nl - buf.data() + 1;
+        if (!scan_batch(sc, buf.data(), cut, source, json, t)) { ok = false; break; }
+        memmove(buf.data(), buf.data() + cut, have - cut);
+        have -= cut;
+    }
+    if (fd) close(fd);
+    return ok;
+}
+
+int cmd_match(int argc, char** argv) {
+    std::vector<std::string> pos;
+    std::string format = "json", extractors;
+    bool stats = false;
+    size_t batch_bytes = (size_t)256 << 20;  // GPU batches: large, so that one launch amortises PCIe latency
+    int device = 0;
+    if (const char* d = getenv("MATCHY_AMD_DEVICE")) device = atoi(d);
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&](const char* name) -> const char* { if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", name); exit(2); } return argv[++i]; };
+        auto eqval = [&](const char* name, std::string& out) {  // --name=value or --name value
+            size_t n = strlen(name);
+            if (a.compare(0, n, name) != 0) return false;
+            if (a.size() == n) { out = next(name); return true; }
+            if (a[n] == '=') { out = a.substr(n + 1); return true; }
+            return false;
+        };
+        std::string v;
+        if (eqval("--format", v)) format = v;
+        else if (a == "-s" || a == "--stats") stats = true;
+        else if (eqval("--batch-bytes", v)) { size_t b = strtoull(v.c_str(), nullptr, 10); if (b >= 4096) batch_bytes = b; }
+        else if (eqval("--extractors", v)) extractors = v;
+        else if (eqval("--device", v)) device = atoi(v.c_str());
+        else if (eqval("--threads", v) || eqval("--readers", v) || eqval("--cache-size", v)) {}
+        else if (a == "-j") (void)next("-j");
+        else if (a == "-p" || a == "--progress" || a == "--debug-routing") {}
+        else if (a == "-f" || a == "--follow") { fprintf(stderr, "Error: --follow is not supported by this build\n"); return 1; }
+        else if (a.size() > 1 && a[0] == '-') { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
+        else pos.push_back(a);
+    }
+    if (pos.size() < 2) return usage();
+    if (format != "json" && format != "summary") { fprintf(stderr, "Error: Unknown format: %s. Use 'json' or 'summary'\n", format.c_str()); return 1; }
+    const auto t0 = std::chrono::steady_clock::now();
+    // database: .mxy file, or a .csv / .json source that is built in memory first (match_cmd.rs:20-31, 222-239)
+    matchy_t* db = nullptr;
+    const std::string dbpath = pos[0];
+    if (ends_with_ci(dbpath, ".csv") || ends_with_ci(dbpath, ".json")) {
+        DatabaseBuilder b;
+        std::string err;
+        std::vector<uint8_t> blob;
+        if (!add_inputs(b, {dbpath}, ends_with_ci(dbpath, ".csv") ? "csv" : "json", false, err) || !b.build(blob)) {
+            fprintf(stderr, "Error: %s\n", err.empty() ? b.error().c_str() : err.c_str());
+            return 1;
+        }
+        db = matchy_open_buffer(blob.data(), blob.size());
+    } else {
+        db = matchy_open(dbpath.c_str());
+    }
+    if (!db) { fprintf(stderr, "Error: Failed to open database %s: %s\n", dbpath.c_str(), matchy_amd_last_error()); return 1; }
+    uint32_t mask = 0;
+    if (!extractors.empty()) {
+        uint32_t auto_mask = 0;
+        if (matchy_has_ip_data(db)) auto_mask |= MATCHY_EXTRACT_IPV4 | MATCHY_EXTRACT_IPV6;
+        if (matchy_has_literal_data(db) || matchy_has_glob_data(db))
+            auto_mask |= MATCHY_EXTRACT_DOMAINS | MATCHY_EXTRACT_EMAILS | MATCHY_EXTRACT_HASHES | MATCHY_EXTRACT_BITCOIN | MATCHY_EXTRACT_ETHEREUM | MATCHY_EXTRACT_MONERO;
+        std::string err;
+        if (!parse_extractors(extractors, auto_mask, mask, err)) { fprintf(stderr, "Error: %s\n", err.c_str()); matchy_close(db); return 1; }
+    }
+    matchy_scanner_t* sc = matchy_scanner_create(db, mask, device);
+    if (!sc) { fprintf(stderr, "Error: Failed to create the GPU scanner: %s\n", matchy_amd_last_error()); matchy_close(db); return 1; }
+    Totals t;
+    size_t processed = 0, failed = 0;
+    bool stdin_seen = false;
+    for (size_t i = 1; i < pos.size(); ++i) {
+        if (pos[i] == "-") {
+            if (stdin_seen) { if (stats) fprintf(stderr, "[WARN] Skipping duplicate stdin argument\n"); continue; }
+            stdin_seen = true;
+        }
+        if (process_input(sc, pos[i], batch_bytes, format == "json", t)) ++processed; else ++failed;
+    }
+    fflush(stdout);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) {
+        fprintf(stderr, "\n[INFO] === Processing Complete ===\n");
+        if (pos.size() > 2) {
+            fprintf(stderr, "[INFO] Files processed: %zu\n", processed);
+            if (failed) fprintf(stderr, "[INFO] Files failed: %zu\n", failed);
+        }
+        fprintf(stderr, "[INFO] Lines processed: %s\n", fmt_num(t.lines).c_str());
+        fprintf(stderr, "[INFO] Lines with matches: %s (%.1f%%)\n", fmt_num(t.lines_with_matches).c_str(),
+                t.lines ? 100.0 * (double)t.lines_with_matches / (double)t.lines : 0.0);
+        fprintf(stderr, "[INFO] Total matches: %s\n", fmt_num(t.matches).c_str());
+        fprintf(stderr, "[INFO] Candidates tested: %s\n", fmt_num(t.candidates).c_str());
+        fprintf(stderr, "[INFO] Throughput: %.2f MB/s\n", secs > 0 ? (double)t.bytes / 1e6 / secs : 0.0);
+        fprintf(stderr, "[INFO] Total time: %.2fs\n", secs);
+        fprintf(stderr, "[INFO] Query rate: %.0f queries/s\n", secs > 0 ? (double)t.candidates / secs : 0.0);
+        fprintf(stderr, "\n[INFO] === Device ===\n[INFO] HIP device: %d (one scanner, batches of %zu MiB)\n", device, batch_bytes >> 20);
+    }
+    matchy_scanner_free(sc);
+    matchy_close(db);
+    if (failed) { fprintf(stderr, "Error: %zu file(s) failed to process\n", failed); return 1; }
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) return usage();
+    std::string cmd = argv[1];
+    if (cmd == "build") return cmd_build(argc - 2, argv + 2);
+    if (cmd == "match") return cmd_match(argc - 2, argv + 2);
+    if (cmd == "--version" || cmd == "-V" || cmd == "version") { printf("matchy %s (MI355X build)\n", matchy_version()); return 0; }
+    return usage();
+}

@@ -1,0 +1,132 @@
+"""`matchy` command line (matchy_amd/bin/matchy): `build` runs on the host only; `match` needs the GPU (-m gpu).
+Mirrors the reference's CLI tests (crates/matchy/tests/cli_tests.rs:407-439, 690-1009): behaviour, not bytes of the
+reference's files."""
+import json
+import os
+import stat
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+CLI = ROOT / "matchy_amd" / "bin" / "matchy"
+
+
+@pytest.fixture(scope="module")
+def cli():
+    import matchy_amd.build as B
+    B.build()
+    assert CLI.exists()
+    return str(CLI)
+
+
+def _run(args, **kw):
+    return subprocess.run(args, capture_output=True, timeout=600, **kw)
+
+
+def _c1_csv(path):
+    from tools import synth
+    cfg = synth.config("c1")
+    rows = list(synth.ioc_entries(cfg))
+    with open(path, "w") as f:
+        f.write("entry,threat_level,category,source\n")
+        for k, d in rows:
+            d = json.loads(d)
+            f.write(f"{k.decode()},{d['threat_level']},{d['category']},{d['source']}\n")
+    return cfg, rows
+
+
+def test_build_csv_matches_library_builder(cli, tmp_path):
+    import matchy_amd as M
+    cfg, rows = _c1_csv(tmp_path / "c1.csv")
+    out = tmp_path / "c1.mxy"
+    r = _run([cli, "build", str(tmp_path / "c1.csv"), "-o", str(out), "-f", "csv"], env=dict(os.environ, MATCHY_BUILD_EPOCH="7"))
+    assert r.returncode == 0, r.stderr
+    assert f"Database built: {out}" in r.stdout.decode()
+    assert stat.S_IMODE(out.stat().st_mode) == 0o444  # build_cmd.rs:364-371
+    b = M.DatabaseBuilder(build_epoch=7)
+    for k, d in rows:
+        b.add_entry(k.decode(), json.loads(d))
+    assert out.read_bytes() == b.build()
+    # rebuilding over the read-only file works
+    r = _run([cli, "build", str(tmp_path / "c1.csv"), "-o", str(out), "-f", "csv"])
+    assert r.returncode == 0, r.stderr
+
+
+def test_build_csv_value_typing(cli, tmp_path, oracle):
+    # build_cmd.rs:226-236: i64 -> Int32 (truncating), u64 -> Uint64, f64 -> Double, true/false -> Bool, empty dropped
+    (tmp_path / "t.csv").write_text('key,n,big,huge,f,flag,s,empty,q\n1.2.3.4,42,4294967298,18446744073709551615,1.5,true,hello,,"a,b ""c"""\n')
+    out = tmp_path / "t.mxy"
+    assert _run([cli, "build", str(tmp_path / "t.csv"), "-o", str(out), "-f", "csv"]).returncode == 0
+    db = oracle.Database(out.read_bytes())
+    got = db.lookup("1.2.3.4")
+    assert got["kind"] == "ip"
+    assert got["data"] == {"n": 42, "big": 2, "huge": 18446744073709551615, "f": 1.5, "flag": True, "s": "hello", "q": 'a,b "c"'}
+
+
+def test_build_text_and_json(cli, tmp_path, oracle):
+    (tmp_path / "t.txt").write_text("# comment\n10.0.0.0/8\n\n  *.evil.com  \nexact.example.org\n")
+    out = tmp_path / "t.mxy"
+    assert _run([cli, "build", str(tmp_path / "t.txt"), "-o", str(out)]).returncode == 0
+    db = oracle.Database(out.read_bytes())
+    assert db.lookup("10.9.8.7")["kind"] == "ip"
+    assert db.lookup("x.evil.com")["kind"] == "pattern"
+    assert db.lookup("exact.example.org")["kind"] == "pattern"
+    assert db.lookup("nope.example.org")["kind"] == "notfound"
+    (tmp_path / "j.json").write_text(json.dumps([{"key": "8.8.8.8", "data": {"who": "dns", "n": 5}}, {"key": "*.bad.net"}]))
+    out2 = tmp_path / "j.mxy"
+    assert _run([cli, "build", str(tmp_path / "j.json"), "-o", str(out2), "-f", "json"]).returncode == 0
+    db2 = oracle.Database(out2.read_bytes())
+    assert db2.lookup("8.8.8.8")["data"] == {"who": "dns", "n": 5}
+    assert db2.lookup("a.bad.net")["kind"] == "pattern"
+
+
+def test_build_errors(cli, tmp_path):
+    (tmp_path / "bad.csv").write_text("a,b\n1,2\n")
+    r = _run([cli, "build", str(tmp_path / "bad.csv"), "-o", str(tmp_path / "x.mxy"), "-f", "csv"])
+    assert r.returncode != 0 and b"'entry' or 'key' column" in r.stderr
+    r = _run([cli, "build", str(tmp_path / "missing.txt"), "-o", str(tmp_path / "x.mxy")])
+    assert r.returncode != 0
+    r = _run([cli, "build", str(tmp_path / "bad.csv"), "-o", str(tmp_path / "x.mxy"), "-i"])
+    assert r.returncode != 0 and b"case-insensitive" in r.stderr
+    assert _run([cli]).returncode == 2
+    assert _run([cli, "build", str(tmp_path / "bad.csv")]).returncode == 2  # no -o
+
+
+@pytest.mark.gpu
+def test_match_config1_end_to_end(cli, tmp_path, oracle):
+    """BASELINE configs[0]: 1K-indicator CSV -> .mxy, 10K-line access.log via `matchy match` (here: on the GPU)."""
+    from tools import synth
+    cfg, rows = _c1_csv(tmp_path / "c1.csv")
+    dbp = tmp_path / "c1.mxy"
+    assert _run([cli, "build", str(tmp_path / "c1.csv"), "-o", str(dbp), "-f", "csv"]).returncode == 0
+    log = synth.make_log(cfg, 0, 10000)
+    logp = tmp_path / "access.log"
+    logp.write_bytes(log)
+    want_hits, want_lines, st = oracle.Database(dbp.read_bytes()).scan(log, source=str(logp))
+    r = _run([cli, "match", str(dbp), str(logp), "-s"])
+    assert r.returncode == 0, r.stderr
+    got = r.stdout.decode().splitlines()
+    assert got == want_lines and len(got) > 50
+    for line in got[:20]:
+        obj = json.loads(line)
+        assert list(obj) == sorted(obj) and obj["timestamp"] == "0.000" and obj["source"] == str(logp)
+    err = r.stderr.decode()
+    assert "[INFO] Lines processed: 10,000" in err and f"[INFO] Total matches: {len(got):,}" in err
+    assert f"[INFO] Candidates tested: {st.candidates:,}" in err and "[INFO] Throughput:" in err
+    # small batches (newline-aligned cuts + carry), stdin, CSV database built in memory: same match set
+    r2 = _run([cli, "match", str(dbp), str(logp), "--batch-bytes", "65536"])
+    assert r2.returncode == 0 and r2.stdout.decode().splitlines() == want_lines
+    r3 = _run([cli, "match", str(tmp_path / "c1.csv"), "-", "--batch-bytes=100000"], input=log)
+    assert r3.returncode == 0
+    assert [json.loads(l) | {"source": ""} for l in r3.stdout.decode().splitlines()] == [json.loads(l) | {"source": ""} for l in want_lines]
+    # summary: statistics only; extractor selection; a missing input fails the run but the others are processed
+    r4 = _run([cli, "match", str(dbp), str(logp), "--format", "summary", "-s"])
+    assert r4.returncode == 0 and r4.stdout == b"" and b"Total matches" in r4.stderr
+    r5 = _run([cli, "match", str(dbp), str(logp), "--extractors=ip"])
+    ips = [json.loads(l) for l in r5.stdout.decode().splitlines()]
+    assert ips and all(o["match_type"] == "ip" for o in ips)
+    assert len(ips) == sum(1 for l in want_lines if json.loads(l)["match_type"] == "ip")
+    r6 = _run([cli, "match", str(dbp), str(tmp_path / "nope.log"), str(logp)])
+    assert r6.returncode != 0 and r6.stdout.decode().splitlines() == want_lines
