@@ -10,7 +10,7 @@ LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libmatchy_amd.so"
 BINDIR = PKG / "bin"
 CLI = BINDIR / "matchy"
-SOURCES = ["k_anchor.hip", "scan_kernels.hip", "engine.cpp", "db_image.cpp", "db_builder.cpp", "data_codec.cpp", "capi.cpp"]
+SOURCES = ["k_anchor.hip", "scan_kernels.hip", "sort_hits.hip", "engine.cpp", "db_image.cpp", "db_builder.cpp", "data_codec.cpp", "capi.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

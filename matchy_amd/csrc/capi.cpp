@@ -160,12 +160,7 @@ void fill_result(const FinalHit* fin, size_t n_fin, const uint32_t* ids, const l
     if (n_fin) memcpy(in->hits.data(), fin, n_fin * sizeof(FinalHit));
     in->ids.assign(ids, ids + n_ids);
     in->offs.assign(offs, offs + n_ids);
-    if (sorted) std::sort(in->hits.begin(), in->hits.end(), [](const matchy_scan_hit_t& a, const matchy_scan_hit_t& b) {
-        if (a.start != b.start) return a.start < b.start;
-        int ra = type_rank(a.item_type), rb = type_rank(b.item_type);
-        if (ra != rb) return ra < rb;
-        return a.end < b.end;
-    });
+    (void)sorted;  // canonical order is produced on the GPU (sort_hits.hip); the copy keeps it
     out->hits = in->hits.data();
     out->pattern_ids = in->ids.data(); out->data_offsets = in->offs.data();
     out->_internal = in;
@@ -459,8 +454,8 @@ int32_t matchy_scanner_scan_device(matchy_scanner_t* s, const void* dptr, size_t
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st);
         ScanOutput so;
-        h->sc->fetch(so, false, st, (fetch_mode & 1) ? HITS_FINAL : HITS_NONE);
         const bool sorted = (fetch_mode & 2) != 0;
+        h->sc->fetch(so, false, st, (fetch_mode & 1) ? HITS_FINAL : HITS_NONE, sorted);
         fill_result(so.fin, so.n_fin, so.fin_ids, so.fin_offs, so.n_fin_ids, so.lines, so.n_cand, len, !sorted, sorted, out);
         if (!(fetch_mode & 1)) out->n_hits = so.n_hits;  // count only; `hits` stays NULL
         return MATCHY_SUCCESS;

@@ -374,7 +374,11 @@ void Scanner::ensure_pinned(size_t bytes) {
     MXY_HIP(hipHostMalloc(&pinned_, pinned_bytes_, hipHostMallocDefault));
 }
 
-void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode) {
+size_t sort_hits_temp_bytes(uint32_t n);
+hipError_t sort_hits(const FinalHit* fin, uint32_t n, unsigned long long* keys, uint32_t* vals, void* temp, size_t temp_bytes, FinalHit* out,
+                     hipStream_t stream);
+
+void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode, bool sorted) {
     const bool trace = !single_ && getenv("MATCHY_AMD_TRACE");
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
@@ -433,7 +437,16 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         const size_t hb = (size_t)c.n_final * sizeof(FinalHit), ib = (((size_t)c.n_final_ids * 4) + 7) & ~(size_t)7, ob = (size_t)c.n_final_ids * 8;
         ensure_pinned(hb + ib + ob);
         uint8_t* base = (uint8_t*)pinned_;
-        MXY_HIP(hipMemcpyAsync(base, final_.p, hb, hipMemcpyDeviceToHost, stream));
+        const FinalHit* src = final_.p;
+        if (sorted) {
+            const uint32_t n = c.n_final;
+            if (sort_keys_.n < 2 * (size_t)n) { sort_keys_.alloc(2 * (size_t)n + 2048); sort_vals_.alloc(2 * (size_t)n + 2048); final_sorted_.alloc((size_t)n + 1024); }
+            const size_t tb = sort_hits_temp_bytes(n);
+            if (sort_tmp_.n < tb) sort_tmp_.alloc(tb + tb / 4 + 4096);
+            MXY_HIP(sort_hits(final_.p, n, sort_keys_.p, sort_vals_.p, sort_tmp_.p, tb, final_sorted_.p, stream));
+            src = final_sorted_.p;
+        }
+        MXY_HIP(hipMemcpyAsync(base, src, hb, hipMemcpyDeviceToHost, stream));
         if (c.n_final_ids) {
             MXY_HIP(hipMemcpyAsync(base + hb, final_ids_.p, (size_t)c.n_final_ids * 4, hipMemcpyDeviceToHost, stream));
             MXY_HIP(hipMemcpyAsync(base + hb + ib, final_offs_.p, ob, hipMemcpyDeviceToHost, stream));
@@ -506,7 +519,7 @@ void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_
         if (n) MXY_HIP(hipMemcpy(staging_.p, data + pos, n, hipMemcpyHostToDevice));
         scan_device(staging_.p, (uint32_t)n, lookup, nullptr);
         ScanOutput part;
-        fetch(part, want_cands, nullptr, lookup && fin ? HITS_FINAL : HITS_NONE);
+        fetch(part, want_cands, nullptr, lookup && fin ? HITS_FINAL : HITS_NONE, true);
         out.lines += part.lines; out.n_cand += part.n_cand; out.n_hits += part.n_hits;
         for (int t = 0; t < IT_COUNT; ++t) out.by_type[t] += part.by_type[t];
         if (fin && part.n_fin) {

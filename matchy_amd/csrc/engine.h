@@ -102,7 +102,8 @@ public:
     // lookup=false stops after extraction. Results stay on the device until fetch().
     void scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream);
     // Copies counters (and hits / candidates) back. Call after scan_device; synchronises the stream.
-    void fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode = HITS_FINAL);
+    // sorted: the final records are put into canonical order on the GPU (sort_hits.hip) before they are copied back
+    void fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode = HITS_FINAL, bool sorted = false);
     // One synthetic candidate (single-query API): `text` is uploaded, only the lookup kernel runs.
     void lookup_one(const std::string& text, Candidate c, ScanOutput& out);
     // Convenience: host buffer -> internal device buffer -> scan -> fetch (chunks of < 2^31 bytes).
@@ -128,6 +129,10 @@ private:
     DevBuf<uint32_t> dom_list_;
     DevBuf<Hit> hits_;
     DevBuf<uint32_t> ids_, glob_work_;
+    DevBuf<unsigned long long> sort_keys_;
+    DevBuf<uint32_t> sort_vals_;
+    DevBuf<uint8_t> sort_tmp_;
+    DevBuf<FinalHit> final_sorted_;
     DevBuf<ScanCounters> counters_;
     DevBuf<uint8_t> staging_;  // scan_host only
     void* pinned_ = nullptr;   // one pinned block: FinalHit[n] | u32 ids[m] | i64 offs[m]  (or Hit[n] for HITS_RAW)
