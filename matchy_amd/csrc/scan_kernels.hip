@@ -340,83 +340,116 @@ __device__ bool val_email(const LogView& lg, const DevDb& db, uint32_t at, uint3
     return true;
 }
 
-// ---- SHA-256 (one 64-byte block at a time), Keccak-f[1600], base58, bech32 — rare path, scratch arrays are fine.
-__device__ __noinline__ void d_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
-    const uint32_t K[64] = {
-        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
-        0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
-        0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
-        0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
-        0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
-        0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-    uint32_t total = ((len + 9 + 63) / 64) * 64;
-    auto byte_at = [&](uint32_t i) -> uint32_t {
-        if (i < len) return data[i];
-        if (i == len) return 0x80;
-        if (i >= total - 8) { uint64_t bits = (uint64_t)len * 8; return (uint32_t)(bits >> (8 * (total - 1 - i))) & 0xFF; }
-        return 0;
-    };
-    auto rotr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
-    for (uint32_t off = 0; off < total; off += 64) {
-        uint32_t w[64];
-        for (int i = 0; i < 16; ++i)
-            w[i] = (byte_at(off + 4 * i) << 24) | (byte_at(off + 4 * i + 1) << 16) | (byte_at(off + 4 * i + 2) << 8) | byte_at(off + 4 * i + 3);
-        for (int i = 16; i < 64; ++i) {
-            uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
-            uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
-            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
-        }
+// ---- SHA-256, Keccak-f[1600], base58, bech32 for the checksum validators of k_rare. All state lives in registers
+// (fully unrolled rounds, static indices); byte strings (the token and the decoded address) live in a per-lane LDS
+// scratch, so nothing goes to scratch memory.
+struct Sha256 {
+    uint32_t h[8];
+    __device__ __forceinline__ void init() {
+        h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a; h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+    }
+    __device__ __forceinline__ static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    // one 64-byte block given as 16 big-endian words
+    __device__ void block(uint32_t (&w)[16]) {
+        constexpr uint32_t K[64] = {
+            0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+            0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+            0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+            0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+            0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+            0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
         uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
         for (int i = 0; i < 64; ++i) {
-            uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
-            uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            if (i >= 16) {  // rolling 16-word message schedule
+                const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+                const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3), s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+                w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+            }
+            const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i & 15];
+            const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
             hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
         }
         h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
     }
-    for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
-}
+    // hash of data[0, len) (len < 120: at most two blocks); data may be in LDS
+    __device__ void hash(const uint8_t* data, uint32_t len) {
+        init();
+        const uint32_t total = ((len + 9 + 63) / 64) * 64;
+        for (uint32_t off = 0; off < total; off += 64) {
+            uint32_t w[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const uint32_t q = off + 4 * i + bb;
+                    uint32_t v = 0;
+                    if (q < len) v = data[q];
+                    else if (q == len) v = 0x80;
+                    else if (q >= total - 4) v = ((len * 8) >> (8 * (total - 1 - q))) & 0xFF;
+                    x = (x << 8) | v;
+                }
+                w[i] = x;
+            }
+            block(w);
+        }
+    }
+};
 
-__device__ __noinline__ void d_keccak_f(uint64_t st[25]) {
-    const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
-                             0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
-                             0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
-                             0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-                             0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-    const int ROTC[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
-    const int PILN[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+// Keccak-256 with the original 0x01 padding (tiny-keccak Keccak::v256), input <= 135 bytes (one block); out = the first
+// 4 bytes of the digest for the Monero check, or all 32 for EIP-55.
+__device__ void d_keccak256_1blk(const uint8_t* data, uint32_t len, uint64_t (&out)[4]) {
+    constexpr uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+                                 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+                                 0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+                                 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+                                 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    constexpr int ROTC[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+    constexpr int PILN[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    uint64_t st[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) st[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {  // rate = 136 bytes = 17 lanes
+        uint64_t x = 0;
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const uint32_t q = 8 * i + bb;
+            uint32_t v = q < len ? data[q] : 0;
+            if (q == len) v ^= 0x01;
+            if (q == 135) v ^= 0x80;
+            x |= (uint64_t)v << (8 * bb);
+        }
+        st[i] = x;
+    }
+#pragma unroll 1
     for (int round = 0; round < 24; ++round) {
         uint64_t bc[5];
+#pragma unroll
         for (int i = 0; i < 5; ++i) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
+#pragma unroll
         for (int i = 0; i < 5; ++i) {
-            uint64_t t = bc[(i + 4) % 5] ^ rotl64(bc[(i + 1) % 5], 1);
+            const uint64_t t = bc[(i + 4) % 5] ^ rotl64(bc[(i + 1) % 5], 1);
+#pragma unroll
             for (int j = 0; j < 25; j += 5) st[j + i] ^= t;
         }
         uint64_t t = st[1];
-        for (int i = 0; i < 24; ++i) { int j = PILN[i]; uint64_t b = st[j]; st[j] = rotl64(t, ROTC[i]); t = b; }
+#pragma unroll
+        for (int i = 0; i < 24; ++i) { const int j = PILN[i]; const uint64_t b = st[j]; st[j] = rotl64(t, ROTC[i]); t = b; }
+#pragma unroll
         for (int j = 0; j < 25; j += 5) {
+#pragma unroll
             for (int i = 0; i < 5; ++i) bc[i] = st[j + i];
+#pragma unroll
             for (int i = 0; i < 5; ++i) st[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
         }
         st[0] ^= RC[round];
     }
-}
-// Keccak-256 with the original 0x01 padding (tiny-keccak Keccak::v256), input <= 135 bytes (one block)
-__device__ void d_keccak256_1blk(const uint8_t* data, uint32_t len, uint8_t out[32]) {
-    uint64_t st[25];
-    for (int i = 0; i < 25; ++i) st[i] = 0;
-    for (uint32_t i = 0; i < 136; ++i) {
-        uint32_t b = i < len ? data[i] : 0;
-        if (i == len) b ^= 0x01;
-        if (i == 135) b ^= 0x80;
-        st[i / 8] ^= (uint64_t)b << (8 * (i % 8));
-    }
-    d_keccak_f(st);
-    for (int i = 0; i < 4; ++i) for (int b = 0; b < 8; ++b) out[8 * i + b] = (uint8_t)(st[i] >> (8 * b));
+    out[0] = st[0]; out[1] = st[1]; out[2] = st[2]; out[3] = st[3];
 }
 
-__device__ int d_b58_val(uint32_t c) {
+__device__ __forceinline__ int d_b58_val(uint32_t c) {
     // "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz"
     if (c >= '1' && c <= '9') return (int)c - '1';
     if (c >= 'A' && c <= 'H') return (int)c - 'A' + 9;
@@ -426,39 +459,67 @@ __device__ int d_b58_val(uint32_t c) {
     if (c >= 'm' && c <= 'z') return (int)c - 'm' + 44;
     return -1;
 }
-// bs58::decode(..).into_vec(): out is big-endian, length returned (0 on invalid character); n <= 110 -> <= 96 bytes
-__device__ __noinline__ uint32_t d_base58_decode(const uint8_t* s, uint32_t n, uint8_t out[112]) {
-    uint8_t num[96];
-    uint32_t nlen = 0, zeros = 0;
+// bs58::decode(..).into_vec() into `dec` (big-endian), length returned, 0 on an invalid character. The number is kept
+// in NL 32-bit limbs in registers (58^62 < 2^384: 12 limbs for Bitcoin; 58^110 < 2^672: 21 limbs for Monero).
+template <int NL>
+__device__ uint32_t d_base58_decode(const uint8_t* s, uint32_t n, uint8_t* dec) {
+    uint32_t L[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) L[i] = 0;
+    uint32_t zeros = 0;
     bool leading = true;
-    for (uint32_t i = 0; i < n; ++i) {
-        int v = d_b58_val(s[i]);
+    for (uint32_t k = 0; k < n; ++k) {
+        const int v = d_b58_val(s[k]);
         if (v < 0) return 0;
         if (leading && v == 0) { ++zeros; continue; }
         leading = false;
         uint32_t carry = (uint32_t)v;
-        for (uint32_t k = 0; k < nlen; ++k) { carry += (uint32_t)num[k] * 58u; num[k] = (uint8_t)carry; carry >>= 8; }
-        while (carry && nlen < 96) { num[nlen++] = (uint8_t)carry; carry >>= 8; }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const uint64_t t = (uint64_t)L[i] * 58u + carry;
+            L[i] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
     }
-    uint32_t o = 0;
-    for (uint32_t k = 0; k < zeros; ++k) out[o++] = 0;
-    for (uint32_t k = nlen; k-- > 0;) out[o++] = num[k];
-    return o;
+    // significant bytes of the number
+    uint32_t nbytes = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) if (L[i]) nbytes = 4 * i + 1 + ((31u - (uint32_t)__clz((int)L[i])) >> 3);
+    for (uint32_t k = 0; k < zeros; ++k) dec[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const uint32_t j = 4 * i + bb;  // little-endian byte index
+            if (j < nbytes) dec[zeros + nbytes - 1 - j] = (uint8_t)(L[i] >> (8 * bb));
+        }
+    }
+    return zeros + nbytes;
 }
-__device__ bool val_btc_base58(const uint8_t* s, uint32_t n) {  // ext:1799-1822
-    uint8_t dec[112], h1[32], h2[32];
-    uint32_t dl = d_base58_decode(s, n, dec);
+__device__ bool val_btc_base58(const uint8_t* s, uint32_t n, uint8_t* dec) {  // ext:1799-1822
+    const uint32_t dl = d_base58_decode<12>(s, n, dec);
     if (dl < 5) return false;
-    d_sha256(dec, dl - 4, h1);
-    d_sha256(h1, 32, h2);
-    return h2[0] == dec[dl - 4] && h2[1] == dec[dl - 3] && h2[2] == dec[dl - 2] && h2[3] == dec[dl - 1];
+    Sha256 h1, h2;
+    h1.hash(dec, dl - 4);
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = h1.h[i];
+    w[8] = 0x80000000u;
+#pragma unroll
+    for (int i = 9; i < 15; ++i) w[i] = 0;
+    w[15] = 256;
+    h2.init();
+    h2.block(w);
+    const uint32_t chk = ((uint32_t)dec[dl - 4] << 24) | ((uint32_t)dec[dl - 3] << 16) | ((uint32_t)dec[dl - 2] << 8) | dec[dl - 1];
+    return h2.h[0] == chk;
 }
-__device__ bool val_monero(const uint8_t* s, uint32_t n) {  // ext:1895-1920
-    uint8_t dec[112], h[32];
-    uint32_t dl = d_base58_decode(s, n, dec);
+__device__ bool val_monero(const uint8_t* s, uint32_t n, uint8_t* dec) {  // ext:1895-1920
+    const uint32_t dl = d_base58_decode<21>(s, n, dec);
     if (dl < 5) return false;
+    uint64_t h[4];
     d_keccak256_1blk(dec, dl - 4, h);  // dl <= 81
-    return h[0] == dec[dl - 4] && h[1] == dec[dl - 3] && h[2] == dec[dl - 2] && h[3] == dec[dl - 1];
+    const uint32_t chk = (uint32_t)dec[dl - 4] | ((uint32_t)dec[dl - 3] << 8) | ((uint32_t)dec[dl - 2] << 16) | ((uint32_t)dec[dl - 1] << 24);
+    return (uint32_t)h[0] == chk;
 }
 __device__ int d_bech32_val(uint32_t c) {
     const char* CS = "qpzry9x8gf2tvdw0s3jn54khce6mua7l";
@@ -486,9 +547,8 @@ __device__ bool val_btc_bech32(const uint8_t* s, uint32_t n) {
     }
     return chk == 1 || chk == 0x2bc830a3u;
 }
-__device__ bool val_eth(const uint8_t* a) {  // ext:1328-1361, 1840-1892: "0x" + 40 hex, EIP-55 when mixed case
+__device__ bool val_eth(const uint8_t* a, uint8_t* lower) {  // ext:1328-1361, 1840-1892: "0x" + 40 hex, EIP-55 when mixed case
     bool all_lower = true, all_upper = true;
-    uint8_t lower[40], hash[32];
     for (int i = 0; i < 40; ++i) {
         uint32_t c = a[2 + i];
         if (!d_is_hex(c)) return false;
@@ -496,11 +556,13 @@ __device__ bool val_eth(const uint8_t* a) {  // ext:1328-1361, 1840-1892: "0x" +
         lower[i] = (uint8_t)d_lower(c);
     }
     if (all_lower || all_upper) return true;
-    d_keccak256_1blk(lower, 40, hash);
+    uint64_t h[4];
+    d_keccak256_1blk(lower, 40, h);
     for (int i = 0; i < 40; ++i) {
         uint32_t c = a[2 + i];
         if (d_is_alpha(c)) {
-            uint32_t nib = (i & 1) ? (hash[i / 2] & 0x0f) : (hash[i / 2] >> 4);
+            const uint32_t byte = (uint32_t)(h[i >> 4] >> (8 * ((i >> 1) & 7))) & 0xFF;
+            const uint32_t nib = (i & 1) ? (byte & 0x0f) : (byte >> 4);
             if ((c < 'a') != (nib >= 8)) return false;
         }
     }
@@ -640,10 +702,15 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
 // k_rare — stage A3: checksum validators (Base58Check, Bech32, EIP-55, Monero): very rare in logs and heavy in
 // registers, one lane per entry of the `heavy` list written by k_validate.
 __global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
+    // per lane: the token (<= 110 bytes, copied with wide loads) and the decoded address / lower-cased hex
+    __shared__ __attribute__((aligned(16))) uint8_t tokbuf[64][112];
+    __shared__ __attribute__((aligned(16))) uint8_t decbuf[64][96];
     LogView lg{p.log, p.len};
     ChunkWriter<Candidate, CAND_CHUNK> cw;
     const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
     const uint32_t n = min(p.counters->n_heavy, p.heavy_cap);
+    uint8_t* tb = tokbuf[threadIdx.x];
+    uint8_t* dec = decbuf[threadIdx.x];
     for (uint32_t base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
         const uint32_t i = base + threadIdx.x;
         RareAnchor ra{0, 0xFF};
@@ -651,13 +718,22 @@ __global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
         const uint32_t kind = ra.len_kind & 0xFF, tl = ra.len_kind >> 8;
         bool em = false;
         Candidate ct{0, 0, 0, 0};
-        if (kind != 0xFF) {
-            const uint8_t* s = lg.p + ra.pos;
+        if (kind != 0xFF && tl <= 110) {
+            // token bytes -> LDS: 16 bytes per load while they are inside the buffer, bytes at its very end
+            for (uint32_t k = 0; k < tl; k += 16) {
+                if (ra.pos + k + 16 <= lg.len) {
+                    uint4 v;
+                    __builtin_memcpy(&v, lg.p + ra.pos + k, 16);
+                    *reinterpret_cast<uint4*>(tb + k) = v;
+                } else {
+                    for (uint32_t b = k; b < tl; ++b) tb[b] = lg.p[ra.pos + b];
+                }
+            }
             int ty = -1;
-            if (kind == HEAVY_BECH32) { if (val_btc_bech32(s, tl)) ty = IT_BITCOIN; }
-            else if (kind == HEAVY_B58) { if (val_btc_base58(s, tl)) ty = IT_BITCOIN; }
-            else if (kind == HEAVY_ETH) { if (val_eth(s)) ty = IT_ETHEREUM; }
-            else if (kind == HEAVY_XMR) { if (val_monero(s, tl)) ty = IT_MONERO; }
+            if (kind == HEAVY_BECH32) { if (val_btc_bech32(tb, tl)) ty = IT_BITCOIN; }
+            else if (kind == HEAVY_B58) { if (val_btc_base58(tb, tl, dec)) ty = IT_BITCOIN; }
+            else if (kind == HEAVY_ETH) { if (val_eth(tb, dec)) ty = IT_ETHEREUM; }
+            else if (kind == HEAVY_XMR) { if (val_monero(tb, tl, dec)) ty = IT_MONERO; }
             if (ty >= 0) { ct.start = ra.pos; ct.len_type = tl | ((uint32_t)ty << 24); em = true; }
         }
         cw.append(em, ct, p.cands, p.cand_cap, &p.counters->n_cand, SC);
