@@ -87,6 +87,38 @@ struct ChunkWriter {
     }
 };
 
+// Chunked writer for the plane-organised domain anchor list (TokParams::dom_list): slots are reserved like in
+// ChunkWriter (one atomic per ANCHOR_CHUNK slots), the caller stores the planes of its slot.
+struct DomWriter {
+    uint32_t base = 0xFFFFFFFFu, used = 0;
+    __device__ __forceinline__ void pad_rest(uint32_t* out, uint32_t cap) {
+        if (base == 0xFFFFFFFFu) return;
+        for (uint32_t k = used + lane_id(); k < ANCHOR_CHUNK; k += 64)
+            if (base + k < cap) out[dom_plane_index(base + k, 0)] = 0xFFFFFFFFu;
+        used = ANCHOR_CHUNK;
+    }
+    // all lanes of the converged wave call this; returns the lane's slot, or 0xFFFFFFFF (not emitting / list full)
+    __device__ __forceinline__ uint32_t reserve(bool emit, uint32_t* out, uint32_t cap, uint32_t* counter) {
+        const uint64_t m = __ballot(emit);
+        if (m == 0) return 0xFFFFFFFFu;
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (base == 0xFFFFFFFFu || used + n > ANCHOR_CHUNK) {
+            pad_rest(out, cap);
+            uint32_t b = 0;
+            if (lane_id() == 0) b = atomicAdd(counter, ANCHOR_CHUNK);
+            base = __builtin_amdgcn_readfirstlane(b);
+            used = 0;
+        }
+        uint32_t slot = 0xFFFFFFFFu;
+        if (emit) {
+            slot = base + used + (uint32_t)__popcll(m & lanemask_lt());
+            if (slot >= cap) slot = 0xFFFFFFFFu;
+        }
+        used += n;
+        return slot;
+    }
+};
+
 struct LogView {
     const uint8_t* p;
     uint32_t len;

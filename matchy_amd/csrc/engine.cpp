@@ -313,8 +313,9 @@ void Scanner::ensure_capacity(uint32_t len) {
     if (heavy_.n < want_r) heavy_.alloc(want_r);
     if (final_.n < hits_.n) { final_.alloc(hits_.n); }
     if (final_ids_.n < hits_.n + ids_.n) { final_ids_.alloc(hits_.n + ids_.n); final_offs_.alloc(hits_.n + ids_.n); }
-    size_t want_a = std::max<size_t>(4096, (size_t)len / 32);
-    if (dom_list_.n < want_a) dom_list_.alloc(want_a);
+    // domain anchor list: slots of DOM_PLANES dwords, whole 1024-slot chunks (see TokParams::dom_list)
+    const size_t want_d = ((std::max<size_t>(8192, (size_t)len / 96) + ANCHOR_CHUNK - 1) / ANCHOR_CHUNK) * ANCHOR_CHUNK;
+    if (dom_slots_ < want_d) { dom_list_.alloc(want_d * DOM_PLANES); dom_slots_ = want_d; }
 }
 
 void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream) {
@@ -333,7 +334,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.rare = rare_.p; tp.rare_cap = (uint32_t)rare_.n;
     tp.tok = tok_.p; tp.tok_cap = (uint32_t)tok_.n;
     tp.heavy = heavy_.p; tp.heavy_cap = (uint32_t)heavy_.n;
-    tp.dom_list = dom_list_.p; tp.dom_cap = (uint32_t)dom_list_.n;
+    tp.dom_list = dom_list_.p; tp.dom_cap = (uint32_t)dom_slots_;
     tp.counters = counters_.p;
     int grid_tok = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * 8);
     if (grid_tok < 1) grid_tok = 1;
@@ -386,7 +387,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
         MXY_HIP(hipStreamSynchronize(stream));
         const ScanCounters& c = host_counters_;
-        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_dom > dom_list_.n;
+        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_dom > dom_slots_;
         if (!over) break;
         if (trace) fprintf(stderr, "[matchy_amd] work buffers overflow (attempt %d): regrow and rescan\n", attempt);
         if (single_) throw HipError{"lookup_one: work buffers overflow"};
@@ -396,7 +397,10 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         if (c.n_tok > tok_.n) tok_.alloc((size_t)c.n_tok + c.n_tok / 4 + 1024);
         if (c.n_heavy > heavy_.n) heavy_.alloc((size_t)c.n_heavy + c.n_heavy / 4 + 1024);
         if (glob_work_.n && c.n_glob_work > glob_work_.n) glob_work_.alloc((size_t)c.n_glob_work + c.n_glob_work / 4 + 1024);
-        if (c.n_dom > dom_list_.n) dom_list_.alloc((size_t)c.n_dom + c.n_dom / 4 + 1024);
+        if (c.n_dom > dom_slots_) {
+            dom_slots_ = (((size_t)c.n_dom + c.n_dom / 4 + ANCHOR_CHUNK) / ANCHOR_CHUNK) * ANCHOR_CHUNK;
+            dom_list_.alloc(dom_slots_ * DOM_PLANES);
+        }
         if (c.n_hits > hits_.n || hits_.n < cands_.n / 4) hits_.alloc(std::max<size_t>((size_t)c.n_hits + c.n_hits / 4 + 1024, cands_.n / 4));
         if (c.n_ids > ids_.n) ids_.alloc((size_t)c.n_ids + c.n_ids / 4 + 1024);
         if (final_.n < hits_.n) final_.alloc(hits_.n);

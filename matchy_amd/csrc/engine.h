@@ -127,6 +127,7 @@ private:
     DevBuf<uint32_t> final_ids_;
     DevBuf<long long> final_offs_;
     DevBuf<uint32_t> dom_list_;
+    size_t dom_slots_ = 0;
     DevBuf<Hit> hits_;
     DevBuf<uint32_t> ids_, glob_work_;
     DevBuf<unsigned long long> sort_keys_;

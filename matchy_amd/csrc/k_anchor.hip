@@ -116,25 +116,27 @@ __device__ __forceinline__ void drain_v4(const uint32_t* ring, uint32_t& head, u
 // Mirrors the first steps of val_domain (scan_kernels.hip): a '.' inside the label means a later dot owns the run, the
 // run must end at a boundary, and the label must be the last label of some public suffix. Undecidable cases (label
 // longer than 8 bytes, bytes not resident) are kept.
-__device__ __forceinline__ void drain_dom(const uint32_t* ring, uint32_t& head, uint32_t n, const WaveCtx& cx,
-                                          ChunkWriter<uint32_t, ANCHOR_CHUNK>& cw) {
+__device__ __forceinline__ void drain_dom(const uint32_t* ring, uint32_t& head, uint32_t n, const WaveCtx& cx, DomWriter& dw) {
     const uint32_t lane = lane_id();
     const TokParams& p = *cx.p;
     __builtin_amdgcn_wave_barrier();
     uint32_t j = 0xFFFFFFFFu;
-    bool keep = false;
+    bool keep = false, have_ctx = false;
+    uint32_t ctx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ctx[k] = 0;
     if (lane < n) {
         j = ring[(head + lane) & (QCAP - 1)];
         keep = true;
-        if (j >= cx.res_lo && j + 8 <= cx.res_hi) {
-            uint32_t w[2];
-            raw_read<2>(cx.raw32, j, w);
+        if (j >= cx.res_lo + 24 && j + 8 <= cx.res_hi) {
+            raw_read<8>(cx.raw32, j - 24, ctx);   // log[j-24, j+8): the last label starts at byte 24
+            have_ctx = true;
             uint32_t th = 2166136261u, stop = 0;
             bool open = true;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (open) {
-                    const uint32_t c = ((k < 4 ? w[0] : w[1]) >> (8 * (k & 3))) & 0xFF;
+                    const uint32_t c = ((k < 4 ? ctx[6] : ctx[7]) >> (8 * (k & 3))) & 0xFF;
                     if (!d_is_domain_char_fast(c)) { open = false; stop = c; }
                     else if (c == '.') { open = false; keep = false; stop = ' '; }
                     else th = tld_hash_step(th, c);
@@ -146,7 +148,12 @@ __device__ __forceinline__ void drain_dom(const uint32_t* ring, uint32_t& head, 
             }
         }
     }
-    cw.append(keep, j, p.dom_list, p.dom_cap, &p.counters->n_dom, 0xFFFFFFFFu);
+    const uint32_t slot = dw.reserve(keep, p.dom_list, p.dom_cap, &p.counters->n_dom);
+    if (slot != 0xFFFFFFFFu) {
+        p.dom_list[dom_plane_index(slot, 0)] = have_ctx ? j : (j | 0x80000000u);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p.dom_list[dom_plane_index(slot, 1 + k)] = ctx[k];
+    }
     head += n;
     __builtin_amdgcn_wave_barrier();
 }
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0;   // ring heads / tails (wave-uniform)
     uint32_t v4_old = 0, dom_old = 0;            // block start of the oldest ring entry (valid while the ring is non-empty)
     ChunkWriter<Candidate, V4_CHUNK> cw_cand;
-    ChunkWriter<uint32_t, ANCHOR_CHUNK> cw_dom;
+    DomWriter cw_dom;
     ChunkWriter<uint2, RARE_CHUNK> cw_misc, cw_tok;  // rare anchors are sparse: small chunks keep the lists dense
     const uint2 S64 = make_uint2(0xFFFFFFFFu, 0xFFu);
     uint2* rare_out = reinterpret_cast<uint2*>(p.rare);
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     }
     commit_v4(pend, cx, cw_cand);
     // mark the unused tail of every open chunk
-    cw_dom.pad_rest(p.dom_list, p.dom_cap, 0xFFFFFFFFu);
+    cw_dom.pad_rest(p.dom_list, p.dom_cap);
     cw_cand.pad_rest(p.cands, p.cand_cap, Candidate{0, 0xFFFFFFFFu, 0, 0});
     cw_misc.pad_rest(rare_out, p.rare_cap, S64);
     cw_tok.pad_rest(tok_out, p.tok_cap, S64);

@@ -38,10 +38,6 @@ struct BackReader {
         p = base; pos = q; cb = 0; k = 0; cur = 0; nxt = 0;
         if (q >= 16) { cb = q - 8; k = 8; cur = load8(p + cb); nxt = load8(p + cb - 8); }
     }
-    // same with the two words already loaded by the caller: c0 = p[q-8, q), c1 = p[q-16, q-8); needs q >= 16
-    __device__ __forceinline__ void init_pre(const uint8_t* base, uint32_t q, uint64_t c0, uint64_t c1) {
-        p = base; pos = q; cb = q - 8; k = 8; cur = c0; nxt = c1;
-    }
     __device__ __forceinline__ uint32_t next() {
         --pos;
         if (pos < 16) return p[pos];  // the first bytes of the buffer: plain loads (no read before the buffer)
@@ -158,26 +154,44 @@ __device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* b
     return true;
 }
 
-// The same for an anchor whose surroundings were loaded ahead of time (k_validate software pipeline): w = log[j, j+8),
-// b0 = log[j-8, j), b1 = log[j-16, j-8). The common case — last label of <= 7 bytes that alone is a public suffix — is
-// decided from these registers plus further BackReader loads for names longer than 16 bytes; everything else takes
-// val_domain.
+// Byte-class masks of 8 log bytes at once (SWAR; bit 7 of each byte of the result is the class bit, all other bits 0).
+// Every addend keeps each byte below 0x100, so no carry crosses a byte.
+struct ByteMasks { uint64_t dc, dot, dash, high; };
+__device__ __forceinline__ ByteMasks domain_masks(uint64_t x) {
+    constexpr uint64_t H = 0x8080808080808080ull, L7 = 0x7F7F7F7F7F7F7F7Full;
+    const uint64_t t = x & L7, l = t | 0x2020202020202020ull;
+    const uint64_t dig = (t + 0x5050505050505050ull) & ~(t + 0x4646464646464646ull);   // '0'..'9'
+    const uint64_t alp = (l + 0x1F1F1F1F1F1F1F1Full) & ~(l + 0x0505050505050505ull);   // 'a'..'z' after case folding
+    const uint64_t ndot = (t ^ 0x2E2E2E2E2E2E2E2Eull) + L7, ndash = (t ^ 0x2D2D2D2D2D2D2D2Dull) + L7;  // bit 7 set iff different
+    ByteMasks m;
+    m.high = x & H;
+    m.dot = ~ndot & ~x & H;
+    m.dash = ~ndash & ~x & H;
+    m.dc = (((dig | alp) & ~x) | m.dot | m.dash | m.high) & H;  // DOMAIN_CHAR_LOOKUP (ext:1597-1629)
+    return m;
+}
+
+// The same for an anchor that comes with its context record (k_anchor copies log[j-24, j+8) from its LDS window):
+// w = log[j, j+8), b0 = log[j-8, j), b1 = log[j-16, j-8), b2 = log[j-24, j-16). The common case — last label of <= 7
+// bytes that alone is a public suffix, name no longer than the context — is decided with mask arithmetic on these
+// registers, without a per-byte loop and without divergent control flow (k_validate is bound by scalar-ALU issue, i.e.
+// by control flow): the rules of is_valid_domain (ext:637-689) become tests on the dot / dash / domain-char masks.
+// Everything else takes val_domain.
 __device__ __forceinline__ bool val_domain_pre(const LogView& lg, const DevDb& db, const uint32_t* bloom, const uint2* tldtab,
-                                               uint32_t min_labels, uint32_t j, uint2 w, uint64_t b0, uint64_t b1, uint32_t& start,
-                                               uint32_t& end) {
-    uint32_t ll = 8, stop_c = 0;
-    bool dot_inside = false;
-#pragma unroll
-    for (int k = 7; k >= 0; --k) {
-        const uint32_t c = ((k < 4 ? w.x : w.y) >> (8 * (k & 3))) & 0xFF;
-        if (!d_is_domain_char_fast(c)) { ll = k; stop_c = c; dot_inside = false; }
-        else if (c == '.') dot_inside = true;   // only dots before the first non-domain byte count (reset above)
-    }
-    if (ll <= 7) {
-        if (dot_inside) return false;           // a later dot owns this run
+                                               uint32_t min_labels, uint32_t j, uint2 w, uint64_t b0, uint64_t b1, uint64_t b2,
+                                               uint32_t& start, uint32_t& end) {
+    constexpr uint64_t H = 0x8080808080808080ull;
+    const uint64_t w64 = (uint64_t)w.x | ((uint64_t)w.y << 32);
+    const ByteMasks mw = domain_masks(w64);
+    // last label = leading domain-char bytes of w; ll = its length (8: not terminated within the window)
+    const uint64_t ndc = ~mw.dc & H;
+    const uint32_t ll = ndc ? (uint32_t)(__ffsll((long long)ndc) - 1) >> 3 : 8u;
+    if (ll <= 7 && ll >= 1) {
+        const uint64_t below = (1ull << (8 * ll)) - 1ull;            // the label's bytes
+        if (mw.dot & below) return false;                            // a later dot owns this run
+        const uint32_t stop_c = (uint32_t)(w64 >> (8 * ll)) & 0xFF;
         if (!d_is_boundary(stop_c)) return false;
-        const uint32_t lo = ll >= 4 ? w.x : (w.x & ((1u << (8 * ll)) - 1u));
-        const uint32_t hi = ll > 4 ? (w.y & ((1u << (8 * (ll - 4))) - 1u)) : 0u;
+        const uint32_t lo = (uint32_t)(w64 & below), hi = (uint32_t)((w64 & below) >> 32);
         uint32_t slot = tld_tab_slot(lo, hi);
         bool alone = false;
         for (;;) {
@@ -187,19 +201,45 @@ __device__ __forceinline__ bool val_domain_pre(const LogView& lg, const DevDb& d
             slot = (slot + 1) & ((1u << TLD_TAB_BITS) - 1);
         }
         if (alone) {
-            const uint32_t lastc = ((ll > 4 ? hi : lo) >> (8 * ((ll - 1) & 3))) & 0xFF;
-            WalkInit wi;
-            wi.rh = 0;
-            wi.cur = ll;
-            wi.last_c = lo & 0xFF;
-            wi.high = ((lo | hi) & 0x80808080u) != 0;
-            wi.bad = lastc == '-';
-            BackReader br;
-            br.init_pre(lg.p, j, b0, b1);
-            uint32_t s;
-            if (!domain_walk_back<false>(lg, db, min_labels, j + ll, br, wi, s)) return false;
-            start = s; end = j + ll;
-            return true;
+            // the 24 bytes in front of the label, address order: b2 | b1 | b0; the run extends leftwards from the top
+            // byte of b0 (the dot at j-1) while bytes are domain chars
+            const ByteMasks m0 = domain_masks(b0), m1 = domain_masks(b1), m2 = domain_masks(b2);
+            const uint64_t n0m = ~m0.dc & H, n1m = ~m1.dc & H, n2m = ~m2.dc & H;
+            const uint32_t c0 = n0m ? (uint32_t)__clzll((long long)n0m) >> 3 : 8u;   // domain chars at the top of b0
+            const uint32_t c1 = n1m ? (uint32_t)__clzll((long long)n1m) >> 3 : 8u, c2 = n2m ? (uint32_t)__clzll((long long)n2m) >> 3 : 8u;
+            const uint32_t consumed = c0 < 8 ? c0 : (c1 < 8 ? 8 + c1 : 16 + c2);
+            if (consumed < 24 || j == 24) {   // the run starts inside the context (or at the start of the buffer)
+                // region masks: the top `k` bytes of each word that belong to the run
+                auto top = [](uint32_t k) -> uint64_t { return k == 0 ? 0ull : (~0ull << (64 - 8 * k)); };
+                const uint64_t r0 = top(min(consumed, 8u)), r1 = top(consumed > 8 ? min(consumed - 8, 8u) : 0u),
+                               r2 = top(consumed > 16 ? consumed - 16 : 0u);
+                // "byte to the right" (one position closer to the label) moved onto each byte: shift towards lower
+                // addresses; the byte right of b0's top byte is the label's first byte (neither dot nor dash)
+                const uint64_t d0 = m0.dot >> 8, d1 = (m1.dot >> 8) | (m0.dot << 56), d2 = (m2.dot >> 8) | (m1.dot << 56);
+                const uint64_t s0 = m0.dash >> 8, s1 = (m1.dash >> 8) | (m0.dash << 56), s2 = (m2.dash >> 8) | (m1.dash << 56);
+                // bad events: empty label (two dots in a row), label starting with '-' (dot, then dash to its right),
+                // label ending with '-' (dash, then dot to its right)
+                const uint64_t bad = ((m0.dot & (d0 | s0)) | (m0.dash & d0)) & r0;
+                const uint64_t bad1 = ((m1.dot & (d1 | s1)) | (m1.dash & d1)) & r1, bad2 = ((m2.dot & (d2 | s2)) | (m2.dash & d2)) & r2;
+                const uint32_t ndots = (uint32_t)(__popcll(m0.dot & r0) + __popcll(m1.dot & r1) + __popcll(m2.dot & r2));
+                // leftmost byte of the run: must not be a dot (empty leftmost label) or a dash
+                const uint32_t li = 24 - consumed;                       // its index in address order (consumed >= 1: the dot)
+                const uint64_t lw = li < 8 ? b2 : li < 16 ? b1 : b0;
+                const uint32_t left_c = (uint32_t)(lw >> (8 * (li & 7))) & 0xFF;
+                const uint32_t fi = 23 - consumed;                       // byte in front of the run (if inside the context)
+                const uint64_t fw = fi < 8 ? b2 : fi < 16 ? b1 : b0;
+                const uint32_t first_c = consumed < 24 ? (uint32_t)(fw >> (8 * (fi & 7))) & 0xFF : 0x100u;
+                const uint32_t lastc = (uint32_t)(w64 >> (8 * (ll - 1))) & 0xFF;
+                const bool any_bad = (bad | bad1 | bad2) != 0 || lastc == '-' || consumed == 0 || left_c == '.' || left_c == '-';
+                if (any_bad || ndots == 0 || 1 + ndots < min_labels) return false;
+                if (first_c != 0x100 && !d_is_boundary(first_c)) return false;
+                const uint32_t s_pos = j - consumed;
+                const bool high = ((m0.high & r0) | (m1.high & r1) | (m2.high & r2) | (mw.high & below)) != 0;
+                if (high && !d_valid_utf8(lg.p + s_pos, j + ll - s_pos)) return false;
+                start = s_pos; end = j + ll;
+                return true;
+            }
+            // the name reaches further back than the context: general path below
         }
     }
     return val_domain(lg, db, bloom, tldtab, min_labels, j, start, end);
@@ -584,43 +624,42 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     ChunkWriter<Candidate, CAND_CHUNK> cw;
     const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
     const uint32_t stride = gridDim.x * blockDim.x;
-    // Domain anchors, software-pipelined: the anchor of the next iteration and the 24 bytes around it are loaded while
-    // the current one is validated, so the dependent chain list -> log bytes is off the critical path.
+    // Domain anchors with their context records (planes written by k_anchor, read coalesced), software-pipelined: the
+    // record of the next iteration is loaded while the current one is validated.
     const uint32_t nd = min(p.counters->n_dom, p.dom_cap);
     {
-        const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x;
-        auto anchor_at = [&](uint32_t i) { return i < nd ? p.dom_list[i] : 0xFFFFFFFFu; };
-        auto pre_ok = [&](uint32_t ad) { return ad != 0xFFFFFFFFu && ad >= 16 && ad + 8 <= lg.len; };
-        uint32_t ad_cur = anchor_at(i0), ad_nxt = anchor_at(i0 + stride);
-        uint2 w_cur = make_uint2(0u, 0u);
-        uint64_t b0_cur = 0, b1_cur = 0;
-        if (pre_ok(ad_cur)) {
-            __builtin_memcpy(&w_cur, lg.p + ad_cur, 8);
-            b0_cur = BackReader::load8(lg.p + ad_cur - 8);
-            b1_cur = BackReader::load8(lg.p + ad_cur - 16);
-        }
+        struct Rec { uint32_t j; uint32_t c[8]; };
+        auto load_rec = [&](uint32_t i, Rec& r) {
+            r.j = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r.c[k] = 0;
+            if (i < nd) {
+                r.j = p.dom_list[dom_plane_index(i, 0)];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r.c[k] = p.dom_list[dom_plane_index(i, 1 + k)];
+            }
+        };
+        Rec cur, nxt;
+        load_rec(blockIdx.x * blockDim.x + threadIdx.x, cur);
         for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
             const uint32_t i = base + threadIdx.x;
-            // issue the loads of the next iteration
-            uint2 w_nxt = make_uint2(0u, 0u);
-            uint64_t b0_nxt = 0, b1_nxt = 0;
-            if (pre_ok(ad_nxt)) {
-                __builtin_memcpy(&w_nxt, lg.p + ad_nxt, 8);
-                b0_nxt = BackReader::load8(lg.p + ad_nxt - 8);
-                b1_nxt = BackReader::load8(lg.p + ad_nxt - 16);
-            }
-            const uint32_t ad_n2 = anchor_at(i + 2 * stride);
+            load_rec(i + stride, nxt);
             Candidate c{0, 0, 0, 0};
             bool emit = false;
-            if (ad_cur != 0xFFFFFFFFu) {
+            if (cur.j != 0xFFFFFFFFu) {
                 uint32_t s, e;
-                const bool ok = pre_ok(ad_cur) ? val_domain_pre(lg, db, bloom, tldtab, p.min_labels, ad_cur, w_cur, b0_cur, b1_cur, s, e)
-                                               : val_domain(lg, db, bloom, tldtab, p.min_labels, ad_cur, s, e);
+                bool ok;
+                if (!(cur.j & 0x80000000u)) {
+                    const uint64_t b2 = (uint64_t)cur.c[0] | ((uint64_t)cur.c[1] << 32), b1 = (uint64_t)cur.c[2] | ((uint64_t)cur.c[3] << 32),
+                                   b0 = (uint64_t)cur.c[4] | ((uint64_t)cur.c[5] << 32);
+                    ok = val_domain_pre(lg, db, bloom, tldtab, p.min_labels, cur.j, make_uint2(cur.c[6], cur.c[7]), b0, b1, b2, s, e);
+                } else {
+                    ok = val_domain(lg, db, bloom, tldtab, p.min_labels, cur.j & 0x7FFFFFFFu, s, e);
+                }
                 if (ok) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true; }
             }
             cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
-            ad_cur = ad_nxt; ad_nxt = ad_n2;
-            w_cur = w_nxt; b0_cur = b0_nxt; b1_cur = b1_nxt;
+            cur = nxt;
         }
     }
     // Long tokens: hex hashes are decided here; the checksum validators (Base58Check, Bech32, EIP-55, Monero) need

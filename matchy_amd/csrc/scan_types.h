@@ -130,7 +130,11 @@ struct TokParams {
     uint32_t tok_cap;
     RareAnchor* heavy;        // tokens that passed the cheap prefilters of k_validate and need k_rare
     uint32_t heavy_cap;
-    uint32_t* dom_list;       // domain anchor positions written by k_anchor (after its prefilter), consumed by k_validate
+    // Domain anchors that survive k_anchor's prefilter, with 32 bytes of context copied from its LDS window so that
+    // k_validate reads them coalesced instead of gathering log lines: per 1024-slot chunk 9 planes of 1024 dwords
+    // (dom_plane_index): plane 0 = anchor position j (bit 31 set: no context, 0xFFFFFFFF: unused slot),
+    // planes 1..8 = log[j-24, j+8). dom_cap counts slots.
+    uint32_t* dom_list;
     uint32_t dom_cap;
     ScanCounters* counters;
 };
@@ -182,6 +186,10 @@ struct PackParams {
 // Output lists are filled through wave-private chunks (one atomic per chunk, not per append); unused slots of a
 // chunk hold a sentinel (anchor 0xFFFFFFFF, Candidate.len_type 0xFFFFFFFF, RareAnchor kind 0xFF, Hit.kind 0xFF).
 constexpr uint32_t ANCHOR_CHUNK = 1024, RARE_CHUNK = 64, CAND_CHUNK = 512, HIT_CHUNK = 256;
+constexpr uint32_t DOM_PLANES = 9;
+__host__ __device__ inline size_t dom_plane_index(uint32_t slot, uint32_t plane) {
+    return (size_t)(slot / ANCHOR_CHUNK) * (DOM_PLANES * ANCHOR_CHUNK) + (size_t)plane * ANCHOR_CHUNK + (slot % ANCHOR_CHUNK);
+}
 constexpr uint32_t SEG_BYTES = 16384;  // bytes of log per wavefront work item
 constexpr uint32_t MAX_GLOB_RESULTS = 32;
 constexpr uint32_t MAX_GLOB_STARS = 24;
