@@ -641,11 +641,23 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         };
         Rec cur, nxt;
         load_rec(blockIdx.x * blockDim.x + threadIdx.x, cur);
+        {
+            // consume the first record here, so that inside the loop no wait is placed between the store at the top of
+            // an iteration and the first use of `cur` (the wait would also cover that store)
+            uint32_t g = cur.j;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g ^= cur.c[k];
+            asm volatile("" ::"v"(g));
+        }
+        // the candidate of iteration k is stored at the top of iteration k+1, before the next loads are issued: the
+        // wait for those loads (vmcnt counts loads and stores in order) then never waits for a store in flight
+        uint32_t pend_start = 0, pend_lt = 0;
+        bool pend = false;
         for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
             const uint32_t i = base + threadIdx.x;
+            cw.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+            pend = false;
             load_rec(i + stride, nxt);
-            Candidate c{0, 0, 0, 0};
-            bool emit = false;
             if (cur.j != 0xFFFFFFFFu) {
                 uint32_t s, e;
                 bool ok;
@@ -656,11 +668,11 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
                 } else {
                     ok = val_domain(lg, db, bloom, tldtab, p.min_labels, cur.j & 0x7FFFFFFFu, s, e);
                 }
-                if (ok) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true; }
+                if (ok) { pend_start = s; pend_lt = (e - s) | ((uint32_t)IT_DOMAIN << 24); pend = true; }
             }
-            cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
             cur = nxt;
         }
+        cw.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     }
     // Long tokens: hex hashes are decided here; the checksum validators (Base58Check, Bech32, EIP-55, Monero) need
     // SHA-256 / Keccak and hundreds of registers, so tokens that pass their cheap prefix tests go to the `heavy` list
