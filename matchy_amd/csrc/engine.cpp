@@ -336,12 +336,20 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.heavy = heavy_.p; tp.heavy_cap = (uint32_t)heavy_.n;
     tp.dom_list = dom_list_.p; tp.dom_cap = (uint32_t)dom_slots_;
     tp.counters = counters_.p;
-    int grid_tok = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * 8);
+    // workgroups per CU for k_anchor / k_validate / k_lookup / k_pack: what is resident at once (grid-stride kernels; a
+    // larger grid only adds a partially filled second round). MATCHY_AMD_GRID=a,v,l,p overrides for experiments.
+    // k_anchor: two full rounds of resident workgroups; k_validate: one; k_lookup: 4 per CU measured best (more waves in
+    // flight only add contention on the random table accesses).
+    static const int occ_a = anchor_blocks_per_cu(), occ_v = validate_blocks_per_cu();
+    int gm[4] = {2 * occ_a, occ_v, 4, 2};
+    if (const char* g = getenv("MATCHY_AMD_GRID")) (void)sscanf(g, "%d,%d,%d,%d", &gm[0], &gm[1], &gm[2], &gm[3]);
+    for (int& m : gm) m = std::max(1, std::min(m, 64));
+    int grid_tok = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * gm[0]);
     if (grid_tok < 1) grid_tok = 1;
     if (profile_) MXY_HIP(hipEventRecord(ev_[0], stream));
     launch_anchor(tp, ddb_->view, grid_tok, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[1], stream));
-    launch_validate(tp, ddb_->view, n_cu_ * 8, stream);
+    launch_validate(tp, ddb_->view, n_cu_ * gm[1], stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
     bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
     if (rare_possible) launch_rare(tp, ddb_->view, n_cu_, stream);
@@ -355,7 +363,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
             lp.glob_work = glob_work_.p; lp.glob_work_cap = (uint32_t)glob_work_.n;
         }
         lp.counters = counters_.p;
-        launch_lookup(lp, ddb_->view, n_cu_ * 4, stream);
+        launch_lookup(lp, ddb_->view, n_cu_ * gm[2], stream);
         PackParams pp{};
         pp.hits = hits_.p; pp.hit_cap = (uint32_t)hits_.n; pp.ids = ids_.p; pp.ids_cap = (uint32_t)ids_.n;
         pp.lit_offsets = ddb_->lit_offsets.p; pp.n_lit = ddb_->n_lit_offsets;
@@ -363,7 +371,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         pp.out = final_.p; pp.out_cap = (uint32_t)final_.n;
         pp.out_ids = final_ids_.p; pp.out_offs = final_offs_.p; pp.out_ids_cap = (uint32_t)final_ids_.n;
         pp.counters = counters_.p;
-        launch_pack(pp, n_cu_ * 2, stream);
+        launch_pack(pp, n_cu_ * gm[3], stream);
     }
     if (profile_) MXY_HIP(hipEventRecord(ev_[4], stream));
 }

@@ -425,6 +425,13 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     if (lane == 0 && lines) atomicAdd(&p.counters->lines, lines);
 }
 
+// workgroups of k_anchor that are resident on one CU at the same time (register / LDS limited)
+int anchor_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_anchor, AW * 64, 0) != hipSuccess || n < 1) n = 4;
+    return n;
+}
+
 void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_anchor, dim3(grid), dim3(AW * 64), 0, stream, p, db);
 }

@@ -1196,6 +1196,11 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
 void launch_pack(const PackParams& p, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, stream, p);
 }
+int validate_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate, 256, 0) != hipSuccess || n < 1) n = 4;
+    return n;
+}
 void launch_validate(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_validate, dim3(grid), dim3(256), 0, stream, p, db);
 }
