@@ -452,9 +452,9 @@ int32_t matchy_scanner_scan_device(matchy_scanner_t* s, const void* dptr, size_t
     ScannerH* h = reinterpret_cast<ScannerH*>(s);
     try {
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st);
-        ScanOutput so;
         const bool sorted = (fetch_mode & 2) != 0;
+        h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st, (fetch_mode & 1) && !sorted);
+        ScanOutput so;
         h->sc->fetch(so, false, st, (fetch_mode & 1) ? HITS_FINAL : HITS_NONE, sorted);
         fill_result(so.fin, so.n_fin, so.fin_ids, so.fin_offs, so.n_fin_ids, so.lines, so.n_cand, len, !sorted, sorted, out);
         if (!(fetch_mode & 1)) out->n_hits = so.n_hits;  // count only; `hits` stays NULL

@@ -301,6 +301,7 @@ Scanner::Scanner(std::shared_ptr<const DbImage> img, std::shared_ptr<DeviceDb> d
 
 Scanner::~Scanner() {
     if (pinned_) (void)hipHostFree(pinned_);
+    if (mirror_) (void)hipHostFree(mirror_);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
 }
 
@@ -318,12 +319,20 @@ void Scanner::ensure_capacity(uint32_t len) {
     if (dom_slots_ < want_d) { dom_list_.alloc(want_d * DOM_PLANES); dom_slots_ = want_d; }
 }
 
-void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream) {
+void Scanner::ensure_mirror(uint32_t recs, uint32_t ids) {
+    if (mirror_ && mirror_cap_ >= recs && mirror_ids_cap_ >= ids) return;
+    if (mirror_) (void)hipHostFree(mirror_);
+    mirror_cap_ = std::max(recs, mirror_cap_); mirror_ids_cap_ = std::max(ids, mirror_ids_cap_);
+    const size_t bytes = (size_t)mirror_cap_ * sizeof(FinalHit) + (size_t)mirror_ids_cap_ * 12 + 64;
+    MXY_HIP(hipHostMalloc(&mirror_, bytes, hipHostMallocDefault));
+}
+
+void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror) {
     if (len >= 0x7FFF0000u) throw HipError{"scan_device: chunk too large (must be < 2^31 bytes)"};
     if (((uintptr_t)dptr & 15) != 0) throw HipError{"scan_device: device pointer must be 16-byte aligned"};
     MXY_HIP(hipSetDevice(ddb_->device));
     ensure_capacity(len);
-    last_ptr_ = dptr; last_len_ = len; last_lookup_ = lookup;
+    last_ptr_ = dptr; last_len_ = len; last_lookup_ = lookup; last_mirror_ = host_mirror;
     MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters), stream));
     TokParams tp{};
     tp.log = dptr; tp.len = len; tp.flags = flags_; tp.min_labels = min_labels_;
@@ -370,6 +379,17 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         pp.glob_offsets = ddb_->glob_offsets.p; pp.n_glob = ddb_->n_glob_offsets;
         pp.out = final_.p; pp.out_cap = (uint32_t)final_.n;
         pp.out_ids = final_ids_.p; pp.out_offs = final_offs_.p; pp.out_ids_cap = (uint32_t)final_ids_.n;
+        mirror_used_ = false;
+        if (host_mirror) {
+            static const uint32_t mirror0 = getenv("MATCHY_AMD_MIRROR_RECS") ? (uint32_t)atoi(getenv("MATCHY_AMD_MIRROR_RECS")) : (1u << 20);
+            ensure_mirror(std::max(mirror0, 16u), std::max(mirror0 / 16, 16u));
+            uint8_t* mb = (uint8_t*)mirror_;
+            pp.host_out = (FinalHit*)mb; pp.host_cap = mirror_cap_;
+            pp.host_ids = (uint32_t*)(mb + (size_t)mirror_cap_ * sizeof(FinalHit));
+            pp.host_offs = (long long*)(mb + (size_t)mirror_cap_ * sizeof(FinalHit) + (((size_t)mirror_ids_cap_ * 4 + 7) & ~(size_t)7));
+            pp.host_ids_cap = mirror_ids_cap_;
+            mirror_used_ = true;
+        }
         pp.counters = counters_.p;
         launch_pack(pp, n_cu_ * gm[3], stream);
     }
@@ -413,7 +433,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         if (c.n_ids > ids_.n) ids_.alloc((size_t)c.n_ids + c.n_ids / 4 + 1024);
         if (final_.n < hits_.n) final_.alloc(hits_.n);
         if (final_ids_.n < hits_.n + ids_.n) { final_ids_.alloc(hits_.n + ids_.n); final_offs_.alloc(hits_.n + ids_.n); }
-        scan_device(last_ptr_, last_len_, last_lookup_, stream);
+        scan_device(last_ptr_, last_len_, last_lookup_, stream, last_mirror_);
         if (attempt == 5) throw HipError{"scan: work buffers still overflow after regrowing"};
     }
     const ScanCounters& c = host_counters_;
@@ -445,7 +465,19 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
             MXY_HIP(hipMemcpyAsync(out.ids.data(), ids_.p, (size_t)c.n_ids * 4, hipMemcpyDeviceToHost, stream));
         }
     }
-    if (get_fin) {
+    if (get_fin && !sorted && mirror_used_ && c.n_final <= mirror_cap_ && c.n_final_ids <= mirror_ids_cap_) {
+        // k_pack has already written the records into pinned host memory
+        uint8_t* mb = (uint8_t*)mirror_;
+        out.fin = (const FinalHit*)mb; out.n_fin = c.n_final;
+        out.fin_ids = (const uint32_t*)(mb + (size_t)mirror_cap_ * sizeof(FinalHit));
+        out.fin_offs = (const long long*)(mb + (size_t)mirror_cap_ * sizeof(FinalHit) + (((size_t)mirror_ids_cap_ * 4 + 7) & ~(size_t)7));
+        out.n_fin_ids = c.n_final_ids;
+    } else if (get_fin) {
+        if (mirror_used_ && !sorted) {  // did not fit: take the copy path now, have a larger mirror next time
+            const uint32_t want_r = std::max(mirror_cap_, c.n_final + c.n_final / 2), want_i = std::max(mirror_ids_cap_, c.n_final_ids + c.n_final_ids / 2);
+            mirror_used_ = false;
+            ensure_mirror(want_r, want_i);
+        }
         const size_t hb = (size_t)c.n_final * sizeof(FinalHit), ib = (((size_t)c.n_final_ids * 4) + 7) & ~(size_t)7, ob = (size_t)c.n_final_ids * 8;
         ensure_pinned(hb + ib + ob);
         uint8_t* base = (uint8_t*)pinned_;

@@ -102,7 +102,8 @@ public:
     ~Scanner();
     // Scan `len` bytes already resident in device memory (16-byte aligned). len < 2^31.
     // lookup=false stops after extraction. Results stay on the device until fetch().
-    void scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream);
+    // host_mirror: k_pack also writes the final records into pinned host memory (unsorted fetches then need no copy)
+    void scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror = false);
     // Copies counters (and hits / candidates) back. Call after scan_device; synchronises the stream.
     // sorted: the final records are put into canonical order on the GPU (sort_hits.hip) before they are copied back
     void fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode = HITS_FINAL, bool sorted = false);
@@ -138,6 +139,11 @@ private:
     DevBuf<FinalHit> final_sorted_;
     DevBuf<ScanCounters> counters_;
     DevBuf<uint8_t> staging_;  // scan_host only
+    // pinned mirror of the final records written by k_pack itself: FinalHit[mirror_cap_] | u32 ids[mirror_ids_cap_] | i64 offs[..]
+    void* mirror_ = nullptr;
+    uint32_t mirror_cap_ = 0, mirror_ids_cap_ = 0;
+    bool mirror_used_ = false, last_mirror_ = false;
+    void ensure_mirror(uint32_t recs, uint32_t ids);
     void* pinned_ = nullptr;   // one pinned block: FinalHit[n] | u32 ids[m] | i64 offs[m]  (or Hit[n] for HITS_RAW)
     size_t pinned_bytes_ = 0;
     void ensure_pinned(size_t bytes);

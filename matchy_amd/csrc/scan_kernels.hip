@@ -1177,17 +1177,18 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
                 uint32_t w = my_ids;
                 if (lit_off != 0xFFFFFFFFu) {
                     if (w < p.out_ids_cap) { p.out_ids[w] = h.a; p.out_offs[w] = (long long)lit_off; }
+                    if (w < p.host_ids_cap) { p.host_ids[w] = h.a; p.host_offs[w] = (long long)lit_off; }
                     ++w;
                 }
                 for (uint32_t k = 0; k < h.n_globs; ++k, ++w) {
                     const uint32_t pid = (h.ids_off + k < p.ids_cap) ? p.ids[h.ids_off + k] : 0u;
-                    if (w < p.out_ids_cap) {
-                        p.out_ids[w] = pid;
-                        p.out_offs[w] = pid < p.n_glob ? (long long)p.glob_offsets[pid] : -1ll;
-                    }
+                    const long long go = pid < p.n_glob ? (long long)p.glob_offsets[pid] : -1ll;
+                    if (w < p.out_ids_cap) { p.out_ids[w] = pid; p.out_offs[w] = go; }
+                    if (w < p.host_ids_cap) { p.host_ids[w] = pid; p.host_offs[w] = go; }
                 }
             }
             if (slot < p.out_cap) p.out[slot] = f;
+            if (slot < p.host_cap) p.host_out[slot] = f;
         }
     }
 }

@@ -180,6 +180,13 @@ struct PackParams {
     uint32_t* out_ids;
     long long* out_offs;
     uint32_t out_ids_cap;
+    // optional mirror in pinned host memory (device-visible): records below these capacities are also written there, so
+    // that a scan whose results fit needs no device-to-host copy of the hit records at all
+    FinalHit* host_out;
+    uint32_t host_cap;
+    uint32_t* host_ids;
+    long long* host_offs;
+    uint32_t host_ids_cap;
     ScanCounters* counters;
 };
 

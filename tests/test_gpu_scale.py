@@ -97,3 +97,45 @@ def test_full_size_parity_and_properties(M, oracle):
     assert nl == lines
     assert merged == hits
     sc.close(); db.close()
+
+
+@pytest.mark.parametrize("cfgname,mirror", [("c4/10", "64"), ("c2/10", "64"), ("c2/10", "0")])
+def test_scan_device_fetch_modes(M, oracle, cfgname, mirror, monkeypatch):
+    """matchy_scanner_scan_device on a buffer that lives in HBM: fetch_mode 0 (counts), 1 (records straight from the
+    pinned mirror that k_pack fills, device order) and 3 (GPU-sorted copy) agree with each other and with the oracle;
+    a mirror that is too small (64 records) makes mode 1 take the copy path and grow the mirror for the next scan."""
+    import ctypes
+    from tools import synth
+    if mirror != "0":
+        monkeypatch.setenv("MATCHY_AMD_MIRROR_RECS", mirror)   # read once per process: only the first parametrisation
+    cfg = synth.config(cfgname)
+    blob = synth.build_db(cfg)
+    log = synth.make_log(cfg, 0, 60000)
+    want, _, st = oracle.Database(blob).scan(log, want_json=False)
+    db = M.Database(blob)
+    sc = M.Scanner(db)
+    # device buffer through the HIP runtime the library itself uses (no torch in this process)
+    hip = ctypes.CDLL("libamdhip64.so")
+    dptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(len(log) + 64)) == 0
+    assert hip.hipMemcpy(dptr, log, ctypes.c_size_t(len(log)), 1) == 0
+
+    class _D:
+        def data_ptr(self):
+            return dptr.value
+    d = _D()
+    key = lambda h: (h["start"], h["end"], h["type"])
+    for rep in range(3):  # repeated: borrowed buffers are reused, the mirror may grow between scans
+        r0 = sc.scan_device(d.data_ptr(), len(log), fetch_mode=0)
+        assert (r0.lines, r0.candidates, r0.n_hits) == (st.lines, st.candidates, len(want))
+        r0.close()
+        r1 = sc.scan_device(d.data_ptr(), len(log), fetch_mode=1)
+        h1 = r1.hits()
+        r1.close()
+        r3 = sc.scan_device(d.data_ptr(), len(log), fetch_mode=3)
+        h3 = r3.hits()
+        r3.close()
+        assert h3 == want
+        assert sorted(h1, key=key) == sorted(want, key=key)
+    sc.close(); db.close()
+    hip.hipFree(dptr)
