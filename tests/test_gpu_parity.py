@@ -145,7 +145,7 @@ def test_scan_small_combined_database(M, oracle):
     assert len(gh) >= 8
 
 
-@pytest.mark.parametrize("cfgname,lines", [("c1", 10000), ("c2/20", 20000), ("c4/20", 20000)])
+@pytest.mark.parametrize("cfgname,lines", [("c1", 10000), ("c2/20", 20000), ("c3/20", 20000), ("c3b/20", 20000), ("c4/20", 20000)])
 def test_scan_synthetic_configs(M, oracle, cfgname, lines):
     from tools import synth
     cfg = synth.config(cfgname)
@@ -156,7 +156,7 @@ def test_scan_synthetic_configs(M, oracle, cfgname, lines):
     assert len(gh) == len(wh)
     assert gh == wh
     assert gl == wl
-    assert len(gh) > lines // 200
+    assert len(gh) > 50
 
 
 def test_single_query_api(M, oracle):

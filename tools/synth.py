@@ -25,6 +25,9 @@ def config(name: str) -> Cfg:
     if "/" in name:
         name, s = name.split("/")
         scale = int(s)
+    glob_prefix = name == "c3b"   # C3 "AC-forced" variant: keys written glob:{key} -> 1M AC literals
+    if glob_prefix:
+        name = "c3"
     presets = {
         # C1: 1K-indicator CSV (400 /32, 100 CIDR, 350 domains, 100 globs, 50 hashes)
         "c1": dict(n_ip=400, n_cidr=100, n_dom=350, n_hash=50, n_glob=100),
@@ -36,7 +39,9 @@ def config(name: str) -> Cfg:
         "c4": dict(n_ip=40000, n_cidr=10000, n_dom=25000, n_hash=15000, n_glob=10000),
     }
     p = {k: max(v // scale, 1 if v else 0) for k, v in presets[name].items()}
-    return Cfg(seed=SEED, hit_permille=20, **p)
+    cfg = Cfg(seed=SEED, hit_permille=20, **p)
+    cfg.glob_prefix = glob_prefix
+    return cfg
 
 
 _lib = None
@@ -86,7 +91,10 @@ def ioc_entries(cfg: Cfg):
         for i in range(getattr(cfg, field)):
             L.synth_ioc_key(C.byref(cfg), kind, i, kb, 512)
             L.synth_ioc_data(C.byref(cfg), kind, i, db, 512)
-            yield kb.value, db.value
+            key = kb.value
+            if getattr(cfg, "glob_prefix", False) and kind >= 2:
+                key = b"glob:" + key   # substring semantics through the paraglob section (Q9)
+            yield key, db.value
 
 
 def build_db(cfg: Cfg, epoch=1700000000) -> bytes:
