@@ -194,3 +194,47 @@ def test_null_and_error_handling(M):
     assert not r.found
     L.matchy_close(None)
     L.matchy_scanner_free(None)
+
+
+def test_concurrent_queries_and_scans(M, oracle):
+    """One database handle shared by several threads (c-querying.md: handles are thread-safe for concurrent queries);
+    every thread also owns a scanner. ctypes releases the GIL during the calls, so the C side really runs in parallel."""
+    import threading
+    from tools import synth
+    cfg = synth.config("c1")
+    blob = synth.build_db(cfg)
+    db = M.Database(blob)
+    odb = oracle.Database(blob)
+    keys = [k.decode() for k, _ in synth.ioc_entries(cfg)][::9]
+    probes = [k.split("/")[0] if "/" in k else ("www" + k[1:] if k.startswith("*.") else k) for k in keys] + ["9.9.9.9", "nope.invalid.example"]
+    want_q = {}
+    for q in probes:
+        w = odb.lookup(q)
+        want_q[q] = (w["kind"] != "notfound") and not (w["kind"] == "pattern" and (not w["data"] or w["data"][0] is None))
+    logs = [synth.make_log(cfg, 3000 * t, 3000) for t in range(4)]
+    want_s = [odb.scan(l, want_json=False)[0] for l in logs]
+    errors = []
+
+    def worker(t):
+        try:
+            sc = M.Scanner(db)
+            for rep in range(3):
+                for q in probes:
+                    got = db.lookup(q)
+                    if (got is not None) != want_q[q]:
+                        errors.append((t, "query", q))
+                r = sc.scan(logs[t])
+                if r.hits() != want_s[t]:
+                    errors.append((t, "scan", rep))
+                r.close()
+            sc.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, "exception", repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors[:5]
+    db.close()
