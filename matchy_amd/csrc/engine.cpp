@@ -213,6 +213,20 @@ void DeviceDb::upload(const DbImage& img, int dev) {
         const uint8_t* pool = img.bytes.data() + img.lh_off + img.lh_strings_offset;
         std::vector<uint8_t> pv(pool, pool + img.lh_strings_size);
         lit_pool.upload(pv);
+        {
+            // >= 64 bits per literal (false-positive rate <= 1.6 %), at least 4 Mbit: L2-resident for typical databases
+            size_t bits = (size_t)1 << 22;
+            size_t live = 0;
+            for (const LitSlot& sl : slots) live += sl.str_off != 0xFFFFFFFFu;
+            while (bits < live * 64 && bits < ((size_t)1 << 31)) bits <<= 1;
+            std::vector<uint32_t> bm(bits / 32, 0u);
+            const uint32_t bmask = (uint32_t)(bits - 1);
+            for (const LitSlot& sl : slots)
+                if (sl.str_off != 0xFFFFFFFFu) { const uint32_t b = lit_bm_bit(sl.hash) & bmask; bm[b >> 5] |= 1u << (b & 31); }
+            lit_bm.upload(bm);
+            view.lit_bm = lit_bm.p; view.lit_bm_mask = bmask;
+            bytes_uploaded += bm.size() * 4;
+        }
         view.lit_slots = lit_slots.p; view.lit_mask = mask; view.has_literal = 1;
         view.lit_pool = lit_pool.p; view.lit_pool_size = img.lh_strings_size;
         bytes_uploaded += slots.size() * sizeof(LitSlot) + pv.size();
@@ -337,6 +351,8 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     TokParams tp{};
     tp.log = dptr; tp.len = len; tp.flags = flags_; tp.min_labels = min_labels_;
     tp.filter_v4 = lookup ? 1u : 0u;
+    // without a glob section a string candidate can only hit through the literal table
+    tp.filter_lit = (lookup && !ddb_->view.has_glob) ? 1u : 0u;
     if (const char* dbg = getenv("MATCHY_AMD_DEBUG")) tp.debug = (uint32_t)atoi(dbg);
     tp.n_segs = (uint32_t)(((uint64_t)len + 1 + SEG_BYTES - 1) / SEG_BYTES);
     tp.cands = cands_.p; tp.cand_cap = (uint32_t)cands_.n;

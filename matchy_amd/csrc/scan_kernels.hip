@@ -179,7 +179,8 @@ __device__ __forceinline__ ByteMasks domain_masks(uint64_t x) {
 // Everything else takes val_domain.
 __device__ __forceinline__ bool val_domain_pre(const LogView& lg, const DevDb& db, const uint32_t* bloom, const uint2* tldtab,
                                                uint32_t min_labels, uint32_t j, uint2 w, uint64_t b0, uint64_t b1, uint64_t b2,
-                                               uint32_t& start, uint32_t& end) {
+                                               uint32_t& start, uint32_t& end, bool& in_ctx) {
+    in_ctx = false;
     constexpr uint64_t H = 0x8080808080808080ull;
     const uint64_t w64 = (uint64_t)w.x | ((uint64_t)w.y << 32);
     const ByteMasks mw = domain_masks(w64);
@@ -237,6 +238,7 @@ __device__ __forceinline__ bool val_domain_pre(const LogView& lg, const DevDb& d
                 const bool high = ((m0.high & r0) | (m1.high & r1) | (m2.high & r2) | (mw.high & below)) != 0;
                 if (high && !d_valid_utf8(lg.p + s_pos, j + ll - s_pos)) return false;
                 start = s_pos; end = j + ll;
+                in_ctx = true;   // the whole name lies inside the context record (starts at byte 24 - consumed)
                 return true;
             }
             // the name reaches further back than the context: general path below
@@ -621,9 +623,14 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     for (uint32_t i = threadIdx.x; i < (1u << TLD_TAB_BITS); i += blockDim.x) tldtab[i] = db.tld_tab[i];
     __syncthreads();
     LogView lg{p.log, p.len};
-    ChunkWriter<Candidate, CAND_CHUNK> cw;
+    // candidates: dense when every valid domain is listed (chunks of CAND_CHUNK), sparse otherwise (chunks of 64 keep
+    // the list free of padding for k_lookup)
+    ChunkWriter<Candidate, CAND_CHUNK> cw_dense;
+    ChunkWriter<Candidate, 64> cw;
     const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
     const uint32_t stride = gridDim.x * blockDim.x;
+    __shared__ __attribute__((aligned(16))) uint32_t strbuf[256][8];   // per-lane context bytes for hashing
+    uint32_t dom_listed = 0;   // domain candidates this wave put on the list (they are counted separately)
     // Domain anchors with their context records (planes written by k_anchor, read coalesced), software-pipelined: the
     // record of the next iteration is loaded while the current one is validated.
     const uint32_t nd = min(p.counters->n_dom, p.dom_cap);
@@ -649,30 +656,63 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
             for (int k = 0; k < 8; ++k) g ^= cur.c[k];
             asm volatile("" ::"v"(g));
         }
-        // the candidate of iteration k is stored at the top of iteration k+1, before the next loads are issued: the
-        // wait for those loads (vmcnt counts loads and stores in order) then never waits for a store in flight
-        uint32_t pend_start = 0, pend_lt = 0;
+        // The candidate of iteration k is stored at the top of iteration k+1, before the next loads are issued: the
+        // wait for those loads (vmcnt counts loads and stores in order) then never waits for a store in flight. The
+        // same delay gives the literal-bitmap load (p.filter_lit) a whole iteration to arrive.
+        uint32_t pend_start = 0, pend_lt = 0, pend_word = 0xFFFFFFFFu, pend_bit = 0, n_valid = 0;
         bool pend = false;
+        uint32_t* sb = strbuf[threadIdx.x];
         for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
             const uint32_t i = base + threadIdx.x;
-            cw.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+            if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+            else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
             pend = false;
             load_rec(i + stride, nxt);
             if (cur.j != 0xFFFFFFFFu) {
-                uint32_t s, e;
-                bool ok;
+                uint32_t s = 0, e = 0;
+                bool ok, in_ctx = false;
                 if (!(cur.j & 0x80000000u)) {
                     const uint64_t b2 = (uint64_t)cur.c[0] | ((uint64_t)cur.c[1] << 32), b1 = (uint64_t)cur.c[2] | ((uint64_t)cur.c[3] << 32),
                                    b0 = (uint64_t)cur.c[4] | ((uint64_t)cur.c[5] << 32);
-                    ok = val_domain_pre(lg, db, bloom, tldtab, p.min_labels, cur.j, make_uint2(cur.c[6], cur.c[7]), b0, b1, b2, s, e);
+                    ok = val_domain_pre(lg, db, bloom, tldtab, p.min_labels, cur.j, make_uint2(cur.c[6], cur.c[7]), b0, b1, b2, s, e, in_ctx);
                 } else {
                     ok = val_domain(lg, db, bloom, tldtab, p.min_labels, cur.j & 0x7FFFFFFFu, s, e);
                 }
-                if (ok) { pend_start = s; pend_lt = (e - s) | ((uint32_t)IT_DOMAIN << 24); pend = true; }
+                if (ok) {
+                    pend_start = s; pend_lt = (e - s) | ((uint32_t)IT_DOMAIN << 24); pend = true;
+                    pend_word = 0xFFFFFFFFu; pend_bit = 0;
+                    n_valid += 1;
+                    if (p.filter_lit && in_ctx) {
+                        // XXH64 of the name straight from the context record (no second read of the log): the 32
+                        // context bytes go through a per-lane LDS buffer to get the name aligned to 8-byte lanes
+                        *reinterpret_cast<uint4*>(sb) = make_uint4(cur.c[0], cur.c[1], cur.c[2], cur.c[3]);
+                        *reinterpret_cast<uint4*>(sb + 4) = make_uint4(cur.c[4], cur.c[5], cur.c[6], cur.c[7]);
+                        const uint32_t o = 24 - (cur.j - s), n = e - s;   // offset and length of the name in the context
+                        const uint32_t i0 = o >> 2, sh = o & 3;
+                        uint32_t wd[9];
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) wd[k] = (i0 + k) < 8 ? sb[(i0 + k) & 7] : 0u;
+                        uint64_t ln[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            ln[k] = (uint64_t)__builtin_amdgcn_alignbyte(wd[2 * k + 1], wd[2 * k], sh) |
+                                    ((uint64_t)__builtin_amdgcn_alignbyte(wd[2 * k + 2], wd[2 * k + 1], sh) << 32);
+                        const uint64_t h = xxh64_lanes31(ln[0], ln[1], ln[2], ln[3], n);
+                        const uint32_t b = lit_bm_bit(h) & db.lit_bm_mask;
+                        pend_word = db.lit_bm ? db.lit_bm[b >> 5] : 0u;
+                        pend_bit = b & 31;
+                    }
+                }
             }
             cur = nxt;
         }
-        cw.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+        if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+        else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+        // validated domain candidates, listed or not
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
+        if (lane_id() == 0 && n_valid) atomicAdd(&p.counters->cand_true, n_valid);
+        dom_listed = cw.total;   // (cw_dense holds domain candidates only)
     }
     // Long tokens: hex hashes are decided here; the checksum validators (Base58Check, Bech32, EIP-55, Monero) need
     // SHA-256 / Keccak and hundreds of registers, so tokens that pass their cheap prefix tests go to the `heavy` list
@@ -747,7 +787,8 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     }
     hw.pad_rest(p.heavy, p.heavy_cap, SH);
     cw.pad_rest(p.cands, p.cand_cap, SC);
-    if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
+    cw_dense.pad_rest(p.cands, p.cand_cap, SC);
+    if (lane_id() == 0 && cw.total > dom_listed) atomicAdd(&p.counters->cand_true, cw.total - dom_listed);
 }
 
 // k_rare — stage A3: checksum validators (Base58Check, Bech32, EIP-55, Monero): very rare in logs and heavy in

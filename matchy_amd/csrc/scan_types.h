@@ -62,6 +62,10 @@ struct DevDb {
     const LitSlot* lit_slots;
     uint32_t lit_mask;
     uint32_t has_literal;
+    // bitmap over the literals' XXH64 values (bit lit_bm_bit(h) & lit_bm_mask): clear => no literal has this hash.
+    // k_validate drops (but counts) domain candidates that cannot hit when the database has no glob section.
+    const uint32_t* lit_bm;
+    uint32_t lit_bm_mask;
     const uint8_t* lit_pool;  // LHSH string pool: {u16 len, bytes, NUL}
     uint32_t lit_pool_size;
     // paraglob buffer as stored on disk + a dense literal-id -> pattern-id list (from the ACLH table)
@@ -121,6 +125,7 @@ struct TokParams {
     uint32_t min_labels;
     uint32_t debug;           // profiling only
     uint32_t filter_v4;       // 1: IPv4 candidates whose /24 has no database entry are counted but not listed (lookup scans)
+    uint32_t filter_lit;      // 1: domain candidates whose XXH64 is not in DevDb::lit_bm are counted but not listed
     uint32_t n_segs;
     Candidate* cands;
     uint32_t cand_cap;
