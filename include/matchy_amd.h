@@ -142,18 +142,20 @@ const char *matchy_item_type_name(uint8_t item_type);                           
 
 typedef struct matchy_scanner_t matchy_scanner_t;
 
-/* One match of Worker::process_bytes (processing/mod.rs:423-443): candidate span + lookup result. */
+/* One match of Worker::process_bytes (processing/mod.rs:423-443): candidate span + lookup result, 16 bytes (the
+ * GPU writes these records straight into pinned host memory; compact records halve the PCIe time of a scan). */
 typedef struct matchy_scan_hit_t {
-  uint64_t start;        /* byte offset of the matched text in the scanned buffer */
-  uint64_t end;          /* exclusive */
-  uint8_t item_type;     /* MATCHY_ITEM_TYPE_* */
+  uint32_t start;        /* byte offset of the matched text in the scanned buffer */
+  uint32_t len_type;     /* length of the matched text in bits 0..23, MATCHY_ITEM_TYPE_* in bits 24..31 */
+  uint32_t value;        /* IP results: offset of the entry data in the MMDB data section;
+                            pattern results: index of the first id in pattern_ids / data_offsets */
   uint8_t kind;          /* 2 = IP result, 3 = pattern result */
   uint8_t prefix_len;    /* IP results */
-  uint8_t _pad;
-  uint32_t data_offset;  /* IP results: offset of the entry data in the MMDB data section */
-  uint32_t n_ids;        /* pattern results: number of pattern ids (literal id first, then glob ids ascending) */
-  uint32_t ids_index;    /* pattern results: index of the first id in pattern_ids / data_offsets */
+  uint16_t n_ids;        /* pattern results: number of pattern ids (literal id first, then glob ids ascending) */
 } matchy_scan_hit_t;
+#define MATCHY_SCAN_HIT_LEN(h) ((h).len_type & 0xFFFFFFu)
+#define MATCHY_SCAN_HIT_END(h) ((uint64_t)(h).start + MATCHY_SCAN_HIT_LEN(h))
+#define MATCHY_SCAN_HIT_TYPE(h) ((uint8_t)((h).len_type >> 24))
 
 typedef struct matchy_scan_result_t {
   const matchy_scan_hit_t *hits;  /* canonical order: by start, then chunk-path class order */
@@ -171,7 +173,8 @@ typedef struct matchy_scan_result_t {
  * device = HIP device ordinal. Returns NULL on failure. One scanner per thread. */
 matchy_scanner_t *matchy_scanner_create(const matchy_t *db, uint32_t extract_flags, int32_t device);
 void matchy_scanner_free(matchy_scanner_t *scanner);
-/* Scan a host buffer (copied to the device in newline-aligned pieces of < 1 GiB). */
+/* Scan a host buffer (copied to the device in newline-aligned pieces of < 1 GiB). len must be below 4 GiB per call
+ * (hit offsets are 32 bit); feed larger inputs in batches cut at newlines, like `matchy match` does. */
 int32_t matchy_scanner_scan(matchy_scanner_t *scanner, const uint8_t *data, size_t len, matchy_scan_result_t *out);
 /* Scan bytes that are already resident in device memory (16-byte aligned, len < 2^31) on `hip_stream`
  * (a hipStream_t, NULL = default stream). fetch_mode: 0 = only counters are read back (n_hits is set, hits is NULL),

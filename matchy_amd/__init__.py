@@ -52,9 +52,9 @@ class _Matches(C.Structure):
 
 
 class _ScanHit(C.Structure):
-    _fields_ = [("start", C.c_uint64), ("end", C.c_uint64), ("item_type", C.c_uint8), ("kind", C.c_uint8),
-                ("prefix_len", C.c_uint8), ("_pad", C.c_uint8), ("data_offset", C.c_uint32), ("n_ids", C.c_uint32),
-                ("ids_index", C.c_uint32)]
+    # matchy_scan_hit_t (16 bytes): length in bits 0..23 of len_type, item type in bits 24..31
+    _fields_ = [("start", C.c_uint32), ("len_type", C.c_uint32), ("value", C.c_uint32), ("kind", C.c_uint8),
+                ("prefix_len", C.c_uint8), ("n_ids", C.c_uint16)]
 
 
 class _ScanResult(C.Structure):
@@ -292,10 +292,11 @@ class ScanResult:
             return out
         for i in range(r.n_hits):
             h = r.hits[i]
-            ids = [r.pattern_ids[h.ids_index + k] for k in range(h.n_ids)] if h.kind == 3 else []
-            offs = [r.data_offsets[h.ids_index + k] for k in range(h.n_ids)] if h.kind == 3 else []
-            out.append(dict(start=h.start, end=h.end, type=ITEM_TYPE_NAMES[h.item_type], kind="ip" if h.kind == 2 else "pattern",
-                            prefix_len=h.prefix_len, ip_data_offset=h.data_offset if h.kind == 2 else 0, ids=ids, offs=offs))
+            ids = [r.pattern_ids[h.value + k] for k in range(h.n_ids)] if h.kind == 3 else []
+            offs = [r.data_offsets[h.value + k] for k in range(h.n_ids)] if h.kind == 3 else []
+            out.append(dict(start=h.start, end=h.start + (h.len_type & 0xFFFFFF), type=ITEM_TYPE_NAMES[h.len_type >> 24],
+                            kind="ip" if h.kind == 2 else "pattern", prefix_len=h.prefix_len,
+                            ip_data_offset=h.value if h.kind == 2 else 0, ids=ids, offs=offs))
         return out
 
     def ndjson(self, text: bytes, source="-"):

@@ -138,9 +138,9 @@ matchy_t* open_bytes(std::vector<uint8_t>&& bytes) {
     catch (const std::exception& e) { set_error(e.what()); return nullptr; }
 }
 
-static_assert(sizeof(FinalHit) == sizeof(matchy_scan_hit_t) && offsetof(FinalHit, data_offset) == offsetof(matchy_scan_hit_t, data_offset) &&
-                  offsetof(FinalHit, ids_index) == offsetof(matchy_scan_hit_t, ids_index) && offsetof(FinalHit, kind) == offsetof(matchy_scan_hit_t, kind),
-              "k_pack writes matchy_scan_hit_t records");
+static_assert(sizeof(FinalHit) == sizeof(matchy_scan_hit_t) && sizeof(FinalHit) == 16 && offsetof(FinalHit, value) == offsetof(matchy_scan_hit_t, value) &&
+                  offsetof(FinalHit, n_ids) == offsetof(matchy_scan_hit_t, n_ids) && offsetof(FinalHit, kind) == offsetof(matchy_scan_hit_t, kind),
+              "k_pack writes matchy_scan_hit_t records directly");
 
 // Hand the dense records to the caller. borrowed=true: pointers go straight to the scanner's pinned buffers (no per-hit
 // host work at all); otherwise the arrays are copied into the result and optionally put into canonical order.
@@ -432,7 +432,7 @@ void matchy_scanner_get_timing(const matchy_scanner_t* s, float out[5]) {
 }
 
 int32_t matchy_scanner_scan(matchy_scanner_t* s, const uint8_t* data, size_t len, matchy_scan_result_t* out) {
-    if (!s || !out || (!data && len)) return MATCHY_ERROR_INVALID_PARAM;
+    if (!s || !out || (!data && len) || len > 0xFFFFFFFFull) return MATCHY_ERROR_INVALID_PARAM;
     ScannerH* h = reinterpret_cast<ScannerH*>(s);
     try {
         ScanOutput so;
@@ -473,7 +473,8 @@ char* matchy_scan_hit_to_json(const matchy_scanner_t* s, const matchy_scan_resul
     if (!s || !r || !text || i >= r->n_hits || !r->hits) return nullptr;
     const DbImage& img = reinterpret_cast<const ScannerH*>(s)->sc->image();
     const matchy_scan_hit_t& h = r->hits[i];
-    std::string matched((const char*)text + h.start, h.end - h.start), o = "{";
+    const uint32_t hlen = MATCHY_SCAN_HIT_LEN(h);
+    std::string matched((const char*)text + h.start, hlen), o = "{";
     if (h.kind == 2) {
         IpAddr ip;
         std::string cidr;
@@ -483,14 +484,14 @@ char* matchy_scan_hit_to_json(const matchy_scanner_t* s, const matchy_scan_resul
         o += "\"cidr\":"; json_escape(cidr, o);
         o += ",\"data\":";
         DataValue dv;
-        if (img.decode_data(h.data_offset, dv)) to_json(dv, o); else o += "null";
+        if (img.decode_data(h.value, dv)) to_json(dv, o); else o += "null";
         o += ",\"match_type\":\"ip\",\"matched_text\":"; json_escape(matched, o);
         o += ",\"prefix_len\":" + std::to_string((unsigned)h.prefix_len);
     } else {
         std::string arr;
         bool any = false;
         for (uint32_t k = 0; k < h.n_ids; ++k) {
-            int64_t off = r->data_offsets[h.ids_index + k];
+            int64_t off = r->data_offsets[h.value + k];
             if (off < 0) continue;
             if (any) arr.push_back(',');
             DataValue dv;

@@ -586,8 +586,8 @@ void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_
             const uint32_t id_shift = (uint32_t)fin_ids->size();
             for (size_t i = 0; i < part.n_fin; ++i) {
                 FinalHit h = part.fin[i];
-                h.start += pos; h.end += pos;
-                if (h.kind == 3) h.ids_index += id_shift;
+                h.start += (uint32_t)pos;   // len < 4 GiB is checked by the caller
+                if (h.kind == 3) h.value += id_shift;
                 fin->push_back(h);
             }
             fin_ids->insert(fin_ids->end(), part.fin_ids, part.fin_ids + part.n_fin_ids);

@@ -1207,14 +1207,13 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
             const uint32_t my_ids = ids0 + scan - nid;
             FinalHit f{};
             f.start = h.start;
-            f.end = (uint64_t)h.start + (h.len_type & 0xFFFFFF);
-            f.item_type = (uint8_t)(h.len_type >> 24);
+            f.len_type = h.len_type;
             f.kind = h.kind;
             f.prefix_len = h.prefix_len;
-            if (h.kind == 2) f.data_offset = h.a;
+            if (h.kind == 2) f.value = h.a;
             else {
-                f.n_ids = nid;
-                f.ids_index = my_ids;
+                f.n_ids = (uint16_t)nid;
+                f.value = my_ids;
                 uint32_t w = my_ids;
                 if (lit_off != 0xFFFFFFFFu) {
                     if (w < p.out_ids_cap) { p.out_ids[w] = h.a; p.out_offs[w] = (long long)lit_off; }

@@ -163,11 +163,11 @@ struct LookupParams {
 
 // Final hit record, bit-identical to matchy_scan_hit_t in include/matchy_amd.h (checked by static_assert in capi.cpp).
 struct FinalHit {
-    uint64_t start, end;
-    uint8_t item_type, kind, prefix_len, pad;
-    uint32_t data_offset;
-    uint32_t n_ids;
-    uint32_t ids_index;
+    uint32_t start;
+    uint32_t len_type;    // length | item type << 24
+    uint32_t value;       // IP: data offset; pattern: index of the first id
+    uint8_t kind, prefix_len;
+    uint16_t n_ids;
 };
 
 // k_pack: compacts the chunked hit list into dense FinalHit records and resolves pattern ids to data offsets.

@@ -23,7 +23,7 @@ __global__ void k_sort_keys(const FinalHit* fin, uint32_t n, unsigned long long*
     if (i >= n) return;
     const FinalHit h = fin[i];
     // start < 2^31 and length < 2^24 for one launch (engine.cpp checks the batch size)
-    keys[i] = ((unsigned long long)h.start << 32) | ((unsigned long long)d_type_rank(h.item_type) << 24) | ((h.end - h.start) & 0xFFFFFFull);
+    keys[i] = ((unsigned long long)h.start << 32) | ((unsigned long long)d_type_rank(h.len_type >> 24) << 24) | (h.len_type & 0xFFFFFFull);
     vals[i] = i;
 }
 
