@@ -374,7 +374,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     if (profile_) MXY_HIP(hipEventRecord(ev_[0], stream));
     launch_anchor(tp, ddb_->view, grid_tok, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[1], stream));
-    launch_validate(tp, ddb_->view, n_cu_ * gm[1], stream);
+    launch_validate(tp, ddb_->view, n_cu_ * gm[1], n_cu_, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
     bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
     if (rare_possible) launch_rare(tp, ddb_->view, n_cu_, stream);

@@ -16,7 +16,7 @@ namespace mxy {
 int anchor_blocks_per_cu();
 int validate_blocks_per_cu();
 void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
-void launch_validate(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
+void launch_validate(const TokParams& p, const DevDb& db, int grid, int n_cu, hipStream_t stream);
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_lookup(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_pack(const PackParams& p, int grid, hipStream_t stream);

@@ -176,11 +176,10 @@ __device__ __forceinline__ ByteMasks domain_masks(uint64_t x) {
 // bytes that alone is a public suffix, name no longer than the context — is decided with mask arithmetic on these
 // registers, without a per-byte loop and without divergent control flow (k_validate is bound by scalar-ALU issue, i.e.
 // by control flow): the rules of is_valid_domain (ext:637-689) become tests on the dot / dash / domain-char masks.
-// Everything else takes val_domain.
-__device__ __forceinline__ bool val_domain_pre(const LogView& lg, const DevDb& db, const uint32_t* bloom, const uint2* tldtab,
-                                               uint32_t min_labels, uint32_t j, uint2 w, uint64_t b0, uint64_t b1, uint64_t b2,
-                                               uint32_t& start, uint32_t& end, bool& in_ctx) {
-    in_ctx = false;
+// Everything else is left to the general path (val_domain, in k_validate).
+// Returns 0 (no domain), 1 (domain: start / end set, the whole name lies in the context) or 2 (undecided: general path).
+__device__ __forceinline__ int val_domain_pre(const uint2* tldtab, uint32_t min_labels, uint32_t j, uint2 w, uint64_t b0, uint64_t b1,
+                                              uint64_t b2, uint32_t& start, uint32_t& end) {
     constexpr uint64_t H = 0x8080808080808080ull;
     const uint64_t w64 = (uint64_t)w.x | ((uint64_t)w.y << 32);
     const ByteMasks mw = domain_masks(w64);
@@ -189,15 +188,15 @@ __device__ __forceinline__ bool val_domain_pre(const LogView& lg, const DevDb& d
     const uint32_t ll = ndc ? (uint32_t)(__ffsll((long long)ndc) - 1) >> 3 : 8u;
     if (ll <= 7 && ll >= 1) {
         const uint64_t below = (1ull << (8 * ll)) - 1ull;            // the label's bytes
-        if (mw.dot & below) return false;                            // a later dot owns this run
+        if (mw.dot & below) return 0;                                // a later dot owns this run
         const uint32_t stop_c = (uint32_t)(w64 >> (8 * ll)) & 0xFF;
-        if (!d_is_boundary(stop_c)) return false;
+        if (!d_is_boundary(stop_c)) return 0;
         const uint32_t lo = (uint32_t)(w64 & below), hi = (uint32_t)((w64 & below) >> 32);
         uint32_t slot = tld_tab_slot(lo, hi);
         bool alone = false;
         for (;;) {
             const uint2 t = tldtab[slot];
-            if ((t.y >> 24) == 0) return false;
+            if ((t.y >> 24) == 0) return 0;
             if (t.x == lo && (t.y & 0xFFFFFFu) == hi) { alone = (t.y >> 24) & 1; break; }
             slot = (slot + 1) & ((1u << TLD_TAB_BITS) - 1);
         }
@@ -232,19 +231,18 @@ __device__ __forceinline__ bool val_domain_pre(const LogView& lg, const DevDb& d
                 const uint32_t first_c = consumed < 24 ? (uint32_t)(fw >> (8 * (fi & 7))) & 0xFF : 0x100u;
                 const uint32_t lastc = (uint32_t)(w64 >> (8 * (ll - 1))) & 0xFF;
                 const bool any_bad = (bad | bad1 | bad2) != 0 || lastc == '-' || consumed == 0 || left_c == '.' || left_c == '-';
-                if (any_bad || ndots == 0 || 1 + ndots < min_labels) return false;
-                if (first_c != 0x100 && !d_is_boundary(first_c)) return false;
+                if (any_bad || ndots == 0 || 1 + ndots < min_labels) return 0;
+                if (first_c != 0x100 && !d_is_boundary(first_c)) return 0;
                 const uint32_t s_pos = j - consumed;
                 const bool high = ((m0.high & r0) | (m1.high & r1) | (m2.high & r2) | (mw.high & below)) != 0;
-                if (high && !d_valid_utf8(lg.p + s_pos, j + ll - s_pos)) return false;
+                if (high) return 2;   // needs the UTF-8 check of the general path
                 start = s_pos; end = j + ll;
-                in_ctx = true;   // the whole name lies inside the context record (starts at byte 24 - consumed)
-                return true;
+                return 1;
             }
             // the name reaches further back than the context: general path below
         }
     }
-    return val_domain(lg, db, bloom, tldtab, min_labels, j, start, end);
+    return 2;
 }
 
 __device__ bool all_hex(const LogView& lg, uint32_t s, uint32_t n) {
@@ -611,109 +609,120 @@ __device__ bool val_eth(const uint8_t* a, uint8_t* lower) {  // ext:1328-1361, 1
     return true;
 }
 
-// k_validate — stage A2: one lane per domain / IPv6 / e-mail anchor and per long token written by k_anchor.
-__global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
-    // LDS: the TLD Bloom filter and the exact short-label table for the domain loop; the same bytes are reused
-    // afterwards as one 80-byte window per lane for the IPv6 validator
-    __shared__ __attribute__((aligned(16))) uint8_t smem[TLD_BLOOM_WORDS * 4 + (8u << TLD_TAB_BITS)];
-    static_assert(sizeof(smem) >= 256 * 80, "IPv6 windows alias the tables");
-    uint32_t* bloom = reinterpret_cast<uint32_t*>(smem);
-    uint2* tldtab = reinterpret_cast<uint2*>(smem + TLD_BLOOM_WORDS * 4);
-    for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += blockDim.x) bloom[i] = db.tld_bloom[i];
+// k_validate_dom — stage A2a: one lane per domain anchor with its context record (planes written by k_anchor, read
+// coalesced). Lean on purpose (no general walk, no global log reads): it is latency-bound, so its speed is the number of
+// resident waves. Anchors it cannot decide (no context, last label > 7 bytes or not a suffix on its own, name longer than
+// the context, non-ASCII) go to the rare list as RARE_DOM for k_validate.
+__global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
+    __shared__ uint2 tldtab[1u << TLD_TAB_BITS];
+    __shared__ __attribute__((aligned(16))) uint32_t strbuf[256][8];   // per-lane context bytes for hashing
     for (uint32_t i = threadIdx.x; i < (1u << TLD_TAB_BITS); i += blockDim.x) tldtab[i] = db.tld_tab[i];
     __syncthreads();
-    LogView lg{p.log, p.len};
     // candidates: dense when every valid domain is listed (chunks of CAND_CHUNK), sparse otherwise (chunks of 64 keep
     // the list free of padding for k_lookup)
     ChunkWriter<Candidate, CAND_CHUNK> cw_dense;
     ChunkWriter<Candidate, 64> cw;
+    ChunkWriter<RareAnchor, RARE_CHUNK> sw;   // undecided anchors -> rare list
     const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
+    const RareAnchor SR{0xFFFFFFFFu, 0xFFu};
     const uint32_t stride = gridDim.x * blockDim.x;
-    __shared__ __attribute__((aligned(16))) uint32_t strbuf[256][8];   // per-lane context bytes for hashing
-    uint32_t dom_listed = 0;   // domain candidates this wave put on the list (they are counted separately)
-    // Domain anchors with their context records (planes written by k_anchor, read coalesced), software-pipelined: the
-    // record of the next iteration is loaded while the current one is validated.
     const uint32_t nd = min(p.counters->n_dom, p.dom_cap);
+    struct Rec { uint32_t j; uint32_t c[8]; };
+    auto load_rec = [&](uint32_t i, Rec& r) {
+        r.j = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r.c[k] = 0;
+        if (i < nd) {
+            r.j = p.dom_list[dom_plane_index(i, 0)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r.c[k] = p.dom_list[dom_plane_index(i, 1 + k)];
+        }
+    };
+    Rec cur, nxt;
+    load_rec(blockIdx.x * blockDim.x + threadIdx.x, cur);
     {
-        struct Rec { uint32_t j; uint32_t c[8]; };
-        auto load_rec = [&](uint32_t i, Rec& r) {
-            r.j = 0xFFFFFFFFu;
+        // consume the first record here, so that inside the loop no wait is placed between the store at the top of an
+        // iteration and the first use of `cur` (the wait would also cover that store)
+        uint32_t g = cur.j;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) r.c[k] = 0;
-            if (i < nd) {
-                r.j = p.dom_list[dom_plane_index(i, 0)];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) r.c[k] = p.dom_list[dom_plane_index(i, 1 + k)];
-            }
-        };
-        Rec cur, nxt;
-        load_rec(blockIdx.x * blockDim.x + threadIdx.x, cur);
-        {
-            // consume the first record here, so that inside the loop no wait is placed between the store at the top of
-            // an iteration and the first use of `cur` (the wait would also cover that store)
-            uint32_t g = cur.j;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) g ^= cur.c[k];
-            asm volatile("" ::"v"(g));
-        }
-        // The candidate of iteration k is stored at the top of iteration k+1, before the next loads are issued: the
-        // wait for those loads (vmcnt counts loads and stores in order) then never waits for a store in flight. The
-        // same delay gives the literal-bitmap load (p.filter_lit) a whole iteration to arrive.
-        uint32_t pend_start = 0, pend_lt = 0, pend_word = 0xFFFFFFFFu, pend_bit = 0, n_valid = 0;
-        bool pend = false;
-        uint32_t* sb = strbuf[threadIdx.x];
-        for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
-            const uint32_t i = base + threadIdx.x;
-            if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
-            else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
-            pend = false;
-            load_rec(i + stride, nxt);
-            if (cur.j != 0xFFFFFFFFu) {
-                uint32_t s = 0, e = 0;
-                bool ok, in_ctx = false;
-                if (!(cur.j & 0x80000000u)) {
-                    const uint64_t b2 = (uint64_t)cur.c[0] | ((uint64_t)cur.c[1] << 32), b1 = (uint64_t)cur.c[2] | ((uint64_t)cur.c[3] << 32),
-                                   b0 = (uint64_t)cur.c[4] | ((uint64_t)cur.c[5] << 32);
-                    ok = val_domain_pre(lg, db, bloom, tldtab, p.min_labels, cur.j, make_uint2(cur.c[6], cur.c[7]), b0, b1, b2, s, e, in_ctx);
-                } else {
-                    ok = val_domain(lg, db, bloom, tldtab, p.min_labels, cur.j & 0x7FFFFFFFu, s, e);
-                }
-                if (ok) {
-                    pend_start = s; pend_lt = (e - s) | ((uint32_t)IT_DOMAIN << 24); pend = true;
-                    pend_word = 0xFFFFFFFFu; pend_bit = 0;
-                    n_valid += 1;
-                    if (p.filter_lit && in_ctx) {
-                        // XXH64 of the name straight from the context record (no second read of the log): the 32
-                        // context bytes go through a per-lane LDS buffer to get the name aligned to 8-byte lanes
-                        *reinterpret_cast<uint4*>(sb) = make_uint4(cur.c[0], cur.c[1], cur.c[2], cur.c[3]);
-                        *reinterpret_cast<uint4*>(sb + 4) = make_uint4(cur.c[4], cur.c[5], cur.c[6], cur.c[7]);
-                        const uint32_t o = 24 - (cur.j - s), n = e - s;   // offset and length of the name in the context
-                        const uint32_t i0 = o >> 2, sh = o & 3;
-                        uint32_t wd[9];
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) wd[k] = (i0 + k) < 8 ? sb[(i0 + k) & 7] : 0u;
-                        uint64_t ln[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            ln[k] = (uint64_t)__builtin_amdgcn_alignbyte(wd[2 * k + 1], wd[2 * k], sh) |
-                                    ((uint64_t)__builtin_amdgcn_alignbyte(wd[2 * k + 2], wd[2 * k + 1], sh) << 32);
-                        const uint64_t h = xxh64_lanes31(ln[0], ln[1], ln[2], ln[3], n);
-                        const uint32_t b = lit_bm_bit(h) & db.lit_bm_mask;
-                        pend_word = db.lit_bm ? db.lit_bm[b >> 5] : 0u;
-                        pend_bit = b & 31;
-                    }
-                }
-            }
-            cur = nxt;
-        }
+        for (int k = 0; k < 8; ++k) g ^= cur.c[k];
+        asm volatile("" ::"v"(g));
+    }
+    // The candidate of iteration k is stored at the top of iteration k+1, before the next loads are issued: the wait for
+    // those loads (vmcnt counts loads and stores in order) then never waits for a store in flight. The same delay gives
+    // the literal-bitmap load (p.filter_lit) a whole iteration to arrive.
+    uint32_t pend_start = 0, pend_lt = 0, pend_word = 0xFFFFFFFFu, pend_bit = 0, n_valid = 0;
+    bool pend = false;
+    uint32_t* sb = strbuf[threadIdx.x];
+    for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
+        const uint32_t i = base + threadIdx.x;
         if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
         else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
-        // validated domain candidates, listed or not
+        pend = false;
+        load_rec(i + stride, nxt);
+        bool slow = false;
+        if (cur.j != 0xFFFFFFFFu) {
+            uint32_t s = 0, e = 0;
+            int r = 2;
+            if (!(cur.j & 0x80000000u)) {
+                const uint64_t b2 = (uint64_t)cur.c[0] | ((uint64_t)cur.c[1] << 32), b1 = (uint64_t)cur.c[2] | ((uint64_t)cur.c[3] << 32),
+                               b0 = (uint64_t)cur.c[4] | ((uint64_t)cur.c[5] << 32);
+                r = val_domain_pre(tldtab, p.min_labels, cur.j, make_uint2(cur.c[6], cur.c[7]), b0, b1, b2, s, e);
+            }
+            slow = r == 2;
+            if (r == 1) {
+                pend_start = s; pend_lt = (e - s) | ((uint32_t)IT_DOMAIN << 24); pend = true;
+                pend_word = 0xFFFFFFFFu; pend_bit = 0;
+                n_valid += 1;
+                if (p.filter_lit) {
+                    // XXH64 of the name straight from the context record (no second read of the log): the 32 context
+                    // bytes go through a per-lane LDS buffer to get the name aligned to 8-byte lanes
+                    *reinterpret_cast<uint4*>(sb) = make_uint4(cur.c[0], cur.c[1], cur.c[2], cur.c[3]);
+                    *reinterpret_cast<uint4*>(sb + 4) = make_uint4(cur.c[4], cur.c[5], cur.c[6], cur.c[7]);
+                    const uint32_t o = 24 - (cur.j - s), n = e - s;   // offset and length of the name in the context
+                    const uint32_t i0 = o >> 2, sh = o & 3;
+                    uint32_t wd[9];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
-        if (lane_id() == 0 && n_valid) atomicAdd(&p.counters->cand_true, n_valid);
-        dom_listed = cw.total;   // (cw_dense holds domain candidates only)
+                    for (int k = 0; k < 9; ++k) wd[k] = (i0 + k) < 8 ? sb[(i0 + k) & 7] : 0u;
+                    uint64_t ln[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        ln[k] = (uint64_t)__builtin_amdgcn_alignbyte(wd[2 * k + 1], wd[2 * k], sh) |
+                                ((uint64_t)__builtin_amdgcn_alignbyte(wd[2 * k + 2], wd[2 * k + 1], sh) << 32);
+                    const uint64_t h = xxh64_lanes31(ln[0], ln[1], ln[2], ln[3], n);
+                    const uint32_t b = lit_bm_bit(h) & db.lit_bm_mask;
+                    pend_word = db.lit_bm ? db.lit_bm[b >> 5] : 0u;
+                    pend_bit = b & 31;
+                }
+            }
+        }
+        sw.append(slow, RareAnchor{cur.j & 0x7FFFFFFFu, (uint32_t)RARE_DOM}, p.rare, p.rare_cap, &p.counters->n_rare, SR);
+        cur = nxt;
     }
+    if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+    else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+    sw.pad_rest(p.rare, p.rare_cap, SR);
+    cw.pad_rest(p.cands, p.cand_cap, SC);
+    cw_dense.pad_rest(p.cands, p.cand_cap, SC);
+    // validated domain candidates, listed or not
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
+    if (lane_id() == 0 && n_valid) atomicAdd(&p.counters->cand_true, n_valid);
+}
+
+// k_validate — stage A2b: one lane per long token (hex hashes; prefix tests for the address formats) and per rare
+// anchor: IPv6, e-mail, and the domain anchors k_validate_dom could not decide (general right-to-left walk).
+__global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
+    __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
+    __shared__ uint2 tldtab[1u << TLD_TAB_BITS];
+    __shared__ __attribute__((aligned(16))) uint8_t winbuf[256 * 80];   // one 80-byte IPv6 window per lane
+    for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += blockDim.x) bloom[i] = db.tld_bloom[i];
+    for (uint32_t i = threadIdx.x; i < (1u << TLD_TAB_BITS); i += blockDim.x) tldtab[i] = db.tld_tab[i];
+    __syncthreads();
+    LogView lg{p.log, p.len};
+    ChunkWriter<Candidate, 64> cw;
+    const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
+    const uint32_t stride = gridDim.x * blockDim.x;
     // Long tokens: hex hashes are decided here; the checksum validators (Base58Check, Bech32, EIP-55, Monero) need
     // SHA-256 / Keccak and hundreds of registers, so tokens that pass their cheap prefix tests go to the `heavy` list
     // for k_rare. A token made of non-boundary bytes may contain high bytes; every accepted form is pure ASCII, so the
@@ -754,8 +763,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     }
     // IPv6 ("::") and e-mail ('@') anchors from the rare list. The IPv6 parser reads its bytes many times: each lane
     // copies log[p2-40, p2+40) into its LDS window with five wide loads first.
-    __syncthreads();  // every wave of the block is done with the tables that the windows overwrite
-    uint8_t* win = smem + threadIdx.x * 80;
+    uint8_t* win = winbuf + threadIdx.x * 80;
     const uint32_t nr = min(p.counters->n_rare, p.rare_cap);
     for (uint32_t base = blockIdx.x * blockDim.x; base < nr; base += stride) {
         const uint32_t i = base + threadIdx.x;
@@ -782,13 +790,15 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         } else if (kind == RARE_AT) {
             uint32_t s, e;
             if (val_email(lg, db, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_EMAIL << 24); emit = true; }
+        } else if (kind == RARE_DOM) {
+            uint32_t s, e;
+            if (val_domain(lg, db, bloom, tldtab, p.min_labels, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true; }
         }
         cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     }
     hw.pad_rest(p.heavy, p.heavy_cap, SH);
     cw.pad_rest(p.cands, p.cand_cap, SC);
-    cw_dense.pad_rest(p.cands, p.cand_cap, SC);
-    if (lane_id() == 0 && cw.total > dom_listed) atomicAdd(&p.counters->cand_true, cw.total - dom_listed);
+    if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
 }
 
 // k_rare — stage A3: checksum validators (Base58Check, Bech32, EIP-55, Monero): very rare in logs and heavy in
@@ -1239,11 +1249,13 @@ void launch_pack(const PackParams& p, int grid, hipStream_t stream) {
 }
 int validate_blocks_per_cu() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate, 256, 0) != hipSuccess || n < 1) n = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate_dom, 256, 0) != hipSuccess || n < 1) n = 4;
     return n;
 }
-void launch_validate(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_validate, dim3(grid), dim3(256), 0, stream, p, db);
+// grid = workgroups of k_validate_dom; k_validate (rare anchors, tokens) has a fraction of the work
+void launch_validate(const TokParams& p, const DevDb& db, int grid, int n_cu, hipStream_t stream) {
+    if (p.flags & EX_DOMAINS) hipLaunchKernelGGL(k_validate_dom, dim3(grid), dim3(256), 0, stream, p, db);
+    hipLaunchKernelGGL(k_validate, dim3(n_cu * 2), dim3(256), 0, stream, p, db);
 }
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_rare, dim3(grid), dim3(64), 0, stream, p, db);

@@ -26,7 +26,7 @@ struct Candidate {
 };
 
 // Anchors that need the rare-path validators (IPv6, e-mail, hash / crypto tokens), 8 bytes.
-enum RareKind : uint32_t { RARE_V6 = 0, RARE_AT = 1, RARE_TOK = 2, HEAVY_B58 = 3, HEAVY_BECH32 = 4, HEAVY_ETH = 5, HEAVY_XMR = 6 };
+enum RareKind : uint32_t { RARE_V6 = 0, RARE_AT = 1, RARE_TOK = 2, HEAVY_B58 = 3, HEAVY_BECH32 = 4, HEAVY_ETH = 5, HEAVY_XMR = 6, RARE_DOM = 7 };
 struct RareAnchor {
     uint32_t pos;       // RARE_V6: index of the 2nd ':' of a "::"; RARE_AT: index of '@'; RARE_TOK: token start
     uint32_t len_kind;  // RareKind in bits 0..7, token length in bits 8..31
