@@ -56,6 +56,7 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) -
 // the number of atomics on the shared list counter ~CHUNK/64 times lower than one atomic per append.
 template <class T, uint32_t CHUNK>
 struct ChunkWriter {
+    static_assert(CHUNK >= 64, "one append can carry 64 entries");
     uint32_t base = 0xFFFFFFFFu;  // wave-uniform; 0xFFFFFFFF = no chunk yet
     uint32_t used = 0;
     uint32_t total = 0;           // entries really appended by this wave

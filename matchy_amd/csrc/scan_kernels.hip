@@ -16,6 +16,8 @@
 // against oracle/.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "hashes.h"
 #include "scan_types.h"
 
@@ -1255,7 +1257,8 @@ int validate_blocks_per_cu() {
 // grid = workgroups of k_validate_dom; k_validate (rare anchors, tokens) has a fraction of the work
 void launch_validate(const TokParams& p, const DevDb& db, int grid, int n_cu, hipStream_t stream) {
     if (p.flags & EX_DOMAINS) hipLaunchKernelGGL(k_validate_dom, dim3(grid), dim3(256), 0, stream, p, db);
-    hipLaunchKernelGGL(k_validate, dim3(n_cu * 2), dim3(256), 0, stream, p, db);
+    static const int misc_mult = getenv("MATCHY_AMD_MISC_GRID") ? atoi(getenv("MATCHY_AMD_MISC_GRID")) : 2;
+    hipLaunchKernelGGL(k_validate, dim3(n_cu * (misc_mult > 0 ? misc_mult : 2)), dim3(256), 0, stream, p, db);
 }
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_rare, dim3(grid), dim3(64), 0, stream, p, db);
