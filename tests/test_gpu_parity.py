@@ -238,3 +238,108 @@ def test_concurrent_queries_and_scans(M, oracle):
         th.join(timeout=300)
     assert not errors, errors[:5]
     db.close()
+
+
+@pytest.mark.parametrize("seed", [42, 7, 20251212])
+def test_domain_rules_structured_fuzz(M, oracle, seed):
+    """Structure-aware differential fuzz of the domain rules (labels with dashes, empty labels, high bytes, long names,
+    real and fake TLDs, every kind of delimiter): exercises the mask-arithmetic fast path of k_validate_dom, its hand-over
+    to the general walk, and the literal bitmap (scan against a database that contains some of the generated names)."""
+    rng = random.Random(seed)
+    tlds = [b"com", b"net", b"org", b"io", b"co.uk", b"uk", b"ck", b"www.ck", b"za", b"co.za", b"html", b"zip", b"museum", b"photography",
+            b"xn--p1ai", b"a", b"comx", b"c-m", b"", "рф".encode(), b"COM", b"travel", b"b\xc3\xbccher"]
+    alpha = b"abcdefghijklmnopqrstuvwxyz0123456789"
+    delims = [b" ", b"\n", b"/", b",", b"(", b")", b"\"", b"=", b":", b";", b"<", b">", b"[", b"x", b"_", b"-", b".", b"", b"\t", b"'", b"@", b"\xff"]
+
+    def label():
+        r = rng.random()
+        n = rng.choice([1, 1, 2, 3, 5, 8, 13, 24, 40])
+        s = bytes(rng.choice(alpha) for _ in range(n))
+        if r < 0.08:
+            s = b"-" + s
+        elif r < 0.16:
+            s = s + b"-"
+        elif r < 0.22:
+            s = s[: n // 2] + b"-" + s[n // 2:]
+        elif r < 0.26:
+            s = b""
+        elif r < 0.30:
+            s = s + "é".encode()
+        elif r < 0.32:
+            s = s + b"\xc3"          # truncated UTF-8
+        elif r < 0.36:
+            s = s.upper()
+        return s
+
+    names = []
+    for _ in range(6000):
+        k = rng.choice([0, 1, 1, 2, 2, 3, 5])
+        parts = [label() for _ in range(k)] + [rng.choice(tlds)]
+        names.append(b".".join(parts))
+    buf = bytearray()
+    for nm in names:
+        buf += rng.choice(delims) + nm + rng.choice(delims)
+        if rng.random() < 0.1:
+            buf += b"q" * rng.choice([1, 7, 23, 24, 25, 100])
+    buf = bytes(buf)
+    ex = M.Extractor()
+    got, want = ex.extract_from_chunk(buf), oracle.extract(buf)
+    ex.close()
+    assert len(got) == len(want)
+    assert got == want
+    # lookup path: database with a sample of the valid names (+ one IP so that the trie exists)
+    valid = sorted({v for t, s, e, v in want if t == "Domain"})
+    assert len(valid) > 300
+    b = M.DatabaseBuilder(build_epoch=3)
+    for v in valid[::5]:
+        b.add_entry("literal:" + v, {"n": len(v)})
+    b.add_entry("192.0.2.1", {"ip": True})
+    blob = b.build()
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, buf)
+    assert gs == ws and gh == wh and gl == wl
+    assert len(gh) >= len(valid[::5])
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_ipv4_structured_fuzz(M, oracle, seed):
+    """Dotted-quad look-alikes with every kind of octet (leading zeros, > 255, 1-4 digits, missing / extra octets) and
+    delimiter, packed densely so that windows straddle the kernel's blocks; then scanned against a CIDR-heavy database
+    (exercises the first-level table, the /24 bitmap and the prefix-length quirk)."""
+    rng = random.Random(seed)
+    delims = [b" ", b"\n", b"/", b",", b":", b"[", b"]", b"=", b"x", b".", b"", b"-", b"\"", b"a", b"1"]
+
+    def octet():
+        r = rng.random()
+        if r < 0.55:
+            return str(rng.randrange(256)).encode()
+        if r < 0.65:
+            return str(rng.randrange(256, 1000)).encode()
+        if r < 0.75:
+            return b"0" + str(rng.randrange(100)).encode()
+        if r < 0.80:
+            return b""
+        if r < 0.85:
+            return str(rng.randrange(1000, 100000)).encode()
+        return rng.choice([b"0", b"00", b"255", b"256", b"1", b"10", b"192", b"168"])
+
+    buf = bytearray()
+    for _ in range(8000):
+        k = rng.choice([2, 3, 4, 4, 4, 4, 5, 6])
+        buf += rng.choice(delims) + b".".join(octet() for _ in range(k)) + rng.choice(delims)
+    buf = bytes(buf)
+    ex = M.Extractor()
+    got, want = ex.extract_from_chunk(buf), oracle.extract(buf)
+    ex.close()
+    assert got == want
+    ips = sorted({v for t, s, e, v in want if t == "IPv4"})
+    assert len(ips) > 200
+    b = M.DatabaseBuilder(build_epoch=4)
+    for i, ip in enumerate(ips[::7]):
+        a = ip.split(".")
+        pfx = rng.choice([32, 32, 24, 16, 27, 12, 30])
+        b.add_entry(ip if pfx == 32 else f"{ip}/{pfx}", {"i": i, "p": pfx})
+    b.add_entry("0.0.0.0/5", {"wide": True})
+    blob = b.build()
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, buf)
+    assert gs == ws and gh == wh and gl == wl
+    assert len(gh) > 40
