@@ -147,6 +147,23 @@ __device__ inline bool d_valid_utf8(const uint8_t* s, uint32_t n) {
     return true;
 }
 
+// Byte-class masks of 8 log bytes at once (SWAR; bit 7 of each byte of the result is the class bit, all other bits 0).
+// Every addend keeps each byte below 0x100, so no carry crosses a byte.
+struct ByteMasks { uint64_t dc, dot, dash, high; };
+__device__ __forceinline__ ByteMasks domain_masks(uint64_t x) {
+    constexpr uint64_t H = 0x8080808080808080ull, L7 = 0x7F7F7F7F7F7F7F7Full;
+    const uint64_t t = x & L7, l = t | 0x2020202020202020ull;
+    const uint64_t dig = (t + 0x5050505050505050ull) & ~(t + 0x4646464646464646ull);   // '0'..'9'
+    const uint64_t alp = (l + 0x1F1F1F1F1F1F1F1Full) & ~(l + 0x0505050505050505ull);   // 'a'..'z' after case folding
+    const uint64_t ndot = (t ^ 0x2E2E2E2E2E2E2E2Eull) + L7, ndash = (t ^ 0x2D2D2D2D2D2D2D2Dull) + L7;  // bit 7 set iff different
+    ByteMasks m;
+    m.high = x & H;
+    m.dot = ~ndot & ~x & H;
+    m.dash = ~ndash & ~x & H;
+    m.dc = (((dig | alp) & ~x) | m.dot | m.dash | m.high) & H;  // DOMAIN_CHAR_LOOKUP (ext:1597-1629)
+    return m;
+}
+
 // ------------------------------------------------------------------------------------------------ IPv4
 // IPv4 dotted-quad rules (ext:813-869, 1120-1179) on a 20-byte window held in registers: q = bytes [dot-4, dot+12),
 // t4 = bytes [dot+12, dot+16), `dot` = position of the first dot of the run. Emits iff the maximal [0-9.] run around

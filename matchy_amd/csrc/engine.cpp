@@ -91,6 +91,14 @@ PslHost* load_psl() {
         size_t ll = s.size() - (dot == std::string::npos ? 0 : dot + 1);
         uint32_t bit = tld_hash(last, ll);
         h->bloom[bit >> 5] |= 1u << (bit & 31);
+        if (ll >= 1 && ll <= 8) {  // second hash used by k_anchor's prefilter (labels that fit its 8-byte window)
+            uint8_t k8[8] = {0};
+            memcpy(k8, last, ll);
+            uint32_t lo8, hi8;
+            memcpy(&lo8, k8, 4); memcpy(&hi8, k8 + 4, 4);
+            const uint32_t b8 = tld_hash8(lo8, hi8) & (TLD_BLOOM_BITS - 1);
+            h->bloom[b8 >> 5] |= 1u << (b8 & 31);
+        }
         h->max_tld_len = std::max<uint32_t>(h->max_tld_len, (uint32_t)ll);
         if (ll) h->tld_first[last[0] >> 5] |= 1u << (last[0] & 31);
     }

@@ -131,6 +131,14 @@ MXY_HD uint64_t fx_u32(uint32_t v) { return rotl64((uint64_t)v * 0xf1357aea2e62a
 constexpr uint32_t TLD_TAB_BITS = 11;
 MXY_HD uint32_t tld_tab_slot(uint32_t lo, uint32_t hi24) { return ((lo ^ (hi24 * 0x9E3779B1u)) * 0x85EBCA6Bu) >> (32 - TLD_TAB_BITS); }
 
+// Bloom-filter bit (before masking) of a last label of <= 8 bytes packed little-endian in lo / hi (zero padded); the
+// streaming kernel's prefilter uses this two-multiply hash, longer labels use the byte-wise one (tld_hash_step).
+MXY_HD uint32_t tld_hash8(uint32_t lo, uint32_t hi) {
+    uint32_t h = (lo * 0x9E3779B1u) ^ (hi * 0x85EBCA6Bu);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15;   // finaliser: the low bits of a product only depend on low input bits
+    return h;
+}
+
 MXY_HD uint64_t psl_hash_init() { return 0xcbf29ce484222325ULL; }
 MXY_HD uint64_t psl_hash_step(uint64_t h, uint8_t b) { return (h ^ b) * 0x100000001b3ULL; }
 MXY_HD uint64_t psl_hash_finish(uint64_t h) { h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ULL; h ^= h >> 32; return h; }

@@ -131,20 +131,21 @@ __device__ __forceinline__ void drain_dom(const uint32_t* ring, uint32_t& head, 
         if (j >= cx.res_lo + 24 && j + 8 <= cx.res_hi) {
             raw_read<8>(cx.raw32, j - 24, ctx);   // log[j-24, j+8): the last label starts at byte 24
             have_ctx = true;
-            uint32_t th = 2166136261u, stop = 0;
-            bool open = true;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (open) {
-                    const uint32_t c = ((k < 4 ? ctx[6] : ctx[7]) >> (8 * (k & 3))) & 0xFF;
-                    if (!d_is_domain_char_fast(c)) { open = false; stop = c; }
-                    else if (c == '.') { open = false; keep = false; stop = ' '; }
-                    else th = tld_hash_step(th, c);
-                }
-            }
-            if (keep && !open) {
-                const uint32_t bit = tld_hash_bit(th);
-                keep = d_is_boundary(stop) && ((cx.bloom[bit >> 5] >> (bit & 31)) & 1);
+            // the label's 8-byte window as SWAR masks (no per-byte loop, no divergent control flow)
+            constexpr uint64_t H = 0x8080808080808080ull;
+            const uint64_t w64 = (uint64_t)ctx[6] | ((uint64_t)ctx[7] << 32);
+            const ByteMasks mw = domain_masks(w64);
+            const uint64_t ndc = ~mw.dc & H;
+            if (ndc) {   // the label ends inside the window: ll = its length (>= 1: byte j can start a TLD)
+                const uint32_t ll = (uint32_t)(__ffsll((long long)ndc) - 1) >> 3;
+                const uint64_t below = (1ull << (8 * ll)) - 1ull;
+                const uint32_t stop = (uint32_t)(w64 >> (8 * ll)) & 0xFF;
+                const uint32_t bit = tld_hash8((uint32_t)(w64 & below), (uint32_t)((w64 & below) >> 32)) & (TLD_BLOOM_BITS - 1);
+                // a '.' inside the label: a later dot owns the run; the run must end at a boundary; the label must be
+                // some public suffix's last label
+                keep = (mw.dot & below) == 0 && d_is_boundary(stop) && ((cx.bloom[bit >> 5] >> (bit & 31)) & 1);
+            } else {
+                keep = mw.dot == 0;   // 8 domain chars: undecided unless a later dot already shows up
             }
         }
     }

@@ -156,23 +156,6 @@ __device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* b
     return true;
 }
 
-// Byte-class masks of 8 log bytes at once (SWAR; bit 7 of each byte of the result is the class bit, all other bits 0).
-// Every addend keeps each byte below 0x100, so no carry crosses a byte.
-struct ByteMasks { uint64_t dc, dot, dash, high; };
-__device__ __forceinline__ ByteMasks domain_masks(uint64_t x) {
-    constexpr uint64_t H = 0x8080808080808080ull, L7 = 0x7F7F7F7F7F7F7F7Full;
-    const uint64_t t = x & L7, l = t | 0x2020202020202020ull;
-    const uint64_t dig = (t + 0x5050505050505050ull) & ~(t + 0x4646464646464646ull);   // '0'..'9'
-    const uint64_t alp = (l + 0x1F1F1F1F1F1F1F1Full) & ~(l + 0x0505050505050505ull);   // 'a'..'z' after case folding
-    const uint64_t ndot = (t ^ 0x2E2E2E2E2E2E2E2Eull) + L7, ndash = (t ^ 0x2D2D2D2D2D2D2D2Dull) + L7;  // bit 7 set iff different
-    ByteMasks m;
-    m.high = x & H;
-    m.dot = ~ndot & ~x & H;
-    m.dash = ~ndash & ~x & H;
-    m.dc = (((dig | alp) & ~x) | m.dot | m.dash | m.high) & H;  // DOMAIN_CHAR_LOOKUP (ext:1597-1629)
-    return m;
-}
-
 // The same for an anchor that comes with its context record (k_anchor copies log[j-24, j+8) from its LDS window):
 // w = log[j, j+8), b0 = log[j-8, j), b1 = log[j-16, j-8), b2 = log[j-24, j-16). The common case — last label of <= 7
 // bytes that alone is a public suffix, name no longer than the context — is decided with mask arithmetic on these
