@@ -288,12 +288,21 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             // ---- every anchor pattern for the lane's 16 positions (SWAR on bit 0 of each byte, 4 dwords); the flags of
             // dword k go to bit k of each byte: bit (8 b + k) <-> position 4 k + b
             uint32_t Fd = 0, F4 = 0, Fm = 0, bl[4], A1s[4];
+            // byte-shifted views shared by neighbouring dwords: S1[k] = classes of positions (4k-3 .. 4k) seen from dword
+            // k-1/k, i.e. v_alignbyte(X[k+1], X[k], 1); the look-ahead views of dword k are the look-back views of k+1
+            uint32_t S1[5], S2[5], S3[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                S1[k] = __builtin_amdgcn_alignbyte(X[k + 1], X[k], 1);
+                S2[k] = __builtin_amdgcn_alignbyte(X[k + 1], X[k], 2);
+                S3[k] = __builtin_amdgcn_alignbyte(X[k + 1], X[k], 3);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t A = X[k + 1], P = X[k], N = X[k + 2];
-                const uint32_t A1 = __builtin_amdgcn_alignbyte(A, P, 3);  // classes of positions pos-1 .. pos+2
-                const uint32_t A2 = __builtin_amdgcn_alignbyte(A, P, 2);  // pos-2 .. pos+1
-                const uint32_t A3 = __builtin_amdgcn_alignbyte(A, P, 1);  // pos-3 .. pos
+                const uint32_t A1 = S3[k];  // classes of positions pos-1 .. pos+2
+                const uint32_t A2 = S2[k];  // pos-2 .. pos+1
+                const uint32_t A3 = S1[k];  // pos-3 .. pos
                 bl[k] = A & LSB;
                 A1s[k] = A1;
                 // domain: TLD1 at j (bit 7), '.' at j-1 (bit 2), label byte at j-2 (bit 5)
@@ -303,8 +312,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                     uint32_t f = (A >> 2) & (A1 >> 1) & (A2 | ((A2 >> 1) & (A3 | ((A3 >> 1) & P)))) & LSB;
                     // ... and followed by a second octet and a second dot: digit, then '.' | digit,'.' | digit,digit,'.'
                     // (necessary for a dotted quad; drops "HTTP/1.1", "Mozilla/5.0", "Safari/537.36" style anchors)
-                    const uint32_t F1 = __builtin_amdgcn_alignbyte(N, A, 1), F2 = __builtin_amdgcn_alignbyte(N, A, 2),
-                                   F3 = __builtin_amdgcn_alignbyte(N, A, 3);
+                    const uint32_t F1 = S1[k + 1], F2 = S2[k + 1], F3 = S3[k + 1];  // pos+1 .., pos+2 .., pos+3 ..
                     f &= (F1 >> 1) & ((F2 >> 2) | ((F2 >> 1) & ((F3 >> 2) | ((F3 >> 1) & (N >> 2)))));
                     F4 |= f << k;
                 }
