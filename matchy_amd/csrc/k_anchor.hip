@@ -82,14 +82,27 @@ __device__ __forceinline__ void commit_v4(PendingV4& pd, const WaveCtx& cx, Chun
     pd.ok = false;
 }
 
-__device__ __forceinline__ void drain_v4(const uint32_t* ring, uint32_t& head, uint32_t n, const WaveCtx& cx, PendingV4& pd,
-                                         ChunkWriter<Candidate, V4_CHUNK>& cw) {
+__device__ __forceinline__ void drain_v4(uint32_t* ring, uint32_t& head, uint32_t& tail, uint32_t n, bool final, const WaveCtx& cx,
+                                         PendingV4& pd, ChunkWriter<Candidate, V4_CHUNK>& cw) {
     const uint32_t lane = lane_id();
     const TokParams& p = *cx.p;
     commit_v4(pd, cx, cw);
     __builtin_amdgcn_wave_barrier();
-    if (lane < n) {
-        const uint32_t dot = ring[(head + lane) & (QCAP - 1)];
+    const bool have = lane < n;
+    uint32_t dot = 0;
+    if (have) dot = ring[(head + lane) & (QCAP - 1)];
+    head += n;
+    // an anchor in the last bytes of the newest block has its look-ahead in the block that is not staged yet: it goes
+    // back into the ring and is validated by a later drain (without this nearly every drain would drag one lane
+    // through the global-memory fallback below)
+    const bool later = have && !final && dot + 16 > cx.res_hi;
+    const uint64_t rm = __ballot(later);
+    if (rm) {
+        __builtin_amdgcn_wave_barrier();
+        if (later) ring[(tail + mbcnt64(rm)) & (QCAP - 1)] = dot;
+        tail += (uint32_t)__popcll(rm);
+    }
+    if (have && !later) {
         uint32_t s = 0, e = 0, a = 0;
         bool ok;
         if (dot >= cx.res_lo + 4 && dot + 16 <= cx.res_hi) {
@@ -97,7 +110,7 @@ __device__ __forceinline__ void drain_v4(const uint32_t* ring, uint32_t& head, u
             raw_read<5>(cx.raw32, dot - 4, w);
             ok = d_ipv4_from_window(make_uint4(w[0], w[1], w[2], w[3]), w[4], dot, s, e, a);
         } else if (dot >= 4 && dot + 16 <= p.len) {
-            ok = val_ipv4_fast(p.log, dot, s, e, a);          // window not resident (segment / block edge): HBM
+            ok = val_ipv4_fast(p.log, dot, s, e, a);          // window not resident (segment edges): HBM
         } else {
             ok = val_ipv4(LogView{p.log, p.len}, dot, s, e, a);  // buffer edge
         }
@@ -108,7 +121,6 @@ __device__ __forceinline__ void drain_v4(const uint32_t* ring, uint32_t& head, u
             pd.word = p.filter_v4 ? cx.bm24[a >> 13] : 0xFFFFFFFFu;
         }
     }
-    head += n;
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -116,7 +128,8 @@ __device__ __forceinline__ void drain_v4(const uint32_t* ring, uint32_t& head, u
 // Mirrors the first steps of val_domain (scan_kernels.hip): a '.' inside the label means a later dot owns the run, the
 // run must end at a boundary, and the label must be the last label of some public suffix. Undecidable cases (label
 // longer than 8 bytes, bytes not resident) are kept.
-__device__ __forceinline__ void drain_dom(const uint32_t* ring, uint32_t& head, uint32_t n, const WaveCtx& cx, DomWriter& dw) {
+__device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32_t& tail, uint32_t n, bool final, const WaveCtx& cx,
+                                          DomWriter& dw) {
     const uint32_t lane = lane_id();
     const TokParams& p = *cx.p;
     __builtin_amdgcn_wave_barrier();
@@ -125,8 +138,18 @@ __device__ __forceinline__ void drain_dom(const uint32_t* ring, uint32_t& head, 
     uint32_t ctx[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) ctx[k] = 0;
-    if (lane < n) {
-        j = ring[(head + lane) & (QCAP - 1)];
+    const bool have = lane < n;
+    if (have) j = ring[(head + lane) & (QCAP - 1)];
+    head += n;
+    // label window not staged yet (anchor in the last bytes of the newest block): back into the ring for a later drain
+    const bool later = have && !final && j + 8 > cx.res_hi;
+    const uint64_t rm = __ballot(later);
+    if (rm) {
+        __builtin_amdgcn_wave_barrier();
+        if (later) ring[(tail + mbcnt64(rm)) & (QCAP - 1)] = j;
+        tail += (uint32_t)__popcll(rm);
+    }
+    if (have && !later) {
         keep = true;
         if (j >= cx.res_lo + 24 && j + 8 <= cx.res_hi) {
             raw_read<8>(cx.raw32, j - 24, ctx);   // log[j-24, j+8): the last label starts at byte 24
@@ -155,7 +178,6 @@ __device__ __forceinline__ void drain_dom(const uint32_t* ring, uint32_t& head, 
 #pragma unroll
         for (int k = 0; k < 8; ++k) p.dom_list[dom_plane_index(slot, 1 + k)] = ctx[k];
     }
-    head += n;
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -258,8 +280,8 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             // ---- anchors whose look-back bytes are about to be overwritten in the raw window leave first
             if (blk >= seg_start + RAW_BYTES - BLK_BYTES) {
                 const uint32_t lim = blk - (RAW_BYTES - BLK_BYTES);   // entries of blocks <= lim expire
-                if (v4t != v4h && v4_old <= lim) drain_v4(rv4, v4h, v4t - v4h, cx, pend, cw_cand);
-                if (dt != dh && dom_old <= lim) drain_dom(rdom, dh, dt - dh, cx, cw_dom);
+                if (v4t != v4h && v4_old <= lim) { drain_v4(rv4, v4h, v4t, v4t - v4h, false, cx, pend, cw_cand); v4_old = blk - BLK_BYTES; }
+                if (dt != dh && dom_old <= lim) { drain_dom(rdom, dh, dt, dt - dh, false, cx, cw_dom); dom_old = blk - BLK_BYTES; }
             }
             // ---- this lane's 16 bytes: raw bytes into the window, bytes -> class bytes; prefetch the next block
             uint32_t wv[4] = {nx[0], nx[1], nx[2], nx[3]};
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                     }
                     if (dt == dh) dom_old = blk;
                     dt += (uint32_t)__popcll(m);
-                    if (dt - dh >= 64) { drain_dom(rdom, dh, 64u, cx, cw_dom); dom_old = blk; }
+                    if (dt - dh >= 64) { drain_dom(rdom, dh, dt, 64u, false, cx, cw_dom); dom_old = blk; }
                 }
             }
             if (en_v4) {
@@ -345,7 +367,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                     }
                     if (v4t == v4h) v4_old = blk;
                     v4t += (uint32_t)__popcll(m);
-                    if (v4t - v4h >= 64) { drain_v4(rv4, v4h, 64u, cx, pend, cw_cand); v4_old = blk; }
+                    if (v4t - v4h >= 64) { drain_v4(rv4, v4h, v4t, 64u, false, cx, pend, cw_cand); v4_old = blk; }
                 }
             }
             if (en_rare_row) {
@@ -412,8 +434,8 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             }
         }
         // the next segment of this wave is not contiguous: finish the rings while their bytes are still in the window
-        if (dt != dh) drain_dom(rdom, dh, dt - dh, cx, cw_dom);
-        if (v4t != v4h) drain_v4(rv4, v4h, v4t - v4h, cx, pend, cw_cand);
+        if (dt != dh) drain_dom(rdom, dh, dt, dt - dh, true, cx, cw_dom);
+        if (v4t != v4h) drain_v4(rv4, v4h, v4t, v4t - v4h, true, cx, pend, cw_cand);
     }
     commit_v4(pend, cx, cw_cand);
     // mark the unused tail of every open chunk
