@@ -167,8 +167,19 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
                 // a '.' inside the label: a later dot owns the run; the run must end at a boundary; the label must be
                 // some public suffix's last label
                 keep = (mw.dot & below) == 0 && d_is_boundary(stop) && ((cx.bloom[bit >> 5] >> (bit & 31)) & 1);
-            } else {
-                keep = mw.dot == 0;   // 8 domain chars: undecided unless a later dot already shows up
+            } else if (mw.dot) {
+                keep = false;         // 8 domain chars with a dot among them: a later dot owns the run
+            } else if (j + 24 <= cx.res_hi) {
+                // a label of 8+ bytes: usually not the last one ("www.examplesite.com" at 'e'). Look 16 bytes further: a
+                // dot before the first non-domain byte settles it; otherwise it stays undecided (long last label)
+                uint32_t more[4];
+                raw_read<4>(cx.raw32, j + 8, more);
+                const ByteMasks ma = domain_masks((uint64_t)more[0] | ((uint64_t)more[1] << 32));
+                const ByteMasks mb = domain_masks((uint64_t)more[2] | ((uint64_t)more[3] << 32));
+                const uint64_t na = ~ma.dc & H, nb = ~mb.dc & H;
+                const uint64_t below_a = na ? ((1ull << ((uint32_t)(__ffsll((long long)na) - 1) & ~7u)) - 1ull) : ~0ull;
+                const uint64_t below_b = na ? 0ull : (nb ? ((1ull << ((uint32_t)(__ffsll((long long)nb) - 1) & ~7u)) - 1ull) : ~0ull);
+                keep = ((ma.dot & below_a) | (mb.dot & below_b)) == 0;
             }
         }
     }
