@@ -3,20 +3,21 @@
 // One wavefront owns one 16 KiB segment at a time (grid-stride). Per 1 KiB block:
 //   * every lane loads 16 contiguous log bytes (one coalesced global_load_dwordx4 per lane = 1 KiB per wave; the next
 //     block's load is issued before the current block is processed),
-//   * the raw bytes go to a per-wave circular LDS window (RAW_BYTES) so that anchors can be validated later without
-//     touching HBM again; bytes become class bytes through a 256-entry LDS table and are staged in LDS as well,
-//   * 4 super-rows of 256 bytes: each lane owns one dword of class bytes (4 positions); with the neighbouring dwords
-//     and v_alignbyte it has the classes of positions j-4..j+4 for its 4 positions and evaluates every anchor
-//     pattern for all 4 at once (SWAR: shifts + ands, result in bit 0 of each byte); lanes with a hit are compacted
-//     with ballot + v_mbcnt (wavefront ballot / prefix-sum) into per-type LDS rings,
+//   * the raw bytes go to a per-wave circular LDS window (RAW_BYTES) so that anchors can be processed later without
+//     touching HBM again; bytes become class bytes through a 256-entry LDS table,
+//   * each lane keeps the class bytes of its 16 positions in 4 registers, gets the neighbouring dwords with two DPP wave
+//     shifts and evaluates every anchor pattern for all 16 positions at once (SWAR: v_alignbyte + shifts + ands, result
+//     in bit 0 of each byte); lanes with a hit are compacted with ballot + v_mbcnt (wavefront ballot / prefix-sum)
+//     into per-type LDS rings, one compaction loop per block and type,
 //   * when a ring holds 64 anchors the whole wave processes them, one anchor per lane, from the LDS window:
-//     IPv4 anchors are fully validated (dotted-quad rules) and leave as candidates; domain anchors pass a cheap
-//     prefilter (last label ends within 8 bytes at a boundary and is some public suffix's last label — Bloom filter)
-//     and the survivors leave as anchor positions for k_validate. Lists are written through wave-private chunks
-//     (one atomic per chunk, coalesced stores).
-// Tokens long enough to be hashes / crypto addresses (>= 26 bytes) are found without per-byte work: the ballot of
-// "my dword has no boundary byte" gives one bit per dword, five set bits in a row below a token end are necessary
-// for such a token, and only then is the exact length computed.
+//     IPv4 anchors are fully validated (dotted-quad rules), checked against the database's /24 bitmap and leave as
+//     candidates; domain anchors pass a SWAR prefilter (a later dot owns the run; the run ends at a boundary; the last
+//     label is some public suffix's last label — Bloom filter) and the survivors leave with 32 bytes of context for
+//     k_validate_dom. Anchors whose look-ahead lies in the block that is not staged yet go back into the ring.
+//     Lists are written through wave-private chunks (one atomic per chunk, coalesced stores).
+// Tokens long enough to be hashes / crypto addresses (>= 26 bytes) are found without per-byte work: four ballots of
+// "my dword has no boundary byte" give one bit per dword, five set bits in a row below a token end are necessary
+// for such a token (scalar shift / and on the masks), and only then is the exact length computed.
 //
 // Anchor rules (exact-coverage arguments in DESIGN.md §Anchors; differential-tested against oracle/):
 //   IPv4    '.' at j preceded by 1-3 digits preceded by a boundary / buffer start, followed by 1-3 digits and '.'
@@ -42,7 +43,7 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// (cur << k) with the top k bits of prev shifted in at the bottom: bit i = "dword i-k", across the super-row edge
+// (cur << k) with the top k bits of prev shifted in at the bottom: bit i = "dword i-k", across the block edge
 __device__ __forceinline__ uint64_t shl_carry(uint64_t cur, uint64_t prev, int k) { return (cur << k) | (prev >> (64 - k)); }
 
 // n_dw + 1 dwords of the circular window starting at absolute byte position `a`, shifted so that byte `a` is byte 0

@@ -1,8 +1,10 @@
 // HIP kernels for the `matchy match` hot path on gfx950 (MI355X, wave64).
 //
 //   (k_anchor, stage A1, lives in k_anchor.hip: streaming pass; validates IPv4 itself, lists the other anchors)
-//   k_validate  stage A2: one lane per domain / IPv6 / e-mail anchor and per long token (hex hashes; prefix tests for
-//               the address formats).
+//   k_validate_dom  stage A2a: one lane per domain anchor with its 32-byte context record: suffix table, label rules as
+//               mask arithmetic, XXH64 from registers + literal bitmap. Lean and branch-free on purpose.
+//   k_validate  stage A2b: one lane per long token (hex hashes; prefix tests for the address formats) and per rare
+//               anchor: IPv6, e-mail, and the domains k_validate_dom leaves undecided (general right-to-left walk).
 //   k_rare      stage A3: checksum validators that are rare in logs and heavy in registers (Base58Check, Bech32,
 //               EIP-55, Monero) — one lane per prefiltered token.
 //   k_lookup    stage B: one lane per candidate: MMDB trie walk / XXH64 literal probe / Aho-Corasick DFA + glob

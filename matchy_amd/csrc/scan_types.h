@@ -123,7 +123,7 @@ struct TokParams {
     uint32_t len;
     uint32_t flags;           // ExtractFlags
     uint32_t min_labels;
-    uint32_t debug;           // profiling only
+    uint32_t debug;           // MATCHY_AMD_DEBUG: free for kernel experiments (unused in the shipped kernels)
     uint32_t filter_v4;       // 1: IPv4 candidates whose /24 has no database entry are counted but not listed (lookup scans)
     uint32_t filter_lit;      // 1: domain candidates whose XXH64 is not in DevDb::lit_bm are counted but not listed
     uint32_t n_segs;
