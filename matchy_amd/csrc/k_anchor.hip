@@ -404,17 +404,25 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                 // A token of >= 26 bytes that ends in dword i leaves dwords i-1..i-5 boundary-free (necessary); only the
                 // lowest boundary byte of a dword can close a long token and it must follow a non-boundary byte.
                 uint32_t ck = 4;  // dword of this lane that may close a long token (at most one can)
+                uint64_t c5[4];   // scalar masks: bit L = dwords i-1..i-5 of dword (L, k) are boundary-free
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    uint64_t c5 = ~0ull;
+                    uint64_t c = ~0ull;
 #pragma unroll
                     for (int t = 1; t <= 5; ++t) {
                         int idx = k - t, sh = 0;
                         while (idx < 0) { idx += 4; ++sh; }
-                        c5 &= sh ? shl_carry(Z[idx], Zp[idx], sh) : Z[idx];
+                        c &= sh ? shl_carry(Z[idx], Zp[idx], sh) : Z[idx];
                     }
-                    const uint32_t low = bl[k] & (0u - bl[k]);
-                    if ((low & ~A1s[k]) != 0 && ((c5 >> lane) & 1)) ck = k;
+                    c5[k] = c;
+                }
+                // logs rarely hold 20+ boundary-free bytes: the per-lane tests run only when some dword qualifies
+                if (c5[0] | c5[1] | c5[2] | c5[3]) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t low = bl[k] & (0u - bl[k]);
+                        if ((low & ~A1s[k]) != 0 && ((c5[k] >> lane) & 1)) ck = k;
+                    }
                 }
                 const uint64_t anyB = ~(Z[0] & Z[1] & Z[2] & Z[3]);  // lanes with at least one boundary byte
                 const uint64_t cm = __ballot(ck < 4);
