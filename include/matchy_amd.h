@@ -158,7 +158,8 @@ typedef struct matchy_scan_hit_t {
 #define MATCHY_SCAN_HIT_TYPE(h) ((uint8_t)((h).len_type >> 24))
 
 typedef struct matchy_scan_result_t {
-  const matchy_scan_hit_t *hits;  /* canonical order: by start, then chunk-path class order */
+  const matchy_scan_hit_t *hits;  /* matchy_scanner_scan / fetch_mode 3: canonical order (by start, then chunk-path
+                                     class order); fetch_mode 1: device order */
   size_t n_hits;
   const uint32_t *pattern_ids;
   const int64_t *data_offsets;    /* per pattern id: data-section offset or -1 */
