@@ -249,9 +249,7 @@ void DeviceDb::upload(const DbImage& img, int dev) {
         if (ids.empty()) ids.push_back(0);
         lit2pat_off.upload(off);
         lit2pat.upload(ids);
-        uint32_t rd[8];
         auto r32 = [&](size_t o) { uint32_t v; memcpy(&v, pgp + o, 4); return v; };
-        (void)rd;
         view.pg = pg.p; view.pg_len = (uint32_t)img.pg_len; view.has_glob = 1;
         view.ac_start = r32(20); view.ac_size = r32(24);
         view.patterns_off = r32(36); view.pattern_count = r32(32);
