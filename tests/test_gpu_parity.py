@@ -343,3 +343,44 @@ def test_ipv4_structured_fuzz(M, oracle, seed):
     gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, buf)
     assert gs == ws and gh == wh and gl == wl
     assert len(gh) > 40
+
+
+REFERENCE_BEHAVIOUR = [
+    # (entries, queries) — the behavioural vectors of the reference's own tests (test_ip_longest_prefix_match.rs,
+    # test_literal_hash.rs, paraglob_offset.rs:1890-1944, matchy-paraglob/tests/integration_tests.rs), as in
+    # tests/test_builder_oracle.py, here through matchy_query on the GPU lookup kernels
+    ([("192.0.2.1", {"type": "specific"}), ("192.0.2.0/24", {"type": "general"})], ["192.0.2.1", "192.0.2.2", "192.0.3.1"]),
+    ([("192.0.0.0/8", {"level": "8"}), ("192.0.2.1", {"level": "32"}), ("192.0.2.0/24", {"level": "24"})],
+     ["192.0.2.1", "192.0.2.2", "192.1.1.1", "193.0.0.1"]),
+    ([("2001:db8::/64", {"level": "64"}), ("2001:db8::1", {"level": "128"}), ("2001:db8::/96", {"level": "96"})],
+     ["2001:db8::1", "2001:db8::2", "2001:db8::1:0:0", "2001:db9::1"]),
+    ([("2001:db8::1", {"v": 6}), ("10.1.2.3", {"v": 4}), ("10.9.0.0/16", {"v": 16})], ["10.1.2.3", "10.9.77.1", "10.1.2.4", "2001:db8::1"]),
+    ([(f"pattern_{i}", {"id": i}) for i in range(100)], ["pattern_0", "pattern_57", "pattern_99", "pattern_100", "pattern_"]),
+    ([("*.txt", {"p": 0}), ("test_*", {"p": 1})], ["test_file.txt", "test_file.bin", "other.bin", "x.txt"]),
+    ([("*", {"p": 0}), ("??", {"p": 1})], ["ab", "abc", ""]),
+    ([("*test*", {"p": 0}), ("test*", {"p": 1}), ("*test", {"p": 2})], ["test", "testing", "mytest", "mytesting", "tes"]),
+    ([("glob:hello", {"p": 0}), ("glob:world", {"p": 1})], ["hello world", "say hello", "wor ld"]),
+    ([("file[0-9].txt", {"p": 0}), ("file[!0-9].txt", {"p": 1})], ["file7.txt", "fileX.txt", "file.txt", "file77.txt"]),
+    ([("*.a?", {"p": 0}), ("*.evil.com", {"p": 1})], ["x.ab", "www.evil.com", "evil.com"]),
+    ([("café*.fr", {"u": 1}), ("literal:naïve.example", {"u": 2})], ["café-de-flore.fr", "cafe.fr", "naïve.example", "naive.example"]),
+]
+
+
+def test_reference_behaviour_vectors_through_matchy_query(M, oracle):
+    for entries, queries in REFERENCE_BEHAVIOUR:
+        b = M.DatabaseBuilder(build_epoch=5)
+        for k, v in entries:
+            b.add_entry(k, v)
+        blob = b.build()
+        db = M.Database(blob)
+        odb = oracle.Database(blob)
+        for q in queries:
+            want = odb.lookup(q)
+            got = db.lookup(q)
+            if want["kind"] == "ip":
+                assert got == {"found": True, "prefix_len": want["prefix_len"], "data": want["data"]}, (entries[0][0], q)
+            elif want["kind"] == "pattern" and want["data"] and want["data"][0] is not None:
+                assert got == {"found": True, "prefix_len": 0, "data": want["data"][0]}, (entries[0][0], q)
+            else:
+                assert got is None, (entries[0][0], q, got)
+        db.close()
