@@ -136,6 +136,78 @@ void matchy_matches_free(matchy_matches_t *matches);                            
 void matchy_extractor_free(matchy_extractor_t *extractor);                                    /* matchy.h:1445 */
 const char *matchy_item_type_name(uint8_t item_type);                                         /* matchy.h:1460 */
 
+/* ---- statistics (matchy.h:403-432, 894, 917). This build has no per-thread LRU: cache_hits / cache_misses stay 0 and
+ * matchy_clear_cache is a no-op. Query-type accounting follows Database::lookup (database.rs:725-804), including its
+ * quirk that a miss is always counted as a string query. */
+typedef struct matchy_stats_t {
+  uint64_t total_queries, queries_with_match, queries_without_match, cache_hits, cache_misses, ip_queries, string_queries;
+} matchy_stats_t;
+void matchy_get_stats(const matchy_t *db, matchy_stats_t *stats);      /* matchy.h:894 */
+void matchy_clear_cache(const matchy_t *db);                            /* matchy.h:917 */
+bool matchy_has_pattern_data(const matchy_t *db);                       /* matchy.h:1137 (deprecated alias of has_string_data) */
+
+/* ---- structured access to the data of a query result (MaxMind-style walkers, matchy.h:452-508, 1220-1290) */
+#define MATCHY_ERROR_LOOKUP_PATH_INVALID (-7) /* matchy.h:163 */
+#define MATCHY_ERROR_NO_DATA (-8)             /* matchy.h:168 */
+#define MATCHY_ERROR_DATA_PARSE (-9)          /* matchy.h:173 */
+#define MATCHY_DATA_TYPE_POINTER 1            /* matchy.h:92-157 */
+#define MATCHY_DATA_TYPE_UTF8_STRING 2
+#define MATCHY_DATA_TYPE_DOUBLE 3
+#define MATCHY_DATA_TYPE_BYTES 4
+#define MATCHY_DATA_TYPE_UINT16 5
+#define MATCHY_DATA_TYPE_UINT32 6
+#define MATCHY_DATA_TYPE_MAP 7
+#define MATCHY_DATA_TYPE_INT32 8
+#define MATCHY_DATA_TYPE_UINT64 9
+#define MATCHY_DATA_TYPE_UINT128 10
+#define MATCHY_DATA_TYPE_ARRAY 11
+#define MATCHY_DATA_TYPE_BOOLEAN 14
+#define MATCHY_DATA_TYPE_FLOAT 15
+typedef union matchy_entry_data_value_u { /* matchy.h:24-36 */
+  uint32_t pointer;
+  const char *utf8_string;
+  double double_value;
+  const uint8_t *bytes;
+  uint16_t uint16;
+  uint32_t uint32;
+  int32_t int32;
+  uint64_t uint64;
+  uint8_t uint128[16];
+  bool boolean;
+  float float_value;
+} matchy_entry_data_value_u;
+typedef struct matchy_entry_s { /* matchy.h:457-466 */
+  const matchy_t *db;
+  const void *data_ptr;
+} matchy_entry_s;
+typedef struct matchy_entry_data_t { /* matchy.h:471-494 */
+  bool has_data;
+  uint32_t type_;
+  matchy_entry_data_value_u value;
+  uint32_t data_size; /* string / bytes: length; map / array: element count; scalars: width */
+  uint32_t offset;
+} matchy_entry_data_t;
+typedef struct matchy_entry_data_list_t { /* matchy.h:499-508 */
+  matchy_entry_data_t entry_data;
+  struct matchy_entry_data_list_t *next;
+} matchy_entry_data_list_t;
+int32_t matchy_result_get_entry(const matchy_result_t *result, matchy_entry_s *entry);                               /* matchy.h:1220 */
+/* path = NULL-terminated array of map keys / decimal array indexes. String and byte pointers stay valid until
+ * matchy_free_result (the reference leaks them instead). */
+int32_t matchy_aget_value(const matchy_entry_s *entry, matchy_entry_data_t *entry_data, const char *const *path);   /* matchy.h:1245 */
+/* Depth-first list: a node, then its children (map values in key order; the reference's HashMap order is unspecified). */
+int32_t matchy_get_entry_data_list(const matchy_entry_s *entry, matchy_entry_data_list_t **entry_data_list);         /* matchy.h:1277 */
+void matchy_free_entry_data_list(matchy_entry_data_list_t *list);                                                     /* matchy.h:1290 */
+
+/* ---- validation (matchy.h:1357): both levels run the bounds-checked parse every open performs (header, tree size,
+ * section offsets, literal / paraglob tables). *error_message (if any) is freed with matchy_free_string. */
+#define MATCHY_VALIDATION_STANDARD 0 /* matchy.h:178 */
+#define MATCHY_VALIDATION_STRICT 1   /* matchy.h:183 */
+int32_t matchy_validate(const char *filename, int32_t level, char **error_message);
+/* Schema validation of entry data is outside this build: every schema name is reported as unknown (matchy.h:86, 625). */
+#define MATCHY_ERROR_UNKNOWN_SCHEMA (-8)
+int32_t matchy_builder_set_schema(matchy_builder_t *builder, const char *schema_name);
+
 /* ================================================================================================
  * PART 2 — additive bulk-scan surface (not in the reference)
  * ================================================================================================ */

@@ -36,11 +36,39 @@ EXPORTED_SYMBOLS = [
     "matchy_matches_free", "matchy_extractor_free", "matchy_item_type_name", "matchy_scanner_create", "matchy_scanner_free",
     "matchy_scanner_scan", "matchy_scanner_scan_device", "matchy_scan_result_free", "matchy_scan_hit_to_json",
     "matchy_scanner_set_profile", "matchy_scanner_get_timing", "matchy_amd_last_error", "matchy_builder_set_build_epoch",
+    "matchy_get_stats", "matchy_clear_cache", "matchy_has_pattern_data", "matchy_result_get_entry", "matchy_aget_value",
+    "matchy_get_entry_data_list", "matchy_free_entry_data_list", "matchy_validate", "matchy_builder_set_schema",
 ]
 
 
 class _Result(C.Structure):
     _fields_ = [("found", C.c_bool), ("prefix_len", C.c_uint8), ("_data_cache", C.c_void_p), ("_db_ref", C.c_void_p)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("total_queries", "queries_with_match", "queries_without_match", "cache_hits",
+                                          "cache_misses", "ip_queries", "string_queries")]
+
+
+class _Entry(C.Structure):
+    _fields_ = [("db", C.c_void_p), ("data_ptr", C.c_void_p)]
+
+
+class _EntryValue(C.Union):
+    _fields_ = [("pointer", C.c_uint32), ("utf8_string", C.c_char_p), ("double_value", C.c_double), ("bytes", C.POINTER(C.c_uint8)),
+                ("uint16", C.c_uint16), ("uint32", C.c_uint32), ("int32", C.c_int32), ("uint64", C.c_uint64),
+                ("uint128", C.c_uint8 * 16), ("boolean", C.c_bool), ("float_value", C.c_float)]
+
+
+class _EntryData(C.Structure):
+    _fields_ = [("has_data", C.c_bool), ("type_", C.c_uint32), ("value", _EntryValue), ("data_size", C.c_uint32), ("offset", C.c_uint32)]
+
+
+class _EntryDataList(C.Structure):
+    pass
+
+
+_EntryDataList._fields_ = [("entry_data", _EntryData), ("next", C.POINTER(_EntryDataList))]
 
 
 class _Match(C.Structure):
@@ -116,6 +144,15 @@ def lib():
         "matchy_scanner_set_profile": (None, [vp, C.c_bool]),
         "matchy_scanner_get_timing": (None, [vp, C.POINTER(C.c_float)]),
         "matchy_amd_last_error": (cp, []),
+        "matchy_get_stats": (None, [vp, C.POINTER(_Stats)]),
+        "matchy_clear_cache": (None, [vp]),
+        "matchy_has_pattern_data": (C.c_bool, [vp]),
+        "matchy_result_get_entry": (C.c_int32, [C.POINTER(_Result), C.POINTER(_Entry)]),
+        "matchy_aget_value": (C.c_int32, [C.POINTER(_Entry), C.POINTER(_EntryData), C.POINTER(cp)]),
+        "matchy_get_entry_data_list": (C.c_int32, [C.POINTER(_Entry), C.POINTER(C.POINTER(_EntryDataList))]),
+        "matchy_free_entry_data_list": (None, [C.POINTER(_EntryDataList)]),
+        "matchy_validate": (C.c_int32, [cp, C.c_int32, C.POINTER(vp)]),
+        "matchy_builder_set_schema": (C.c_int32, [vp, cp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -220,6 +257,62 @@ class Database:
             return {"found": True, "prefix_len": r.prefix_len, "data": json.loads(js) if js else None}
         finally:
             L.matchy_free_result(C.byref(r))
+
+    @staticmethod
+    def _entry_value(ed):
+        """matchy_entry_data_t -> (type, python value); maps / arrays yield their element count."""
+        t = ed.type_
+        v = ed.value
+        if t == 2:
+            return t, C.string_at(v.utf8_string, ed.data_size).decode("utf-8")
+        if t == 4:
+            return t, bytes(v.bytes[i] for i in range(ed.data_size))
+        return t, {1: v.pointer, 3: v.double_value, 5: v.uint16, 6: v.uint32, 7: ed.data_size, 8: v.int32, 9: v.uint64,
+                   10: int.from_bytes(bytes(v.uint128), "big"), 11: ed.data_size, 14: bool(v.boolean), 15: v.float_value}[t]
+
+    def get_value(self, query: str, *path):
+        """matchy_query + matchy_result_get_entry + matchy_aget_value -> (rc, type, value)."""
+        L = lib()
+        r = L.matchy_query(self._h, query.encode("utf-8"))
+        try:
+            e = _Entry()
+            rc = L.matchy_result_get_entry(C.byref(r), C.byref(e))
+            if rc != 0:
+                return rc, None, None
+            arr = (C.c_char_p * (len(path) + 1))(*[str(x).encode("utf-8") for x in path], None)
+            ed = _EntryData()
+            rc = L.matchy_aget_value(C.byref(e), C.byref(ed), arr)
+            if rc != 0 or not ed.has_data:
+                return rc, None, None
+            t, v = self._entry_value(ed)
+            return rc, t, v
+        finally:
+            L.matchy_free_result(C.byref(r))
+
+    def entry_data_list(self, query: str):
+        """matchy_get_entry_data_list flattened to [(type, value)], or None when the query has no result."""
+        L = lib()
+        r = L.matchy_query(self._h, query.encode("utf-8"))
+        try:
+            e = _Entry()
+            if L.matchy_result_get_entry(C.byref(r), C.byref(e)) != 0:
+                return None
+            head = C.POINTER(_EntryDataList)()
+            if L.matchy_get_entry_data_list(C.byref(e), C.byref(head)) != 0:
+                return None
+            out, node = [], head
+            while node:
+                out.append(self._entry_value(node.contents.entry_data))
+                node = node.contents.next
+            L.matchy_free_entry_data_list(head)
+            return out
+        finally:
+            L.matchy_free_result(C.byref(r))
+
+    def stats(self):
+        st = _Stats()
+        lib().matchy_get_stats(self._h, C.byref(st))
+        return {n: getattr(st, n) for n, _ in _Stats._fields_}
 
     def has_ip_data(self):
         return bool(lib().matchy_has_ip_data(self._h))

@@ -2,6 +2,7 @@
 #include "../../include/matchy_amd.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +37,8 @@ struct Db {
     DevBuf<Candidate> qcand;
     std::string format;
     int default_device = 0;
+    // DatabaseStats (database.rs:728-795); no LRU here, so cache_hits / cache_misses stay 0
+    mutable std::atomic<uint64_t> st_total{0}, st_match{0}, st_nomatch{0}, st_ip{0}, st_str{0};
 
     std::shared_ptr<DeviceDb> device_db(int device) {
         if ((int)dev.size() <= device) dev.resize(device + 1);
@@ -255,6 +258,14 @@ bool matchy_has_ip_data(const matchy_t* db) { return db && reinterpret_cast<cons
 bool matchy_has_literal_data(const matchy_t* db) { return db && reinterpret_cast<const Db*>(db)->img->has_literal; }
 bool matchy_has_glob_data(const matchy_t* db) { return db && reinterpret_cast<const Db*>(db)->img->has_glob; }
 bool matchy_has_string_data(const matchy_t* db) { return matchy_has_literal_data(db) || matchy_has_glob_data(db); }
+bool matchy_has_pattern_data(const matchy_t* db) { return matchy_has_string_data(db); }
+
+void matchy_get_stats(const matchy_t* dbc, matchy_stats_t* st) {
+    if (!dbc || !st) return;
+    const Db* db = reinterpret_cast<const Db*>(dbc);
+    *st = matchy_stats_t{db->st_total.load(), db->st_match.load(), db->st_nomatch.load(), 0, 0, db->st_ip.load(), db->st_str.load()};
+}
+void matchy_clear_cache(const matchy_t*) {}
 uintptr_t matchy_pattern_count(const matchy_t* db) { return db ? reinterpret_cast<const Db*>(db)->img->pattern_count : 0; }
 char* matchy_metadata(const matchy_t* db) {
     if (!db) return nullptr;
@@ -300,8 +311,11 @@ void matchy_query_into(const matchy_t* dbc, const char* query, matchy_result_t* 
         }
         ScanOutput so;
         db->query_scanner->lookup_one(text, c, so);
-        if (so.hits.empty()) return;
+        db->st_total++;
+        if (so.hits.empty()) { db->st_str++; db->st_nomatch++; return; }   // a miss counts as a string query (database.rs:786-790)
         const Hit& h = so.hits[0];
+        if (h.kind == 2) db->st_ip++; else db->st_str++;
+        db->st_match++;
         DataValue* dv = new DataValue();
         bool ok = false;
         if (h.kind == 2) { ok = db->img->decode_data(h.a, *dv); result->prefix_len = h.prefix_len; }
@@ -335,6 +349,123 @@ char* matchy_result_to_json(const matchy_result_t* r) {
     std::string s;
     to_json(*reinterpret_cast<const DataValue*>(r->_data_cache), s);
     return strdup(s.c_str());
+}
+
+// ------------------------------------------------------------------------------------------------ structured data
+namespace {
+matchy_entry_data_t entry_empty() {
+    matchy_entry_data_t e;
+    memset(&e, 0, sizeof(e));
+    return e;
+}
+// matchy_entry_data_t::from_data_value (c_api/matchy.rs:1599-1690)
+matchy_entry_data_t entry_from(const DataValue& v) {
+    matchy_entry_data_t e = entry_empty();
+    e.has_data = true;
+    e.type_ = (uint32_t)v.type;
+    switch (v.type) {
+        case DataValue::POINTER: e.value.pointer = (uint32_t)v.u; break;
+        case DataValue::STRING: e.value.utf8_string = v.str.c_str(); e.data_size = (uint32_t)v.str.size(); break;
+        case DataValue::DOUBLE: e.value.double_value = v.f64; e.data_size = 8; break;
+        case DataValue::BYTES: e.value.bytes = (const uint8_t*)v.str.data(); e.data_size = (uint32_t)v.str.size(); break;
+        case DataValue::UINT16: e.value.uint16 = (uint16_t)v.u; e.data_size = 2; break;
+        case DataValue::UINT32: e.value.uint32 = (uint32_t)v.u; e.data_size = 4; break;
+        case DataValue::MAP: e.data_size = (uint32_t)v.map.size(); break;
+        case DataValue::INT32: e.value.int32 = v.i32; e.data_size = 4; break;
+        case DataValue::UINT64: e.value.uint64 = v.u; e.data_size = 8; break;
+        case DataValue::UINT128:
+            for (int i = 0; i < 8; ++i) { e.value.uint128[i] = (uint8_t)(v.uhi >> (56 - 8 * i)); e.value.uint128[8 + i] = (uint8_t)(v.u >> (56 - 8 * i)); }
+            e.data_size = 16;
+            break;
+        case DataValue::ARRAY: e.data_size = (uint32_t)v.arr.size(); break;
+        case DataValue::BOOL: e.value.boolean = v.u != 0; e.data_size = 1; break;
+        case DataValue::FLOAT: e.value.float_value = v.f32; e.data_size = 4; break;
+    }
+    return e;
+}
+const DataValue* entry_root(const matchy_entry_s* entry) {
+    if (!entry || !entry->data_ptr) return nullptr;
+    const matchy_result_t* r = reinterpret_cast<const matchy_result_t*>(entry->data_ptr);
+    return reinterpret_cast<const DataValue*>(r->_data_cache);
+}
+void flatten(const DataValue& v, matchy_entry_data_list_t**& tail) {
+    auto* node = new matchy_entry_data_list_t{entry_from(v), nullptr};
+    *tail = node;
+    tail = &node->next;
+    if (v.type == DataValue::MAP) for (const auto& kv : v.map) flatten(kv.second, tail);
+    else if (v.type == DataValue::ARRAY) for (const DataValue& c : v.arr) flatten(c, tail);
+}
+}  // namespace
+
+int32_t matchy_result_get_entry(const matchy_result_t* result, matchy_entry_s* entry) {
+    if (!result || !entry) return MATCHY_ERROR_INVALID_PARAM;
+    if (!result->found) return MATCHY_ERROR_NO_DATA;
+    entry->db = result->_db_ref;
+    entry->data_ptr = result;
+    return MATCHY_SUCCESS;
+}
+int32_t matchy_aget_value(const matchy_entry_s* entry, matchy_entry_data_t* out, const char* const* path) {
+    if (!entry || !out || !path) return MATCHY_ERROR_INVALID_PARAM;
+    for (size_t i = 0; path[i]; ++i) if (!valid_utf8_host((const uint8_t*)path[i], strlen(path[i]))) return MATCHY_ERROR_INVALID_PARAM;
+    *out = entry_empty();
+    const DataValue* v = entry_root(entry);
+    if (!v) return MATCHY_ERROR_NO_DATA;
+    for (size_t i = 0; path[i]; ++i) {   // navigate_path (c_api/matchy.rs:1692-1710)
+        if (v->type == DataValue::MAP) {
+            auto it = v->map.find(path[i]);
+            if (it == v->map.end()) return MATCHY_ERROR_LOOKUP_PATH_INVALID;
+            v = &it->second;
+        } else if (v->type == DataValue::ARRAY) {
+            const char* s = path[i];
+            if (*s == '+') ++s;   // usize::from_str accepts a leading '+'
+            if (!*s) return MATCHY_ERROR_LOOKUP_PATH_INVALID;
+            size_t idx = 0;
+            for (; *s; ++s) {
+                if (*s < '0' || *s > '9' || idx > ((size_t)1 << 56)) return MATCHY_ERROR_LOOKUP_PATH_INVALID;
+                idx = idx * 10 + (size_t)(*s - '0');
+            }
+            if (idx >= v->arr.size()) return MATCHY_ERROR_LOOKUP_PATH_INVALID;
+            v = &v->arr[idx];
+        } else {
+            return MATCHY_ERROR_LOOKUP_PATH_INVALID;
+        }
+    }
+    *out = entry_from(*v);
+    return MATCHY_SUCCESS;
+}
+int32_t matchy_get_entry_data_list(const matchy_entry_s* entry, matchy_entry_data_list_t** list) {
+    if (!entry || !list) return MATCHY_ERROR_INVALID_PARAM;
+    const DataValue* v = entry_root(entry);
+    if (!v) return MATCHY_ERROR_NO_DATA;
+    *list = nullptr;
+    matchy_entry_data_list_t** tail = list;
+    flatten(*v, tail);
+    return MATCHY_SUCCESS;
+}
+void matchy_free_entry_data_list(matchy_entry_data_list_t* list) {
+    while (list) { matchy_entry_data_list_t* n = list->next; delete list; list = n; }
+}
+
+int32_t matchy_validate(const char* filename, int32_t level, char** error_message) {
+    if (error_message) *error_message = nullptr;
+    if (!filename || !valid_utf8_host((const uint8_t*)filename, strlen(filename))) return MATCHY_ERROR_INVALID_PARAM;
+    if (level != MATCHY_VALIDATION_STANDARD && level != MATCHY_VALIDATION_STRICT) return MATCHY_ERROR_INVALID_PARAM;
+    std::vector<uint8_t> bytes;
+    if (!read_file(filename, bytes)) {
+        if (error_message) *error_message = strdup("Failed to validate database");
+        return MATCHY_ERROR_IO;
+    }
+    DbImage img;
+    std::string err;
+    if (!img.open(std::move(bytes), err)) {
+        if (error_message) *error_message = strdup(err.empty() ? "Validation failed (no error details)" : err.c_str());
+        return MATCHY_ERROR_CORRUPT_DATA;
+    }
+    return MATCHY_SUCCESS;
+}
+int32_t matchy_builder_set_schema(matchy_builder_t* b, const char* name) {
+    if (!b || !name) return MATCHY_ERROR_INVALID_PARAM;
+    return MATCHY_ERROR_UNKNOWN_SCHEMA;
 }
 
 // ------------------------------------------------------------------------------------------------ extractor

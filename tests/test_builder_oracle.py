@@ -186,3 +186,38 @@ def test_metadata_fields(oracle):
     assert md["ip_entry_count"] == 1 and md["literal_entry_count"] == 1 and md["glob_entry_count"] == 1
     assert md["match_mode"] == 0 and md["node_count"] == 32 and md["record_size"] == 24
     assert md["pattern_section_offset"] % 4 == 0 and md["literal_section_offset"] > md["pattern_section_offset"]
+
+
+def test_validate_and_schema_entry_points(tmp_path):
+    # matchy_validate (matchy.h:1357) runs without a GPU: it only parses the file
+    import ctypes as C
+    L = M.lib()
+    good = tmp_path / "good.mxy"
+    good.write_bytes(build([("10.0.0.0/8", {"a": 1}), ("*.evil.com", {"b": 2}), ("exact.example", {"c": 3})]))
+    err = C.c_void_p()
+    assert L.matchy_validate(str(good).encode(), 0, C.byref(err)) == 0 and not err.value
+    assert L.matchy_validate(str(good).encode(), 1, None) == 0
+    assert L.matchy_validate(str(good).encode(), 7, None) == -5          # unknown level -> INVALID_PARAM
+    assert L.matchy_validate(None, 0, None) == -5
+    bad = tmp_path / "bad.mxy"
+    blob = bytearray(good.read_bytes())
+    bad.write_bytes(bytes(blob[: len(blob) // 3]))                       # truncated file
+    assert L.matchy_validate(str(bad).encode(), 0, C.byref(err)) == -3   # CORRUPT_DATA with a message
+    assert err.value and len(C.string_at(err.value)) > 0
+    L.matchy_free_string(err)
+    err = C.c_void_p()
+    assert L.matchy_validate(str(tmp_path / "missing.mxy").encode(), 0, C.byref(err)) == -6   # IO
+    assert C.string_at(err.value) == b"Failed to validate database"
+    L.matchy_free_string(err)
+    # schema validation is not built: every name is unknown (MATCHY_ERROR_UNKNOWN_SCHEMA)
+    b = L.matchy_builder_new()
+    assert L.matchy_builder_set_schema(b, b"threatdb") == -8
+    assert L.matchy_builder_set_schema(None, b"threatdb") == -5
+    L.matchy_builder_free(b)
+    # NULL handling of the walkers
+    assert L.matchy_result_get_entry(None, None) == -5
+    assert L.matchy_get_entry_data_list(None, None) == -5
+    L.matchy_free_entry_data_list(None)
+    L.matchy_get_stats(None, None)
+    L.matchy_clear_cache(None)
+    assert L.matchy_has_pattern_data(None) is False

@@ -384,3 +384,50 @@ def test_reference_behaviour_vectors_through_matchy_query(M, oracle):
             else:
                 assert got is None, (entries[0][0], q, got)
         db.close()
+
+
+def test_structured_data_walkers_and_stats(M):
+    """matchy_result_get_entry / matchy_aget_value / matchy_get_entry_data_list / matchy_get_stats
+    (c_api/matchy.rs:989-1006, 1734-1960; the reference's own coverage: tests/test_c_api_extensions.c)."""
+    b = M.DatabaseBuilder(build_epoch=6)
+    data = {"country": "US", "asn": 13335, "score": -7, "big": 2 ** 40, "ratio": 0.5, "flag": True,
+            "tags": ["a", "bb", {"deep": "x"}], "geo": {"lat": 37.75, "name": "somewhere"}}
+    b.add_entry("8.8.8.0/24", data)
+    b.add_entry("evil.example", {"kind": "literal"})
+    b.add_entry("*.bad.example", {"kind": "glob"})
+    db = M.Database(b.build())
+    T_STR, T_DBL, T_U16, T_U32, T_MAP, T_I32, T_U64, T_ARR, T_BOOL = 2, 3, 5, 6, 7, 8, 9, 11, 14
+    assert db.get_value("8.8.8.8", "country") == (0, T_STR, "US")
+    assert db.get_value("8.8.8.8", "asn") == (0, T_U16, 13335)           # serde typing: smallest unsigned that fits
+    assert db.get_value("8.8.8.8", "score") == (0, T_I32, -7)
+    assert db.get_value("8.8.8.8", "big") == (0, T_U64, 2 ** 40)
+    assert db.get_value("8.8.8.8", "ratio") == (0, T_DBL, 0.5)
+    assert db.get_value("8.8.8.8", "flag") == (0, T_BOOL, True)
+    assert db.get_value("8.8.8.8", "geo") == (0, T_MAP, 2)                # maps / arrays: element count
+    assert db.get_value("8.8.8.8", "geo", "name") == (0, T_STR, "somewhere")
+    assert db.get_value("8.8.8.8", "tags") == (0, T_ARR, 3)
+    assert db.get_value("8.8.8.8", "tags", 1) == (0, T_STR, "bb")
+    assert db.get_value("8.8.8.8", "tags", 2, "deep") == (0, T_STR, "x")
+    assert db.get_value("8.8.8.8") == (0, T_MAP, 8)                       # empty path: the root
+    assert db.get_value("8.8.8.8", "nope")[0] == -7                       # LOOKUP_PATH_INVALID
+    assert db.get_value("8.8.8.8", "tags", 3)[0] == -7
+    assert db.get_value("8.8.8.8", "tags", "x")[0] == -7
+    assert db.get_value("8.8.8.8", "country", "x")[0] == -7               # path through a scalar
+    assert db.get_value("9.9.9.9", "country")[0] == -8                    # NO_DATA: not found
+    assert db.get_value("evil.example", "kind") == (0, T_STR, "literal")
+    assert db.get_value("x.bad.example", "kind") == (0, T_STR, "glob")
+    lst = db.entry_data_list("8.8.8.8")
+    # node, then children; map values in key order: asn, big, country, flag, geo{lat,name}, ratio, score, tags[...]
+    assert lst == [(T_MAP, 8), (T_U16, 13335), (T_U64, 2 ** 40), (T_STR, "US"), (T_BOOL, True), (T_MAP, 2), (T_DBL, 37.75),
+                   (T_STR, "somewhere"), (T_DBL, 0.5), (T_I32, -7), (T_ARR, 3), (T_STR, "a"), (T_STR, "bb"), (T_MAP, 1), (T_STR, "x")]
+    assert db.entry_data_list("9.9.9.9") is None
+    # statistics: Database::lookup accounting, misses count as string queries (database.rs:786-790)
+    st0 = db.stats()
+    db.lookup("8.8.8.8"); db.lookup("evil.example"); db.lookup("9.9.9.9"); db.lookup("nope.example")
+    st1 = db.stats()
+    d = {k: st1[k] - st0[k] for k in st1}
+    assert d == {"total_queries": 4, "queries_with_match": 2, "queries_without_match": 2, "cache_hits": 0, "cache_misses": 0,
+                 "ip_queries": 1, "string_queries": 3}
+    assert M.lib().matchy_has_pattern_data(db.handle) is True
+    M.lib().matchy_clear_cache(db.handle)
+    db.close()
