@@ -130,3 +130,18 @@ def test_match_config1_end_to_end(cli, tmp_path, oracle):
     assert len(ips) == sum(1 for l in want_lines if json.loads(l)["match_type"] == "ip")
     r6 = _run([cli, "match", str(dbp), str(tmp_path / "nope.log"), str(logp)])
     assert r6.returncode != 0 and r6.stdout.decode().splitlines() == want_lines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog", ["test_c_api", "test_c_api_extensions"])
+def test_reference_c_test_programs(prog, tmp_path):
+    """The reference's own C test programs (crates/matchy/tests/test_c_api*.c), compiled unmodified against the
+    reference's header and linked with libmatchy_amd.so by `make -C oracle ref_c_tests` (needs /root/reference at build
+    time; the binaries travel to the GPU box). They must pass as they do against the reference library."""
+    exe = ROOT / "oracle" / "_ref" / prog
+    if not exe.exists():
+        pytest.skip("oracle/_ref not built (no /root/reference at build time)")
+    r = subprocess.run([str(exe)], capture_output=True, timeout=300, cwd=tmp_path)
+    out = r.stdout.decode("utf-8", "replace")
+    assert r.returncode == 0, out[-2000:] + r.stderr.decode("utf-8", "replace")[-500:]
+    assert "passed" in out
