@@ -8,11 +8,13 @@
 // match_processor/parallel.rs:297-369: sorted keys, timestamp "0.000") and, with -s, the [INFO] statistics block on
 // stderr (commands/match_cmd.rs:514-581). Every batch is scanned on the GPU through the C ABI (matchy_scanner_scan);
 // there is no CPU scan path. Flags that only tune the reference's CPU thread pool (-j, --readers, --cache-size, -p,
-// --debug-routing) are accepted and ignored; -f/--follow and compressed inputs are not supported.
+// --debug-routing) are accepted and ignored; .gz inputs are decompressed on the host (zlib); -f/--follow is not supported.
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -286,18 +288,33 @@ bool scan_batch(matchy_scanner_t* sc, const uint8_t* data, size_t len, const std
     return true;
 }
 
+// Inputs ending in .gz (case-insensitive) are decompressed on the fly like the reference's file reader does
+// (crates/matchy/src/file_reader.rs:45-75, by extension); "-" is stdin.
 bool process_input(matchy_scanner_t* sc, const std::string& path, size_t batch_bytes, bool json, Totals& t) {
+    const bool gz = ends_with_ci(path, ".gz");
     int fd = path == "-" ? 0 : open(path.c_str(), O_RDONLY);
     if (fd < 0) { fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), strerror(errno)); return false; }
-    if (ends_with_ci(path, ".gz")) { fprintf(stderr, "[ERROR] Failed to process %s: compressed inputs are not supported by this build\n", path.c_str()); if (fd) close(fd); return false; }
+    gzFile zf = nullptr;
+    if (gz) {
+        zf = gzdopen(fd, "rb");
+        if (!zf) { fprintf(stderr, "[ERROR] Failed to process %s: cannot start gzip decoder\n", path.c_str()); close(fd); return false; }
+        gzbuffer(zf, 1u << 20);
+    }
     const std::string source = path == "-" ? "stdin" : path;
     std::vector<uint8_t> buf(batch_bytes + 16);
     size_t have = 0;
     bool ok = true;
     for (;;) {
         if (have == buf.size() - 16) buf.resize(buf.size() * 2);  // a single line longer than the batch: grow
-        ssize_t n = read(fd, buf.data() + have, buf.size() - 16 - have);
-        if (n < 0) { fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), strerror(errno)); ok = false; break; }
+        const size_t room = buf.size() - 16 - have;
+        ssize_t n;
+        if (gz) {
+            n = gzread(zf, buf.data() + have, (unsigned)std::min<size_t>(room, 1u << 30));
+            if (n < 0) { int e; fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), gzerror(zf, &e)); ok = false; break; }
+        } else {
+            n = read(fd, buf.data() + have, room);
+            if (n < 0) { fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), strerror(errno)); ok = false; break; }
+        }
         have += (size_t)n;
         if (n == 0) { ok = scan_batch(sc, buf.data(), have, source, json, t); break; }
         if (have < batch_bytes) continue;
@@ -309,7 +326,8 @@ bool process_input(matchy_scanner_t* sc, const std::string& path, size_t batch_b
         memmove(buf.data(), buf.data() + cut, have - cut);
         have -= cut;
     }
-    if (fd) close(fd);
+    if (gz) gzclose(zf);   // closes fd as well
+    else if (fd) close(fd);
     return ok;
 }
 

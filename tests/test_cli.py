@@ -128,6 +128,13 @@ def test_match_config1_end_to_end(cli, tmp_path, oracle):
     ips = [json.loads(l) for l in r5.stdout.decode().splitlines()]
     assert ips and all(o["match_type"] == "ip" for o in ips)
     assert len(ips) == sum(1 for l in want_lines if json.loads(l)["match_type"] == "ip")
+    # gzip input (by extension, file_reader.rs:45-75)
+    import gzip
+    gzp = tmp_path / "access.log.GZ"
+    gzp.write_bytes(gzip.compress(log))
+    rz = _run([cli, "match", str(dbp), str(gzp), "--batch-bytes", "300000"])
+    assert rz.returncode == 0
+    assert [json.loads(l) | {"source": ""} for l in rz.stdout.decode().splitlines()] == [json.loads(l) | {"source": ""} for l in want_lines]
     r6 = _run([cli, "match", str(dbp), str(tmp_path / "nope.log"), str(logp)])
     assert r6.returncode != 0 and r6.stdout.decode().splitlines() == want_lines
 
