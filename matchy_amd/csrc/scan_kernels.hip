@@ -776,10 +776,16 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
             if (ok) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV6 << 24); emit = true; }
         } else if (kind == RARE_AT) {
             uint32_t s, e;
-            if (val_email(lg, db, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_EMAIL << 24); emit = true; }
+            if (val_email(lg, db, ra.pos, s, e)) {
+                if (e - s > 0xFFFFFFu) atomicOr(&p.counters->error, 4u);   // the record format holds 24-bit lengths
+                c.start = s; c.len_type = (e - s) | ((uint32_t)IT_EMAIL << 24); emit = true;
+            }
         } else if (kind == RARE_DOM) {
             uint32_t s, e;
-            if (val_domain(lg, db, bloom, tldtab, p.min_labels, ra.pos, s, e)) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true; }
+            if (val_domain(lg, db, bloom, tldtab, p.min_labels, ra.pos, s, e)) {
+                if (e - s > 0xFFFFFFu) atomicOr(&p.counters->error, 4u);
+                c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true;
+            }
         }
         cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     }

@@ -109,7 +109,7 @@ struct ScanCounters {
     uint32_t n_dom;                  // domain anchors (first byte of a label that follows a dot)
     uint32_t n_hits;
     uint32_t n_ids;
-    uint32_t error;                  // bit0: glob result list overflow, bit1: glob star-stack overflow
+    uint32_t error;                  // bit0: glob result list overflow, bit1: glob star-stack overflow, bit2: candidate > 16 MiB
     uint32_t cand_true;              // candidates really written (n_cand counts chunk-allocated slots incl. padding)
     uint32_t hits_true;
     uint32_t n_final;                // dense final hit records written by k_pack
