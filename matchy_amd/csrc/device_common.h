@@ -267,6 +267,7 @@ __device__ inline bool psl_suffix_exists(const DevDb& db, const uint8_t* log, ui
     uint64_t rh = psl_hash_init();
     for (uint32_t q = hi; q-- > lo;) {
         uint32_t c = log[q];
+        if (hi - q - 1 > db.max_suffix_len) return false;   // longer than every suffix in the list
         if (c == '.') {
             if (psl_contains(db, psl_hash_finish(rh), log + q + 1, hi - q - 1)) return true;
         }

@@ -100,6 +100,7 @@ PslHost* load_psl() {
             h->bloom[b8 >> 5] |= 1u << (b8 & 31);
         }
         h->max_tld_len = std::max<uint32_t>(h->max_tld_len, (uint32_t)ll);
+        h->max_suffix_len = std::max<uint32_t>(h->max_suffix_len, (uint32_t)s.size());
         if (ll) h->tld_first[last[0] >> 5] |= 1u << (last[0] & 31);
     }
     // exact table of short last labels; flag 1 = the label by itself is a suffix ("com"), unlike e.g. "ck" (only "*.ck")
@@ -302,6 +303,7 @@ void DeviceDb::upload(const DbImage& img, int dev) {
     bloom.upload(psl.bloom);
     view.psl_slots = psl_slots.p; view.psl_mask = psl.mask; view.psl_pool = psl_pool.p; view.tld_bloom = bloom.p;
     view.max_tld_len = psl.max_tld_len;
+    view.max_suffix_len = psl.max_suffix_len;
     tld_tab.upload(psl.tld_tab);
     view.tld_tab = tld_tab.p;
     for (int k = 0; k < 8; ++k) view.tld_first[k] = psl.tld_first[k];

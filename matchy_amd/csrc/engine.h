@@ -35,7 +35,7 @@ struct PslHost {
     std::vector<uint8_t> pool;
     std::vector<uint32_t> bloom;
     std::vector<uint2> tld_tab;   // exact table of the last labels of <= 7 bytes (see DevDb::tld_tab)
-    uint32_t mask = 0, max_tld_len = 0;
+    uint32_t mask = 0, max_tld_len = 0, max_suffix_len = 0;
     uint32_t tld_first[8] = {0};
     static const PslHost& get();  // throws std::runtime_error if the container cannot be found
 };

@@ -70,8 +70,38 @@ __device__ __forceinline__ bool domain_walk_back(const LogView& lg, const DevDb&
     uint32_t labels = 1, cur = wi.cur, last_c = wi.last_c;
     uint32_t first_c = 0x100;  // byte in front of the run (0x100 = buffer start)
     while (br.pos > 0) {
+        // Long runs (hostile input: one lane walks the whole run): once the public-suffix question is settled no hash is
+        // needed any more, and whole 8-byte words of domain characters are handled with the SWAR masks — the rules only
+        // look at neighbouring bytes (dot / dash next to a dot) and count dots. The word that holds the start of the run
+        // is left to the byte loop below.
+        if ((!HASH || found) && br.pos >= 32 && (cur != 0 || last_c == '.')) {
+            constexpr uint64_t H = 0x8080808080808080ull;
+            uint32_t pos = br.pos;
+            uint64_t w = BackReader::load8(lg.p + pos - 8);
+            bool any = false;
+            for (;;) {
+                const uint64_t wn = pos >= 24 ? BackReader::load8(lg.p + pos - 16) : 0ull;   // next word, loaded early
+                const ByteMasks m = domain_masks(w);
+                if ((~m.dc & H) != 0) break;                                   // the run starts inside this word
+                // right-hand neighbour of every byte moved onto it (byte 7's neighbour is the last byte consumed)
+                const uint64_t dr = (m.dot >> 8) | (last_c == '.' ? (0x80ull << 56) : 0ull);
+                const uint64_t sr = (m.dash >> 8) | (last_c == '-' ? (0x80ull << 56) : 0ull);
+                if (((m.dot & (dr | sr)) | (m.dash & dr)) != 0) bad = true;   // empty label, label starting / ending with '-'
+                if (m.dot != 0 && !bad) found = true;
+                labels += (uint32_t)__popcll(m.dot);
+                high |= m.high != 0;
+                last_c = (uint32_t)w & 0xFF;
+                cur = last_c == '.' ? 0u : 1u;
+                pos -= 8;
+                any = true;
+                if (pos < 24) break;
+                w = wn;
+            }
+            if (any) { br.init(lg.p, pos); continue; }
+        }
         uint32_t c = br.next();
         if (!d_is_domain_char_fast(c)) { first_c = c; ++br.pos; break; }
+        if (HASH && !found && e - br.pos - 1 > db.max_suffix_len) return false;   // longer than every public suffix: no TLD
         if (c == '.') {
             if (cur == 0 || last_c == '-') bad = true;
             if (HASH) { if (!found && !bad) found = psl_contains(db, psl_hash_finish(rh), lg.p + br.pos + 1, e - br.pos - 1); }
@@ -343,25 +373,74 @@ __device__ bool val_ipv6_win(const uint8_t* win, uint32_t p2, uint32_t& start, u
     return true;
 }
 
-// E-mail (ext:891-950, 1182-1196)
+// E-mail (ext:891-950, 1182-1196). Both scans go a word at a time over long runs (a multi-megabyte local part is one
+// lane's work): the rules need the class of each byte, "two dots in a row" and "any letter", all of which the SWAR masks give.
+struct LocalMasks { uint64_t loc, dot, alp; };
+__device__ __forceinline__ LocalMasks email_local_masks(uint64_t x) {
+    constexpr uint64_t H = 0x8080808080808080ull, L7 = 0x7F7F7F7F7F7F7F7Full;
+    const uint64_t t = x & L7, l = t | 0x2020202020202020ull;
+    const uint64_t dig = (t + 0x5050505050505050ull) & ~(t + 0x4646464646464646ull);
+    const uint64_t alp = (l + 0x1F1F1F1F1F1F1F1Full) & ~(l + 0x0505050505050505ull);
+    const uint64_t ndot = (t ^ 0x2E2E2E2E2E2E2E2Eull) + L7, ndash = (t ^ 0x2D2D2D2D2D2D2D2Dull) + L7;
+    const uint64_t nus = (t ^ 0x5F5F5F5F5F5F5F5Full) + L7, npl = (t ^ 0x2B2B2B2B2B2B2B2Bull) + L7;
+    LocalMasks m;
+    m.dot = ~ndot & ~x & H;
+    m.alp = alp & ~x & H;
+    m.loc = (dig | alp | ~ndot | ~ndash | ~nus | ~npl) & ~x & H;   // is_email_local_char (ext:1644)
+    return m;
+}
 __device__ bool val_email(const LogView& lg, const DevDb& db, uint32_t at, uint32_t& start, uint32_t& end) {
-    uint32_t s = at;
-    while (s > 0 && d_is_email_local(lg.at(s - 1))) --s;
+    constexpr uint64_t H = 0x8080808080808080ull;
+    uint32_t s = at, prev = '@';
+    bool has_letter = false, dotdot = false;
+    if (s >= 32) {
+        uint64_t w = BackReader::load8(lg.p + s - 8);
+        for (;;) {
+            const uint64_t wn = BackReader::load8(lg.p + s - 16);
+            const LocalMasks m = email_local_masks(w);
+            if ((~m.loc & H) != 0) break;
+            const uint64_t dr = (m.dot >> 8) | (prev == '.' ? (0x80ull << 56) : 0ull);
+            dotdot |= (m.dot & dr) != 0;
+            has_letter |= m.alp != 0;
+            prev = (uint32_t)w & 0xFF;
+            s -= 8;
+            if (s < 32) break;
+            w = wn;
+        }
+    }
+    while (s > 0) {
+        const uint32_t c = lg.at(s - 1);
+        if (!d_is_email_local(c)) break;
+        dotdot |= c == '.' && prev == '.';
+        has_letter |= d_is_alpha(c);
+        prev = c;
+        --s;
+    }
     if (s == at) return false;
     if (s > 0 && !d_is_boundary(lg.at(s - 1))) return false;
     uint32_t e = at + 1;
-    while (e < lg.len && d_is_domain_char(lg.at(e))) ++e;
+    bool has_dot = false;
+    if (e + 32 <= lg.len) {
+        uint64_t w = BackReader::load8(lg.p + e);
+        for (;;) {
+            const uint64_t wn = BackReader::load8(lg.p + e + 8);
+            const ByteMasks m = domain_masks(w);
+            if ((~(m.dc & ~m.high) & H) != 0) break;                  // is_domain_char (ext:1639): ASCII only
+            has_dot |= m.dot != 0;
+            e += 8;
+            if (e + 32 > lg.len) break;
+            w = wn;
+        }
+    }
+    while (e < lg.len) {
+        const uint32_t c = lg.at(e);
+        if (!d_is_domain_char(c)) break;
+        has_dot |= c == '.';
+        ++e;
+    }
     if (e == at + 1) return false;
     if (e < lg.len && !d_is_boundary(lg.at(e))) return false;
-    bool has_letter = false, has_dot = false;
-    for (uint32_t k = s; k < at; ++k) {
-        uint32_t c = lg.at(k);
-        if (c == '.' && k + 1 < at && lg.at(k + 1) == '.') return false;
-        has_letter |= d_is_alpha(c);
-    }
-    if (!has_letter) return false;
-    for (uint32_t k = at + 1; k < e; ++k) has_dot |= lg.at(k) == '.';
-    if (!has_dot) return false;
+    if (dotdot || !has_letter || !has_dot) return false;
     if (!psl_suffix_exists(db, lg.p, at + 1, e)) return false;
     start = s; end = e;  // all bytes are ASCII: from_utf8 always succeeds
     return true;

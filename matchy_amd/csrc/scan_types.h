@@ -91,6 +91,7 @@ struct DevDb {
     const uint8_t* psl_pool;
     const uint32_t* tld_bloom;    // TLD_BLOOM_WORDS words: bloom over the LAST labels of all suffixes
     uint32_t max_tld_len;
+    uint32_t max_suffix_len;      // longest suffix in bytes: a hash walk that has gone further cannot find one any more
     // exact open-addressing table (1 << TLD_TAB_BITS slots) of the last labels of <= 7 bytes: x = bytes 0..3, y = bytes
     // 4..6 | flags << 24 (0x80 occupied, 0x01 the label alone is a public suffix); slot = tld_tab_slot(x, y & 0xFFFFFF)
     const uint2* tld_tab;

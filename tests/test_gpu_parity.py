@@ -240,6 +240,77 @@ def test_concurrent_queries_and_scans(M, oracle):
     db.close()
 
 
+def _long_domain_runs(seed, count=700):
+    """Runs of 40..3000 domain characters: many labels, dashes beside dots at every alignment, empty labels, high bytes."""
+    rng = random.Random(seed)
+    alpha = b"abcdefghijklmnopqrstuvwxyz0123456789"
+    tails = [b"com", b"co.uk", b"ck", b"www.ck", b"zip", b"nosuchtld", b"museum", b"xn--p1ai", "рф".encode()]
+    buf = bytearray()
+    for i in range(count):
+        parts = []
+        total = 0
+        want_len = rng.choice([40, 64, 100, 257, 700, 3000])
+        while total < want_len:
+            n = rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 63, 64, 120])
+            lab = bytearray(rng.choice(alpha) for _ in range(n))
+            r = rng.random()
+            if r < 0.015:
+                lab = bytearray(b"-") + lab
+            elif r < 0.03:
+                lab += b"-"
+            elif r < 0.06 and n > 2:
+                lab[rng.randrange(1, n - 1)] = ord("-")
+            elif r < 0.07:
+                lab = bytearray()
+            elif r < 0.09:
+                lab += "ü".encode()
+            elif r < 0.095:
+                lab += b"\xc3"
+            parts.append(bytes(lab))
+            total += len(lab) + 1
+        buf += rng.choice([b" ", b"\n", b"/", b"=", b"x ", b"_", b"@"]) + b".".join(parts + [rng.choice(tails)]) + rng.choice([b" ", b"\n", b"/", b":", b"_"])
+    return bytes(buf)
+
+
+def _long_emails(seed, count=500):
+    rng = random.Random(seed)
+    alpha = b"abcdefghijklmnopqrstuvwxyz0123456789ABC"
+    buf = bytearray()
+    for i in range(count):
+        n = rng.choice([1, 7, 8, 9, 24, 31, 32, 33, 40, 100, 1000])
+        r = rng.random()
+        loc = bytearray(rng.choice(b"0123456789") if r < 0.1 else rng.choice(alpha) for _ in range(n))
+        for _ in range(rng.choice([0, 0, 1, 3, 10])):
+            loc[rng.randrange(n)] = rng.choice(b"._+-.")
+        if rng.random() < 0.1 and n > 2:
+            k = rng.randrange(n - 1)
+            loc[k:k + 2] = b".."
+        if rng.random() < 0.05:
+            loc[rng.randrange(n)] = rng.choice(b"!\xc3~*")
+        dom = b".".join(bytes(rng.choice(alpha) for _ in range(rng.choice([1, 5, 8, 30, 200]))) for _ in range(rng.choice([1, 2, 3, 12])))
+        dom += rng.choice([b".com", b".co.uk", b".nosuch", b"", b".ck", b".x.ck", b".museum", b"\xc3\xa9.com"])
+        buf += rng.choice([b" ", b"\n", b"<", b"x", b"=", b"\xff"]) + bytes(loc) + b"@" + dom + rng.choice([b" ", b"\n", b">", b"_", b"@"])
+    return bytes(buf)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_long_domain_runs(M, oracle, seed):
+    """The word-at-a-time continuation of the backward domain walk (domain_walk_back, after the public-suffix question is
+    settled) against the oracle's byte walk."""
+    buf = _long_domain_runs(seed)
+    ex = M.Extractor()
+    got, want = ex.extract_from_chunk(buf), oracle.extract(buf)
+    ex.close()
+    assert sum(1 for t, s, e, v in want if t == "Domain" and e - s > 64) > 100
+    assert got == want
+    buf = _long_emails(seed)
+    ex = M.Extractor()
+    got, want = ex.extract_from_chunk(buf), oracle.extract(buf)
+    ex.close()
+    assert sum(1 for t, s, e, v in want if t == "Email" and e - s > 64) > 50
+    assert got == want
+
+
 @pytest.mark.parametrize("seed", [42, 7, 20251212])
 def test_domain_rules_structured_fuzz(M, oracle, seed):
     """Structure-aware differential fuzz of the domain rules (labels with dashes, empty labels, high bytes, long names,
