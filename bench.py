@@ -53,6 +53,9 @@ def main():
     from tools import synth
 
     cfg = synth.config(args.config)
+    base_name = args.config.split("/")[0]
+    cfg_index = {"c1": 0, "c2": 1, "c3": 2, "c3b": 2, "c4": 3, "c5": 4}[base_name]
+    cfg_note = (" (AC-forced variant, glob: keys)" if base_name == "c3b" else "") + (f" (indicators scaled 1/{args.config.split('/')[1]})" if "/" in args.config else "")
     blob = synth.build_db(cfg)
     db = M.Database(blob)
     scanner = M.Scanner(db, extract_flags=args.extract_flags, device=local_rank, profile=True)
@@ -165,7 +168,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {cfg.n_ip + cfg.n_cidr + cfg.n_dom + cfg.n_hash + cfg.n_glob} mixed IoCs "
+            "config": {"workload": f"BASELINE configs[{cfg_index}]{cfg_note}: {cfg.n_ip + cfg.n_cidr + cfg.n_dom + cfg.n_hash + cfg.n_glob} mixed IoCs "
                                    f"({cfg.n_ip} IPv4 + {cfg.n_cidr} CIDR + {cfg.n_dom} domains + {cfg.n_hash} hashes + {cfg.n_glob} globs), "
                                    f"{args.lines} nginx-style lines per GPU",
                        "lines_per_gpu": args.lines, "bytes_per_gpu": nbytes, "sharding": "line-block per GPU, DB replicated, no collective"},

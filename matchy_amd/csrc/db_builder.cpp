@@ -729,6 +729,11 @@ bool DatabaseBuilder::build(std::vector<uint8_t>& db) {
         for (auto* e : ips) needs_v6 |= e->addr.v6;
         size_t est = ips.size();
         record_size = est > 200000000 ? 32 : est > 15000000 ? 28 : 24;
+        // test hook: a larger minimum record size, so that the 28- and 32-bit readers are exercised by small databases
+        if (const char* f = getenv("MATCHY_AMD_MIN_RECORD_SIZE")) {
+            const int want = atoi(f);
+            if ((want == 28 || want == 32) && want > record_size) record_size = want;
+        }
         // (prefix desc, addr asc) with IpAddr ordering V4 < V6 (mmdb_builder.rs:485-487)
         std::stable_sort(ips.begin(), ips.end(), [](const Entry* a, const Entry* b) {
             if (a->prefix_len != b->prefix_len) return a->prefix_len > b->prefix_len;

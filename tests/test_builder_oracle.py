@@ -221,3 +221,38 @@ def test_validate_and_schema_entry_points(tmp_path):
     L.matchy_get_stats(None, None)
     L.matchy_clear_cache(None)
     assert L.matchy_has_pattern_data(None) is False
+
+
+@pytest.mark.parametrize("bits", [28, 32])
+def test_wider_tree_records_read_back_identically(oracle, monkeypatch, bits):
+    """28- and 32-bit MMDB records (format.rs:31-171 / tree.rs:46-130; chosen for very large trees, BASELINE configs[4]):
+    the same entries written with 24-, 28- and 32-bit records answer every probe identically, IPv4 and IPv6."""
+    import random
+    rng = random.Random(bits)
+    entries = []
+    for i in range(3000):
+        a = rng.getrandbits(32)
+        p = rng.choice([8, 12, 16, 20, 23, 24, 24, 24, 28, 32, 32])
+        a &= 0xFFFFFFFF ^ ((1 << (32 - p)) - 1)
+        entries.append((f"{a >> 24}.{(a >> 16) & 255}.{(a >> 8) & 255}.{a & 255}/{p}", {"i": i}))
+    for i in range(300):
+        entries.append((f"2001:db8:{rng.getrandbits(16):x}::/{rng.choice([48, 56, 64])}", {"v6": i}))
+    monkeypatch.delenv("MATCHY_AMD_MIN_RECORD_SIZE", raising=False)
+    narrow = oracle.Database(build(entries))
+    monkeypatch.setenv("MATCHY_AMD_MIN_RECORD_SIZE", str(bits))
+    wide = oracle.Database(build(entries))
+    assert narrow.metadata()["record_size"] == 24 and wide.metadata()["record_size"] == bits
+    assert narrow.metadata()["node_count"] == wide.metadata()["node_count"]
+    probes = []
+    for k, _ in entries[::7]:
+        probes.append(k.split("/")[0])
+    for _ in range(2000):
+        a = rng.getrandbits(32)
+        probes.append(f"{a >> 24}.{(a >> 16) & 255}.{(a >> 8) & 255}.{a & 255}")
+    probes += [f"2001:db8:{rng.getrandbits(16):x}::1" for _ in range(300)] + ["::1", "::ffff:1.2.3.4", "1.2.3.4"]
+    hits = 0
+    for q in probes:
+        a, b = narrow.lookup(q), wide.lookup(q)
+        assert a == b, q
+        hits += a is not None and a.get("kind") == "ip"
+    assert hits > 300

@@ -145,7 +145,8 @@ def test_scan_small_combined_database(M, oracle):
     assert len(gh) >= 8
 
 
-@pytest.mark.parametrize("cfgname,lines", [("c1", 10000), ("c2/20", 20000), ("c3/20", 20000), ("c3b/20", 20000), ("c4/20", 20000)])
+@pytest.mark.parametrize("cfgname,lines", [("c1", 10000), ("c2/20", 20000), ("c3/20", 20000), ("c3b/20", 20000), ("c4/20", 20000),
+                                           ("c5/100", 20000)])
 def test_scan_synthetic_configs(M, oracle, cfgname, lines):
     from tools import synth
     cfg = synth.config(cfgname)
@@ -156,6 +157,23 @@ def test_scan_synthetic_configs(M, oracle, cfgname, lines):
     assert len(gh) == len(wh)
     assert gh == wh
     assert gl == wl
+    assert len(gh) > 50
+
+
+@pytest.mark.parametrize("bits", [28, 32])
+def test_scan_wide_tree_records(M, oracle, monkeypatch, bits):
+    """BASELINE configs[4] selects 28-bit tree records at full size (18M nodes); here the same indicator mix, scaled, is
+    written with 28- and 32-bit records (builder test hook) and scanned: hits and prefix lengths equal the oracle's."""
+    from tools import synth
+    monkeypatch.setenv("MATCHY_AMD_MIN_RECORD_SIZE", str(bits))
+    cfg = synth.config("c5/200")
+    blob = synth.build_db(cfg)
+    monkeypatch.delenv("MATCHY_AMD_MIN_RECORD_SIZE")
+    odb = oracle.Database(blob)
+    assert odb.metadata()["record_size"] == bits
+    text = synth.make_log(cfg, 0, 10000)
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, text)
+    assert gs == ws and gh == wh and gl == wl
     assert len(gh) > 50
 
 

@@ -16,7 +16,7 @@ SEED = 0x6D61746368790001  # "matchy\0\1" — SURVEY §8d
 
 class Cfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_ip", C.c_uint32), ("n_cidr", C.c_uint32), ("n_dom", C.c_uint32),
-                ("n_hash", C.c_uint32), ("n_glob", C.c_uint32), ("hit_permille", C.c_uint32)]
+                ("n_hash", C.c_uint32), ("n_glob", C.c_uint32), ("hit_permille", C.c_uint32), ("cidr_mode", C.c_uint32)]
 
 
 def config(name: str) -> Cfg:
@@ -37,9 +37,11 @@ def config(name: str) -> Cfg:
         "c3": dict(n_ip=0, n_cidr=0, n_dom=700000, n_hash=300000, n_glob=0),
         # C4: C2 with 10K domains replaced by *.domain globs
         "c4": dict(n_ip=40000, n_cidr=10000, n_dom=25000, n_hash=15000, n_glob=10000),
+        # C5: 10M IoCs, CIDR-heavy ip-trie (9M: 70 % /24, 20 % /16../23, 10 % /32) + 1M domains
+        "c5": dict(n_ip=0, n_cidr=9000000, n_dom=1000000, n_hash=0, n_glob=0),
     }
     p = {k: max(v // scale, 1 if v else 0) for k, v in presets[name].items()}
-    cfg = Cfg(seed=SEED, hit_permille=20, **p)
+    cfg = Cfg(seed=SEED, hit_permille=20, cidr_mode=1 if name == "c5" else 0, **p)
     cfg.glob_prefix = glob_prefix
     return cfg
 
@@ -56,6 +58,8 @@ def lib():
         L = C.CDLL(str(LIB))
         L.synth_log.argtypes = [C.POINTER(Cfg), C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]
         L.synth_log.restype = C.c_size_t
+        L.synth_ioc_feed.argtypes = [C.POINTER(Cfg), C.c_int, C.c_void_p, C.c_void_p]
+        L.synth_ioc_feed.restype = C.c_longlong
         for f in (L.synth_ioc_key, L.synth_ioc_data):
             f.argtypes = [C.POINTER(Cfg), C.c_int, C.c_uint32, C.c_char_p, C.c_size_t]
             f.restype = C.c_size_t
@@ -101,10 +105,11 @@ def build_db(cfg: Cfg, epoch=1700000000) -> bytes:
     import matchy_amd as M
     ML = M.lib()
     b = M.DatabaseBuilder(build_epoch=epoch)
-    for key, data in ioc_entries(cfg):
-        rc = ML.matchy_builder_add(b._h, key, data)
-        if rc != 0:
-            raise ValueError(f"builder rejected {key!r}: {M.last_error()}")
+    # the whole feed runs in C++ (tools/synthgen.cpp calls matchy_builder_add directly: 10M entries for C5)
+    fed = lib().synth_ioc_feed(C.byref(cfg), 1 if getattr(cfg, "glob_prefix", False) else 0,
+                               C.cast(ML.matchy_builder_add, C.c_void_p), b._h)
+    if fed < 0:
+        raise ValueError(f"builder rejected entry #{-fed - 1}: {M.last_error()}")
     blob = b.build()
     b.close()
     return blob

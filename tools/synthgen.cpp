@@ -23,6 +23,7 @@ struct Cfg {
     uint64_t seed;
     uint32_t n_ip, n_cidr, n_dom, n_hash, n_glob;
     uint32_t hit_permille;   // share of lines (per mille) whose client IP / referer is planted from the DB
+    uint32_t cidr_mode;      // 0: prefixes /16../30 uniform; 1: BASELINE configs[4] mix (70 % /24, 20 % /16../23, 10 % /32)
 };
 
 const char* TLDS[20] = {"com", "net", "org", "info", "biz", "io", "co", "ru", "cn", "de", "uk", "fr", "nl", "br", "in", "xyz", "top", "site", "online", "app"};
@@ -80,6 +81,10 @@ void ioc_key(const Cfg& c, int kind, uint32_t i, std::string& out) {
         case 1: {
             // prefixes /16../30: the set covers ~1-2 % of the IPv4 space, so the line hit rate stays a few per cent
             uint32_t p = 16 + (uint32_t)((h >> 8) % 15);
+            if (c.cidr_mode == 1) {  // CIDR-heavy feed: mostly /24 blocks, some larger allocations, some single hosts
+                const uint32_t r = (uint32_t)((h >> 8) % 100);
+                p = r < 70 ? 24 : r < 90 ? 16 + (uint32_t)((h >> 20) % 8) : 32;
+            }
             uint32_t a = public_v4(splitmix64(h));
             a &= p == 32 ? 0xFFFFFFFFu : ~((1u << (32 - p)) - 1);
             ipv4_str(a, out);
@@ -176,9 +181,9 @@ void gen_line(const Cfg& c, uint64_t L, std::string& out) {
 
 extern "C" {
 
-struct synth_cfg_t { uint64_t seed; uint32_t n_ip, n_cidr, n_dom, n_hash, n_glob, hit_permille; };
+struct synth_cfg_t { uint64_t seed; uint32_t n_ip, n_cidr, n_dom, n_hash, n_glob, hit_permille, cidr_mode; };
 
-static Cfg to_cfg(const synth_cfg_t* c) { return Cfg{c->seed, c->n_ip, c->n_cidr, c->n_dom, c->n_hash, c->n_glob, c->hit_permille}; }
+static Cfg to_cfg(const synth_cfg_t* c) { return Cfg{c->seed, c->n_ip, c->n_cidr, c->n_dom, c->n_hash, c->n_glob, c->hit_permille, c->cidr_mode}; }
 
 // Writes lines [first, first+n) into out (capacity cap). Returns bytes written, or the required size if cap is too small.
 size_t synth_log(const synth_cfg_t* cfg, uint64_t first, uint64_t n, uint8_t* out, size_t cap) {
@@ -204,6 +209,25 @@ size_t synth_ioc_data(const synth_cfg_t* cfg, int kind, uint32_t i, char* out, s
     ioc_data(to_cfg(cfg), kind, i, s);
     if (s.size() + 1 <= cap) memcpy(out, s.c_str(), s.size() + 1);
     return s.size();
+}
+// Feeds every indicator of the config, in CSV row order, to `add(builder, key, json)` (the product's matchy_builder_add);
+// `glob_prefix` writes string keys as glob:{key}. Returns the number of entries fed, or -(index + 1) of the first rejected one.
+typedef int32_t (*synth_add_fn)(void* builder, const char* key, const char* json);
+long long synth_ioc_feed(const synth_cfg_t* cfg, int glob_prefix, synth_add_fn add, void* builder) {
+    const Cfg c = to_cfg(cfg);
+    const uint32_t counts[5] = {c.n_ip, c.n_cidr, c.n_dom, c.n_hash, c.n_glob};
+    long long fed = 0;
+    std::string k, d;
+    for (int kind = 0; kind < 5; ++kind)
+        for (uint32_t i = 0; i < counts[kind]; ++i) {
+            k.clear(); d.clear();
+            if (glob_prefix && kind >= 2) k = "glob:";
+            ioc_key(c, kind, i, k);
+            ioc_data(c, kind, i, d);
+            if (add(builder, k.c_str(), d.c_str()) != 0) return -(fed + 1);
+            ++fed;
+        }
+    return fed;
 }
 
 }  // extern "C"
