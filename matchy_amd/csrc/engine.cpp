@@ -270,6 +270,7 @@ void DeviceDb::upload(const DbImage& img, int dev) {
             if (img.build_ac_dfa(nx, cls, k, noff, limit)) {
                 dfa.upload(nx); dfa_node.upload(noff); dfa_cls.upload(cls);
                 view.dfa = dfa.p; view.dfa_node = dfa_node.p; view.dfa_cls = dfa_cls.p; view.dfa_k = k;
+                view.dfa_states = (uint32_t)noff.size();
                 bytes_uploaded += nx.size() * 4 + noff.size() * 4 + 256;
             }
         }
@@ -360,7 +361,11 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.log = dptr; tp.len = len; tp.flags = flags_; tp.min_labels = min_labels_;
     tp.filter_v4 = lookup ? 1u : 0u;
     // without a glob section a string candidate can only hit through the literal table
-    tp.filter_lit = (lookup && !ddb_->view.has_glob) ? 1u : 0u;
+    // with a glob section also through a glob, and every glob with a literal part needs an output state of the AC
+    // automaton on the way (pure-wildcard patterns match without one: no prefilter then)
+    const bool ac_ok = ddb_->view.has_glob && ddb_->view.dfa && ddb_->view.wild_count == 0;
+    tp.filter_ac = (lookup && ac_ok) ? 1u : 0u;
+    tp.filter_lit = (lookup && (!ddb_->view.has_glob || ac_ok)) ? 1u : 0u;
     if (const char* dbg = getenv("MATCHY_AMD_DEBUG")) tp.debug = (uint32_t)atoi(dbg);
     tp.n_segs = (uint32_t)(((uint64_t)len + 1 + SEG_BYTES - 1) / SEG_BYTES);
     tp.cands = cands_.p; tp.cand_cap = (uint32_t)cands_.n;

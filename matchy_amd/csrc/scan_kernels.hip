@@ -675,14 +675,42 @@ __device__ bool val_eth(const uint8_t* a, uint8_t* lower) {  // ext:1328-1361, 1
     return true;
 }
 
+// One transition of the flattened automaton. States are numbered breadth-first, so the rows of the shallowest states —
+// where almost every step of a non-matching text happens — are the first ones; the kernels keep them in LDS.
+struct DfaView { const uint8_t* cls; const uint32_t* rows; uint32_t lds_states; };   // cls, rows: LDS
+__device__ __forceinline__ uint32_t dfa_step(const DevDb& db, const DfaView& dv, uint32_t st, uint32_t byte) {
+    const uint32_t c = dv.cls[byte];
+    return st < dv.lds_states ? dv.rows[st * db.dfa_k + c] : db.dfa[(size_t)st * db.dfa_k + c];
+}
+template <uint32_t ENTRIES>
+__device__ __forceinline__ DfaView dfa_stage(const DevDb& db, uint8_t* cls, uint32_t* rows) {   // call before a __syncthreads()
+    DfaView dv{cls, rows, 0};
+    if (db.dfa) {
+        dv.lds_states = min(db.dfa_states, ENTRIES / db.dfa_k);
+        for (uint32_t k = threadIdx.x; k < 256; k += blockDim.x) cls[k] = db.dfa_cls[k];
+        for (uint32_t k = threadIdx.x, nk = dv.lds_states * db.dfa_k; k < nk; k += blockDim.x) rows[k] = db.dfa[k];
+    } else {
+        for (uint32_t k = threadIdx.x; k < 256; k += blockDim.x) cls[k] = 0;
+    }
+    return dv;
+}
+
 // k_validate_dom — stage A2a: one lane per domain anchor with its context record (planes written by k_anchor, read
 // coalesced). Lean on purpose (no general walk, no global log reads): it is latency-bound, so its speed is the number of
 // resident waves. Anchors it cannot decide (no context, last label > 7 bytes or not a suffix on its own, name longer than
 // the context, non-ASCII) go to the rare list as RARE_DOM for k_validate.
+// AC (p.filter_ac): databases with globs — a name is listed if its hash is in the literal bitmap or its text reaches an output
+// state of the glob automaton (walked here from the context bytes, shallow rows in LDS), so k_lookup does not have to fetch
+// the text of every valid name from the log again.
+template <bool AC>
 __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
     __shared__ uint2 tldtab[1u << TLD_TAB_BITS];
     __shared__ __attribute__((aligned(16))) uint32_t strbuf[256][8];   // per-lane context bytes for hashing
+    __shared__ uint8_t dcls[AC ? 256 : 4];
+    __shared__ uint32_t drows[AC ? DFA_LDS_ENTRIES_VAL : 1];
     for (uint32_t i = threadIdx.x; i < (1u << TLD_TAB_BITS); i += blockDim.x) tldtab[i] = db.tld_tab[i];
+    DfaView dv{dcls, drows, 0};
+    if constexpr (AC) dv = dfa_stage<DFA_LDS_ENTRIES_VAL>(db, dcls, drows);
     __syncthreads();
     // candidates: dense when every valid domain is listed (chunks of CAND_CHUNK), sparse otherwise (chunks of 64 keep
     // the list free of padding for k_lookup)
@@ -759,6 +787,16 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
                     const uint32_t b = lit_bm_bit(h) & db.lit_bm_mask;
                     pend_word = db.lit_bm ? db.lit_bm[b >> 5] : 0u;
                     pend_bit = b & 31;
+                    if constexpr (AC) {
+                        const uint8_t* nb = reinterpret_cast<const uint8_t*>(sb) + o;
+                        uint32_t st = 0, any = 0;
+                        for (uint32_t k = 0; k < n; ++k) {
+                            const uint32_t t = dfa_step(db, dv, st, nb[k]);
+                            st = t & 0x7FFFFFFFu;
+                            any |= t;
+                        }
+                        if (any >> 31) { pend_word = 0xFFFFFFFFu; pend_bit = 0; }
+                    }
                 }
             }
         }
@@ -1017,10 +1055,53 @@ __device__ uint32_t ac_transition(const uint8_t* ac, uint32_t ac_len, uint32_t n
 __device__ __forceinline__ uint32_t utf8_adv(uint32_t c) { return c < 0x80 ? 1 : c < 0xE0 ? 2 : c < 0xF0 ? 3 : 4; }
 __device__ __forceinline__ bool is_rust_char(uint32_t c) { return c < 0xD800 || (c > 0xDFFF && c <= 0x10FFFF); }
 
+// Candidate text as the glob pass reads it: the first GLOB_WIN bytes sit in a per-lane LDS window (the star loop of a
+// `*literal` pattern probes the text once per position; from the log each probe would be a dependent global load), the
+// rest comes from the log.
+constexpr uint32_t GLOB_WIN = 64, GLOB_WIN_WORDS = GLOB_WIN / 8 + 1;
+struct TextView {
+    const uint8_t* g;     // the text in the log
+    uint32_t n;           // its length
+    const uint64_t* w;    // LDS window, GLOB_WIN_WORDS words; bytes past the staged ones are zero
+    uint32_t wn;          // bytes staged
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return i < wn ? (uint32_t)(w[i >> 3] >> ((i & 7) * 8)) & 0xFF : g[i]; }
+    // bytes i..i+7 little-endian; bytes at or past n are unspecified
+    __device__ __forceinline__ uint64_t load8(uint32_t i) const {
+        if (i < wn && (i + 8 <= wn || wn >= n)) {   // all 8 bytes staged, or nothing exists past the staged ones
+            const uint64_t a = w[i >> 3], b = w[(i >> 3) + 1];
+            const uint32_t sh = (i & 7) * 8;
+            return sh ? (a >> sh) | (b << (64 - sh)) : a;
+        }
+        uint64_t v = 0;
+        if (i + 8 <= n) __builtin_memcpy(&v, g + i, 8);
+        else for (uint32_t b = 0; i + b < n; ++b) v |= (uint64_t)g[i + b] << (8 * b);
+        return v;
+    }
+};
+// stage the first bytes of text[0, n) (inside log[0, log_len)) into the lane's window
+__device__ __forceinline__ TextView text_stage(const uint8_t* log, uint32_t log_len, uint32_t start, uint32_t n, uint64_t* win) {
+    TextView tv{log + start, n, win, min(n, GLOB_WIN)};
+#pragma unroll
+    for (uint32_t k = 0; k < GLOB_WIN_WORDS; ++k) {
+        uint64_t v = 0;
+        const uint32_t o = k * 8;
+        if (o < tv.wn) {
+            if (start + o + 8 <= log_len) __builtin_memcpy(&v, log + start + o, 8);
+            else for (uint32_t b = 0; start + o + b < log_len; ++b) v |= (uint64_t)log[start + o + b] << (8 * b);
+            if (tv.wn - o < 8) v &= (1ull << ((tv.wn - o) * 8)) - 1;
+        }
+        win[k] = v;
+    }
+    return tv;
+}
+
 // match_glob_from_buffer / match_segments_impl (pg:1364-1639), case-sensitive. The recursion is replayed with an
 // explicit stack of Star frames; every call of the reference consumes one unit of the 100 000-step budget here too.
-__device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const uint8_t* text, uint32_t tn, uint32_t* err) {
+// The header of the segment last looked at and the first 8 bytes of its literal stay in registers: a star re-enters the
+// same segment once per text position.
+__device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView& text, uint32_t* err) {
     const uint8_t* pg = db.pg;
+    const uint32_t tn = text.n;
     uint32_t io = db.glob_seg_off + pattern_id * 8;
     if (io + 8 > db.pg_len) return false;
     uint32_t first = ld32(pg + io);
@@ -1030,6 +1111,8 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const uint8_t* 
     int sp = 0;
     uint32_t pos = 0, seg = 0;
     bool result = false;
+    uint32_t c_seg = 0xFFFFFFFFu, c_h0 = 0, c_dlen = 0, c_doff = 0;
+    uint64_t c_lit8 = 0;
     for (;;) {
         // ---- CALL(pos, seg)
         bool ret = false;
@@ -1040,25 +1123,45 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const uint8_t* 
             uint32_t so = first + seg * 12;
             if (so + 12 > db.pg_len) { result = false; ret = true; }
             else {
-                uint32_t h0 = ld32(pg + so);
-                uint32_t st = h0 & 0xFF, fl = (h0 >> 8) & 0xFF;
-                uint32_t dlen = ld32(pg + so + 4), doff = ld32(pg + so + 8);
+                if (seg != c_seg) {
+                    c_seg = seg;
+                    c_h0 = ld32(pg + so); c_dlen = ld32(pg + so + 4); c_doff = ld32(pg + so + 8);
+                    c_lit8 = 0;
+                    if ((c_h0 & 0xFF) == 0 && c_doff + c_dlen <= db.pg_len) {
+                        if (c_dlen >= 8) __builtin_memcpy(&c_lit8, pg + c_doff, 8);
+                        else for (uint32_t k = 0; k < c_dlen; ++k) c_lit8 |= (uint64_t)pg[c_doff + k] << (8 * k);
+                    }
+                }
+                const uint32_t st = c_h0 & 0xFF, fl = (c_h0 >> 8) & 0xFF, dlen = c_dlen, doff = c_doff;
                 if (st == 0) {
                     bool ok = doff + dlen <= db.pg_len && tn - pos >= dlen;
-                    if (ok) for (uint32_t k = 0; k < dlen; ++k) if (pg[doff + k] != text[pos + k]) { ok = false; break; }
+                    if (ok && dlen) {
+                        const uint64_t m0 = dlen >= 8 ? ~0ull : (1ull << (dlen * 8)) - 1;
+                        uint64_t diff = (text.load8(pos) ^ c_lit8) & m0;
+                        if (diff == 0) {
+                            for (uint32_t k = 8; k < dlen; k += 8) {   // no early exit: the loads are independent
+                                const uint32_t r = dlen - k;
+                                uint64_t x = 0;
+                                if (r >= 8) __builtin_memcpy(&x, pg + doff + k, 8);
+                                else for (uint32_t b = 0; b < r; ++b) x |= (uint64_t)pg[doff + k + b] << (8 * b);
+                                diff |= (text.load8(pos + k) ^ x) & (r >= 8 ? ~0ull : (1ull << (r * 8)) - 1);
+                            }
+                        }
+                        ok = diff == 0;
+                    }
                     if (ok) { pos += dlen; ++seg; } else { result = false; ret = true; }
                 } else if (st == 1) {
                     if (seg + 1 >= count) { result = true; ret = true; }
                     else if (sp >= (int)MAX_GLOB_STARS) { atomicOr(err, 2u); return false; }
                     else { st_seg[sp] = seg; st_pos[sp] = pos; ++sp; ++seg; }
                 } else if (st == 2) {
-                    if (pos < tn) { pos += utf8_adv(text[pos]); ++seg; } else { result = false; ret = true; }
+                    if (pos < tn) { pos += utf8_adv(text.at(pos)); ++seg; } else { result = false; ret = true; }
                 } else if (st == 3) {
                     if (pos >= tn || doff + dlen > db.pg_len) { result = false; ret = true; }
                     else {
-                        uint32_t c = text[pos], adv = utf8_adv(c);
+                        uint32_t c = text.at(pos), adv = utf8_adv(c);
                         uint32_t cp = adv == 1 ? c : adv == 2 ? (c & 0x1F) : adv == 3 ? (c & 0x0F) : (c & 0x07);
-                        for (uint32_t k = 1; k < adv && pos + k < tn; ++k) cp = (cp << 6) | (text[pos + k] & 0x3F);
+                        for (uint32_t k = 1; k < adv && pos + k < tn; ++k) cp = (cp << 6) | (text.at(pos + k) & 0x3F);
                         bool in_class = false;
                         for (uint32_t k = 0; k < dlen / 12 && !in_class; ++k) {
                             const uint8_t* it = pg + doff + k * 12;
@@ -1078,7 +1181,7 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const uint8_t* 
             if (result) { --sp; continue; }  // star returns true: propagate
             uint32_t fp = st_pos[sp - 1];
             if (fp >= tn) { --sp; continue; }  // star exhausted: returns false, propagate
-            fp += utf8_adv(text[fp]);
+            fp += utf8_adv(text.at(fp));
             st_pos[sp - 1] = fp;
             pos = fp;
             seg = st_seg[sp - 1] + 1;
@@ -1088,7 +1191,8 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const uint8_t* 
 }
 
 // Paraglob::find_all (pg:1028-1182): returns the sorted unique pattern ids in out[0..n)
-__device__ uint32_t glob_find_all(const DevDb& db, const uint8_t* cls, const uint8_t* text, uint32_t tn, uint32_t* out, uint32_t* err) {
+__device__ uint32_t glob_find_all(const DevDb& db, const DfaView& dv, const TextView& text, uint32_t* out, uint32_t* err) {
+    const uint32_t tn = text.n;
     uint32_t n = 0;
     auto insert = [&](uint32_t id) {
         uint32_t k = 0;
@@ -1106,14 +1210,14 @@ __device__ uint32_t glob_find_all(const DevDb& db, const uint8_t* cls, const uin
         uint32_t entry_id = ld32(db.pg + eo);
         uint32_t ptype = db.pg[eo + 4];
         if (contains(entry_id)) return;
-        if (ptype == 0 || glob_match(db, entry_id, text, tn, err)) insert(entry_id);
+        if (ptype == 0 || glob_match(db, entry_id, text, err)) insert(entry_id);
     };
     for (uint32_t i = 0; i < db.wild_count; ++i) {
         uint32_t wo = db.wild_off + i * 8;
         if (wo + 8 > db.pg_len) continue;
         uint32_t pid = ld32(db.pg + wo);
         if (db.patterns_off + pid * 16 + 16 > db.pg_len) continue;
-        if (!contains(pid) && glob_match(db, pid, text, tn, err)) insert(pid);
+        if (!contains(pid) && glob_match(db, pid, text, err)) insert(pid);
     }
     if (db.ac_size > 0 && tn > 0) {
         const uint8_t* ac = db.pg + db.ac_start;
@@ -1133,12 +1237,10 @@ __device__ uint32_t glob_find_all(const DevDb& db, const uint8_t* cls, const uin
             // flattened automaton: one table load per byte, the text fetched 8 bytes at a time
             uint32_t st = 0;
             for (uint32_t i = 0; i < tn; i += 8) {
-                uint64_t w = 0;
+                uint64_t w = text.load8(i);
                 const uint32_t m = min(8u, tn - i);
-                if (m == 8) __builtin_memcpy(&w, text + i, 8);
-                else for (uint32_t b = 0; b < m; ++b) w |= (uint64_t)text[i + b] << (8 * b);
                 for (uint32_t b = 0; b < m; ++b) {
-                    const uint32_t e = db.dfa[(size_t)st * db.dfa_k + cls[(uint32_t)w & 0xFF]];
+                    const uint32_t e = dfa_step(db, dv, st, (uint32_t)w & 0xFF);
                     w >>= 8;
                     st = e & 0x7FFFFFFFu;
                     if (e >> 31) outputs(db.dfa_node[st]);
@@ -1147,7 +1249,7 @@ __device__ uint32_t glob_find_all(const DevDb& db, const uint8_t* cls, const uin
         } else {
             uint32_t cur = 0;
             for (uint32_t i = 0; i < tn; ++i) {
-                uint32_t ch = text[i];
+                uint32_t ch = text.at(i);
                 for (;;) {
                     uint32_t nx = ac_transition(ac, db.ac_size, cur, ch);
                     if (nx != 0xFFFFFFFFu) { cur = nx; break; }
@@ -1165,7 +1267,7 @@ __device__ uint32_t glob_find_all(const DevDb& db, const uint8_t* cls, const uin
 
 // true when the text reaches a state of the flattened AC automaton that has output literals (necessary for any glob
 // with a literal part to match)
-__device__ __forceinline__ bool ac_touches_output(const DevDb& db, const uint8_t* cls, const uint8_t* text, uint32_t tn) {
+__device__ __forceinline__ bool ac_touches_output(const DevDb& db, const DfaView& dv, const uint8_t* text, uint32_t tn) {
     uint32_t st = 0, any = 0;
     for (uint32_t i = 0; i < tn; i += 8) {
         uint64_t w = 0;
@@ -1173,7 +1275,7 @@ __device__ __forceinline__ bool ac_touches_output(const DevDb& db, const uint8_t
         if (m == 8) __builtin_memcpy(&w, text + i, 8);
         else for (uint32_t b = 0; b < m; ++b) w |= (uint64_t)text[i + b] << (8 * b);
         for (uint32_t b = 0; b < m; ++b) {
-            const uint32_t e = db.dfa[(size_t)st * db.dfa_k + cls[(uint32_t)w & 0xFF]];
+            const uint32_t e = dfa_step(db, dv, st, (uint32_t)w & 0xFF);
             w >>= 8;
             st = e & 0x7FFFFFFFu;
             any |= e;
@@ -1189,7 +1291,9 @@ __device__ __forceinline__ bool ac_touches_output(const DevDb& db, const uint8_t
 template <bool GLOB>
 __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
     __shared__ uint8_t cls[256];  // byte -> DFA class
-    cls[threadIdx.x] = db.dfa ? db.dfa_cls[threadIdx.x] : 0;
+    __shared__ uint32_t rows[DFA_LDS_ENTRIES];
+    __shared__ uint64_t twin[GLOB ? 256 * GLOB_WIN_WORDS : 1];   // per-lane text window of the glob pass
+    const DfaView dv = dfa_stage<DFA_LDS_ENTRIES>(db, cls, rows);
     __syncthreads();
     const uint32_t n = p.from_work ? min(p.counters->n_glob_work, p.glob_work_cap) : min(p.counters->n_cand, p.cand_cap);
     uint32_t stride = gridDim.x * blockDim.x;
@@ -1223,11 +1327,11 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
                 uint32_t off, pfx;
                 if (db.has_ip && d_parse_ipv6(text, tl, seg) && trie_v6(db, seg, off, pfx)) { h.kind = 2; h.a = off; h.prefix_len = (uint8_t)pfx; emit = true; }
             } else {
-                if (!GLOB && p.ac_filter && ac_touches_output(db, cls, text, tl)) defer = true;
+                if (!GLOB && p.ac_filter && ac_touches_output(db, dv, text, tl)) defer = true;
                 else {
                     uint32_t pid = 0xFFFFFFFFu;
                     if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q)) pid = q; }
-                    if constexpr (GLOB) ng = glob_find_all(db, cls, text, tl, globs, &p.counters->error);
+                    if constexpr (GLOB) ng = glob_find_all(db, dv, text_stage(p.log, p.len, c.start, tl, twin + threadIdx.x * GLOB_WIN_WORDS), globs, &p.counters->error);
                     if (pid != 0xFFFFFFFFu || ng) { h.kind = 3; h.a = pid; h.n_globs = (uint16_t)ng; emit = true; }
                 }
             }
@@ -1321,12 +1425,15 @@ void launch_pack(const PackParams& p, int grid, hipStream_t stream) {
 }
 int validate_blocks_per_cu() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate_dom, 256, 0) != hipSuccess || n < 1) n = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate_dom<false>, 256, 0) != hipSuccess || n < 1) n = 4;
     return n;
 }
 // grid = workgroups of k_validate_dom; k_validate (rare anchors, tokens) has a fraction of the work
 void launch_validate(const TokParams& p, const DevDb& db, int grid, int n_cu, hipStream_t stream) {
-    if (p.flags & EX_DOMAINS) hipLaunchKernelGGL(k_validate_dom, dim3(grid), dim3(256), 0, stream, p, db);
+    if (p.flags & EX_DOMAINS) {
+        if (p.filter_ac) hipLaunchKernelGGL(k_validate_dom<true>, dim3(grid), dim3(256), 0, stream, p, db);
+        else hipLaunchKernelGGL(k_validate_dom<false>, dim3(grid), dim3(256), 0, stream, p, db);
+    }
     static const int misc_mult = getenv("MATCHY_AMD_MISC_GRID") ? atoi(getenv("MATCHY_AMD_MISC_GRID")) : 2;
     hipLaunchKernelGGL(k_validate, dim3(n_cu * (misc_mult > 0 ? misc_mult : 2)), dim3(256), 0, stream, p, db);
 }

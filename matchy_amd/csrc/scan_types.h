@@ -82,6 +82,7 @@ struct DevDb {
     const uint8_t* dfa_cls;
     const uint32_t* dfa_node;
     uint32_t dfa_k;
+    uint32_t dfa_states;          // number of states; they are numbered breadth-first, so the first rows are the shallowest
     const uint32_t* lit2pat_off;  // [n_ac_lits + 1]
     const uint32_t* lit2pat;
     uint32_t n_ac_lits;
@@ -98,6 +99,8 @@ struct DevDb {
     uint32_t tld_first[8];        // 256-bit set: bytes that start the last label of at least one suffix
 };
 
+constexpr uint32_t DFA_LDS_ENTRIES = 8192;      // 32 KiB of transition rows per workgroup of k_lookup
+constexpr uint32_t DFA_LDS_ENTRIES_VAL = 4096;  // 16 KiB per workgroup of k_validate_dom (AC prefilter)
 constexpr uint32_t TLD_BLOOM_BITS = 32768;
 constexpr uint32_t TLD_BLOOM_WORDS = TLD_BLOOM_BITS / 32;
 
@@ -126,7 +129,8 @@ struct TokParams {
     uint32_t min_labels;
     uint32_t debug;           // MATCHY_AMD_DEBUG: free for kernel experiments (unused in the shipped kernels)
     uint32_t filter_v4;       // 1: IPv4 candidates whose /24 has no database entry are counted but not listed (lookup scans)
-    uint32_t filter_lit;      // 1: domain candidates whose XXH64 is not in DevDb::lit_bm are counted but not listed
+    uint32_t filter_lit;      // 1: domain candidates whose XXH64 is not in DevDb::lit_bm are counted but not listed ...
+    uint32_t filter_ac;       // 1: ... unless their text reaches an output state of the glob automaton (databases with globs)
     uint32_t n_segs;
     Candidate* cands;
     uint32_t cand_cap;

@@ -434,6 +434,77 @@ def test_ipv4_structured_fuzz(M, oracle, seed):
     assert len(gh) > 40
 
 
+def _glob_fuzz_case(seed):
+    """Names (some longer than the 64-byte text window of the glob pass, some with multi-byte characters) and globs cut out
+    of them: stars, question marks, classes, literal pieces shorter and longer than 8 bytes."""
+    rng = random.Random(seed)
+    alpha = "abcdefghijklmnopqrstuvwxyz0123456789"
+    tlds = ["com", "net", "org", "io", "co.uk", "museum"]
+
+    def name():
+        k = rng.choice([1, 2, 2, 3, 4, 8])
+        labs = []
+        for _ in range(k):
+            n = rng.choice([1, 2, 3, 5, 8, 9, 13, 21, 40])
+            lab = "".join(rng.choice(alpha) for _ in range(n))
+            if rng.random() < 0.1 and n > 2:
+                lab = lab[:1] + "-" + lab[2:]
+            if rng.random() < 0.06:
+                lab = lab + "ü"
+            labs.append(lab)
+        return ".".join(labs + [rng.choice(tlds)])
+
+    names = [name() for _ in range(400)]
+    pats = {}
+    for _ in range(600):
+        nm = rng.choice(names)
+        chars = list(nm)
+        out = []
+        i = 0
+        wild = False
+        while i < len(chars):
+            r = rng.random()
+            if r < 0.06:
+                out.append("*"); i += rng.choice([0, 1, 3, 10, 30]); wild = True
+            elif r < 0.10:
+                out.append("?"); i += 1; wild = True
+            elif r < 0.13 and chars[i] not in "-.ü":
+                c = chars[i]
+                out.append(rng.choice([f"[{c}]", f"[!{c}]", "[a-z]", "[0-9]", "[!a-m]", f"[{c}x]"])); i += 1; wild = True
+            else:
+                out.append(chars[i]); i += 1
+        if rng.random() < 0.3:
+            out.insert(0, "*"); wild = True
+        pt = "".join(out)
+        if wild and pt not in pats and pt.strip("*?") != "":
+            pats[pt] = len(pats)
+    log = bytearray()
+    for nm in names:
+        log += nm.encode() + rng.choice([b" ", b"\n", b"/", b"\" "])
+        if rng.random() < 0.5:   # a near miss
+            m = list(nm)
+            m[rng.randrange(len(m))] = rng.choice(alpha)
+            log += "".join(m).encode() + b"\n"
+    return pats, bytes(log)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_glob_differential_fuzz(M, oracle, seed):
+    """Paraglob::find_all on the GPU (AC prefilter in k_validate_dom, DFA walk, glob matcher with its LDS text window and
+    cached segment header) against the oracle's restatement of match_segments_impl, over a scan."""
+    pats, log = _glob_fuzz_case(seed)
+    b = M.DatabaseBuilder(build_epoch=6)
+    for pt, i in pats.items():
+        b.add_entry(pt, {"g": i})
+    b.add_entry("literal:" + log.split()[0].decode(), {"lit": True})
+    blob = b.build()
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, log)
+    assert gs == ws
+    assert gh == wh
+    assert gl == wl
+    assert len(gh) > 100
+
+
 REFERENCE_BEHAVIOUR = [
     # (entries, queries) — the behavioural vectors of the reference's own tests (test_ip_longest_prefix_match.rs,
     # test_literal_hash.rs, paraglob_offset.rs:1890-1944, matchy-paraglob/tests/integration_tests.rs), as in
