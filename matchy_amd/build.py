@@ -12,6 +12,9 @@ BINDIR = PKG / "bin"
 CLI = BINDIR / "matchy"
 SOURCES = ["k_anchor.hip", "scan_kernels.hip", "sort_hits.hip", "engine.cpp", "db_image.cpp", "db_builder.cpp", "data_codec.cpp", "capi.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# scan_kernels.hip: keep the dynamically indexed private arrays of the glob matcher (result list, star stack: 80 dwords,
+# touched a few times per text) in scratch instead of in vector registers — 96 VGPRs instead of 512 for k_lookup<true>.
+EXTRA_FLAGS = {"scan_kernels.hip": ["-mllvm", "-amdgpu-promote-alloca-to-vector-limit=64"]}
 
 
 def needs_build():
@@ -32,7 +35,8 @@ def build(force=False, verbose=False):
     procs = []
     for src in SOURCES:
         obj = LIBDIR / (src.rsplit(".", 1)[0] + ".o")
-        cmd = [HIPCC, *flags, "-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
+        extra = EXTRA_FLAGS.get(src, [])
+        cmd = [HIPCC, *flags, *extra, "-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -378,8 +378,8 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     // larger grid only adds a partially filled second round). MATCHY_AMD_GRID=a,v,l,p overrides for experiments.
     // k_anchor: two full rounds of resident workgroups; k_validate: one; k_lookup: 4 per CU measured best (more waves in
     // flight only add contention on the random table accesses).
-    static const int occ_a = anchor_blocks_per_cu(), occ_v = validate_blocks_per_cu();
-    int gm[4] = {2 * occ_a, occ_v, 4, 2};
+    static const int occ_a = anchor_blocks_per_cu(), occ_v = validate_blocks_per_cu(false), occ_v_ac = validate_blocks_per_cu(true);
+    int gm[4] = {2 * occ_a, tp.filter_ac ? occ_v_ac : occ_v, 4, 2};
     if (const char* g = getenv("MATCHY_AMD_GRID")) (void)sscanf(g, "%d,%d,%d,%d", &gm[0], &gm[1], &gm[2], &gm[3]);
     for (int& m : gm) m = std::max(1, std::min(m, 64));
     int grid_tok = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * gm[0]);

@@ -788,12 +788,17 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
                     pend_word = db.lit_bm ? db.lit_bm[b >> 5] : 0u;
                     pend_bit = b & 31;
                     if constexpr (AC) {
-                        const uint8_t* nb = reinterpret_cast<const uint8_t*>(sb) + o;
+                        // the name is in ln[] already: byte -> class look-ups do not depend on the state and go out
+                        // together, the chain is one LDS row look-up per byte
                         uint32_t st = 0, any = 0;
-                        for (uint32_t k = 0; k < n; ++k) {
-                            const uint32_t t = dfa_step(db, dv, st, nb[k]);
-                            st = t & 0x7FFFFFFFu;
-                            any |= t;
+#pragma unroll
+                        for (int k = 0; k < 31; ++k) {
+                            const uint32_t c = dcls[(uint32_t)(ln[k >> 3] >> (8 * (k & 7))) & 0xFF];
+                            if ((uint32_t)k < n) {
+                                const uint32_t t = st < dv.lds_states ? drows[st * db.dfa_k + c] : db.dfa[(size_t)st * db.dfa_k + c];
+                                st = t & 0x7FFFFFFFu;
+                                any |= t;
+                            }
                         }
                         if (any >> 31) { pend_word = 0xFFFFFFFFu; pend_bit = 0; }
                     }
@@ -1059,6 +1064,7 @@ __device__ __forceinline__ bool is_rust_char(uint32_t c) { return c < 0xD800 || 
 // `*literal` pattern probes the text once per position; from the log each probe would be a dependent global load), the
 // rest comes from the log.
 constexpr uint32_t GLOB_WIN = 64, GLOB_WIN_WORDS = GLOB_WIN / 8 + 1;
+constexpr uint32_t GLOB_OUTQ = 8;   // output states queued per text before they are handled (LDS, per lane)
 struct TextView {
     const uint8_t* g;     // the text in the log
     uint32_t n;           // its length
@@ -1107,7 +1113,7 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
     uint32_t first = ld32(pg + io);
     uint32_t count = ld32(pg + io + 4) & 0xFFFF;
     uint32_t steps = 100000;
-    uint32_t st_seg[MAX_GLOB_STARS], st_pos[MAX_GLOB_STARS];
+    uint32_t st_seg[MAX_GLOB_STARS], st_pos[MAX_GLOB_STARS], t_seg = 0, t_pos = 0;
     int sp = 0;
     uint32_t pos = 0, seg = 0;
     bool result = false;
@@ -1153,7 +1159,10 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
                 } else if (st == 1) {
                     if (seg + 1 >= count) { result = true; ret = true; }
                     else if (sp >= (int)MAX_GLOB_STARS) { atomicOr(err, 2u); return false; }
-                    else { st_seg[sp] = seg; st_pos[sp] = pos; ++sp; ++seg; }
+                    else {
+                        if (sp > 0) { st_seg[sp - 1] = t_seg; st_pos[sp - 1] = t_pos; }   // the innermost frame lives in registers
+                        t_seg = seg; t_pos = pos; ++sp; ++seg;
+                    }
                 } else if (st == 2) {
                     if (pos < tn) { pos += utf8_adv(text.at(pos)); ++seg; } else { result = false; ret = true; }
                 } else if (st == 3) {
@@ -1178,20 +1187,23 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
         // ---- RETURN(result) to the innermost Star frame
         for (;;) {
             if (sp == 0) return result;
-            if (result) { --sp; continue; }  // star returns true: propagate
-            uint32_t fp = st_pos[sp - 1];
-            if (fp >= tn) { --sp; continue; }  // star exhausted: returns false, propagate
+            uint32_t fp = t_pos;
+            if (result || fp >= tn) {  // star returns true, or is exhausted and returns false: propagate
+                --sp;
+                if (sp > 0) { t_seg = st_seg[sp - 1]; t_pos = st_pos[sp - 1]; }
+                continue;
+            }
             fp += utf8_adv(text.at(fp));
-            st_pos[sp - 1] = fp;
+            t_pos = fp;
             pos = fp;
-            seg = st_seg[sp - 1] + 1;
+            seg = t_seg + 1;
             break;
         }
     }
 }
 
 // Paraglob::find_all (pg:1028-1182): returns the sorted unique pattern ids in out[0..n)
-__device__ uint32_t glob_find_all(const DevDb& db, const DfaView& dv, const TextView& text, uint32_t* out, uint32_t* err) {
+__device__ uint32_t glob_find_all(const DevDb& db, const DfaView& dv, const TextView& text, uint32_t* oq, uint32_t* out, uint32_t* err) {
     const uint32_t tn = text.n;
     uint32_t n = 0;
     auto insert = [&](uint32_t id) {
@@ -1235,7 +1247,7 @@ __device__ uint32_t glob_find_all(const DevDb& db, const DfaView& dv, const Text
         };
         if (db.dfa) {
             // flattened automaton: one table load per byte, the text fetched 8 bytes at a time
-            uint32_t st = 0;
+            uint32_t st = 0, qn = 0;
             for (uint32_t i = 0; i < tn; i += 8) {
                 uint64_t w = text.load8(i);
                 const uint32_t m = min(8u, tn - i);
@@ -1243,9 +1255,16 @@ __device__ uint32_t glob_find_all(const DevDb& db, const DfaView& dv, const Text
                     const uint32_t e = dfa_step(db, dv, st, (uint32_t)w & 0xFF);
                     w >>= 8;
                     st = e & 0x7FFFFFFFu;
-                    if (e >> 31) outputs(db.dfa_node[st]);
+                    if (e >> 31) {
+                        // Output states are queued and handled after the walk: lanes meet them at different text
+                        // positions, and handling them on the spot would run each lane's chain of dependent loads
+                        // (node -> literal -> patterns -> segments) one after the other instead of side by side.
+                        if (qn < GLOB_OUTQ) oq[qn++] = st;
+                        else outputs(db.dfa_node[st]);
+                    }
                 }
             }
+            for (uint32_t k = 0; k < qn; ++k) outputs(db.dfa_node[oq[k]]);
         } else {
             uint32_t cur = 0;
             for (uint32_t i = 0; i < tn; ++i) {
@@ -1291,9 +1310,12 @@ __device__ __forceinline__ bool ac_touches_output(const DevDb& db, const DfaView
 template <bool GLOB>
 __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
     __shared__ uint8_t cls[256];  // byte -> DFA class
-    __shared__ uint32_t rows[DFA_LDS_ENTRIES];
+    // the glob pass sees texts that go deep into the automaton anyway: a small shallow part, more resident waves
+    constexpr uint32_t ROWS = GLOB ? DFA_LDS_ENTRIES_GLOB : DFA_LDS_ENTRIES;
+    __shared__ uint32_t rows[ROWS];
     __shared__ uint64_t twin[GLOB ? 256 * GLOB_WIN_WORDS : 1];   // per-lane text window of the glob pass
-    const DfaView dv = dfa_stage<DFA_LDS_ENTRIES>(db, cls, rows);
+    __shared__ uint32_t outq[GLOB ? 256 * GLOB_OUTQ : 1];
+    const DfaView dv = dfa_stage<ROWS>(db, cls, rows);
     __syncthreads();
     const uint32_t n = p.from_work ? min(p.counters->n_glob_work, p.glob_work_cap) : min(p.counters->n_cand, p.cand_cap);
     uint32_t stride = gridDim.x * blockDim.x;
@@ -1331,7 +1353,7 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
                 else {
                     uint32_t pid = 0xFFFFFFFFu;
                     if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q)) pid = q; }
-                    if constexpr (GLOB) ng = glob_find_all(db, dv, text_stage(p.log, p.len, c.start, tl, twin + threadIdx.x * GLOB_WIN_WORDS), globs, &p.counters->error);
+                    if constexpr (GLOB) ng = glob_find_all(db, dv, text_stage(p.log, p.len, c.start, tl, twin + threadIdx.x * GLOB_WIN_WORDS), outq + threadIdx.x * GLOB_OUTQ, globs, &p.counters->error);
                     if (pid != 0xFFFFFFFFu || ng) { h.kind = 3; h.a = pid; h.n_globs = (uint16_t)ng; emit = true; }
                 }
             }
@@ -1423,9 +1445,11 @@ __global__ __launch_bounds__(256) void k_pack(PackParams p) {
 void launch_pack(const PackParams& p, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, stream, p);
 }
-int validate_blocks_per_cu() {
+int validate_blocks_per_cu(bool ac) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate_dom<false>, 256, 0) != hipSuccess || n < 1) n = 4;
+    const hipError_t e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate_dom<true>, 256, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate_dom<false>, 256, 0);
+    if (e != hipSuccess || n < 1) n = ac ? 3 : 4;
     return n;
 }
 // grid = workgroups of k_validate_dom; k_validate (rare anchors, tokens) has a fraction of the work

@@ -100,7 +100,8 @@ struct DevDb {
 };
 
 constexpr uint32_t DFA_LDS_ENTRIES = 8192;      // 32 KiB of transition rows per workgroup of k_lookup
-constexpr uint32_t DFA_LDS_ENTRIES_VAL = 4096;  // 16 KiB per workgroup of k_validate_dom (AC prefilter)
+constexpr uint32_t DFA_LDS_ENTRIES_GLOB = 2048; // 8 KiB per workgroup of the glob pass of k_lookup
+constexpr uint32_t DFA_LDS_ENTRIES_VAL = 2048;  // 8 KiB per workgroup of k_validate_dom (AC prefilter)
 constexpr uint32_t TLD_BLOOM_BITS = 32768;
 constexpr uint32_t TLD_BLOOM_WORDS = TLD_BLOOM_BITS / 32;
 
