@@ -376,11 +376,15 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.counters = counters_.p;
     // workgroups per CU for k_anchor / k_validate / k_lookup / k_pack: what is resident at once (grid-stride kernels; a
     // larger grid only adds a partially filled second round). MATCHY_AMD_GRID=a,v,l,p overrides for experiments.
-    // k_anchor: two full rounds of resident workgroups; k_validate: one; k_lookup: 4 per CU measured best (more waves in
-    // flight only add contention on the random table accesses).
+    // k_anchor: two full rounds of resident workgroups; k_validate: one; k_lookup: 2 per CU measured best (every wave
+    // pads its last hit chunk, and more waves in flight only add contention on the random table accesses).
     static const int occ_a = anchor_blocks_per_cu(), occ_v = validate_blocks_per_cu(false), occ_v_ac = validate_blocks_per_cu(true);
-    int gm[4] = {2 * occ_a, tp.filter_ac ? occ_v_ac : occ_v, 4, 2};
-    if (const char* g = getenv("MATCHY_AMD_GRID")) (void)sscanf(g, "%d,%d,%d,%d", &gm[0], &gm[1], &gm[2], &gm[3]);
+    int gm[4] = {2 * occ_a, tp.filter_ac ? occ_v_ac : occ_v, 2, 2};
+    if (const char* g = getenv("MATCHY_AMD_GRID")) {   // 0 keeps the default of that kernel
+        int o[4] = {0, 0, 0, 0};
+        (void)sscanf(g, "%d,%d,%d,%d", &o[0], &o[1], &o[2], &o[3]);
+        for (int k = 0; k < 4; ++k) if (o[k] > 0) gm[k] = o[k];
+    }
     for (int& m : gm) m = std::max(1, std::min(m, 64));
     int grid_tok = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * gm[0]);
     if (grid_tok < 1) grid_tok = 1;
@@ -390,7 +394,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     launch_validate(tp, ddb_->view, n_cu_ * gm[1], n_cu_, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
     bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
-    if (rare_possible) launch_rare(tp, ddb_->view, n_cu_, stream);
+    if (rare_possible) launch_rare(tp, ddb_->view, n_cu_ * 4, stream);   // one wave per SIMD (297 VGPRs)
     if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
     if (lookup) {
         LookupParams lp{};
