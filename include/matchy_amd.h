@@ -268,6 +268,13 @@ char *matchy_scan_hit_to_json(const matchy_scanner_t *scanner, const matchy_scan
 void matchy_scanner_set_profile(matchy_scanner_t *scanner, bool enabled);
 void matchy_scanner_get_timing(const matchy_scanner_t *scanner, float out_ms[5]);
 /* Last error message of the calling thread ("" if none). */
+/* `matchy query DB QUERY` (bin/commands/query_cmd.rs:8-69) as one call: compact JSON array — one object per matching
+ * pattern that carries data (literal first, then globs by id), or the IP entry's data plus "cidr" and "prefix_len", or
+ * [] — and *found = the command's exit-status rule. Free with matchy_free_string. NULL on error. */
+char *matchy_amd_query_json(const matchy_t *db, const char *query, int32_t *found);
+/* matchy_extractor_create with ExtractorBuilder::min_domain_labels (matchy-extractor/src/lib.rs:101-104;
+ * `matchy extract --min-labels`); 0 = the default of 2. */
+matchy_extractor_t *matchy_amd_extractor_create(uint32_t flags, uint32_t min_domain_labels);
 const char *matchy_amd_last_error(void);
 /* Deterministic builds for tests: fixes the build_epoch metadata value. */
 int32_t matchy_builder_set_build_epoch(matchy_builder_t *b, uint64_t epoch);

@@ -334,6 +334,67 @@ void matchy_query_into(const matchy_t* dbc, const char* query, matchy_result_t* 
     } catch (const HipError& e) { set_error(e.what); }
     catch (const std::exception& e) { set_error(e.what()); }
 }
+// The answer `matchy query DB QUERY` prints (bin/commands/query_cmd.rs:8-69), as compact JSON: an array with one object per
+// pattern that carries data (literal first, then globs by id), or one object for an IP hit (its data plus "cidr" and
+// "prefix_len"), or [] when nothing matches. *found follows the command's exit status rule (:19-21).
+char* matchy_amd_query_json(const matchy_t* dbc, const char* query, int32_t* found) {
+    if (found) *found = 0;
+    if (!dbc || !query) return nullptr;
+    Db* db = const_cast<Db*>(reinterpret_cast<const Db*>(dbc));
+    const size_t qn = strlen(query);
+    if (!valid_utf8_host((const uint8_t*)query, qn) || qn >= (1u << 24)) return strdup("[]");
+    try {
+        std::lock_guard<std::mutex> lk(db->mu);
+        if (!db->query_scanner) db->query_scanner = std::make_unique<Scanner>(db->img, db->device_db(db->default_device), EX_ALL, 2);
+        IpAddr ip;
+        std::string text(query, qn);
+        Candidate c{0, 0, 0, 0};
+        const bool is_ip = parse_ip(query, qn, ip);
+        if (is_ip) {
+            if (!ip.v6) { c.v4 = ((uint32_t)ip.b[0] << 24) | ((uint32_t)ip.b[1] << 16) | ((uint32_t)ip.b[2] << 8) | ip.b[3]; c.len_type = (uint32_t)qn | ((uint32_t)IT_IPV4 << 24); }
+            else {
+                char buf[64];
+                snprintf(buf, sizeof(buf), "%x:%x:%x:%x:%x:%x:%x:%x", (ip.b[0] << 8) | ip.b[1], (ip.b[2] << 8) | ip.b[3], (ip.b[4] << 8) | ip.b[5],
+                         (ip.b[6] << 8) | ip.b[7], (ip.b[8] << 8) | ip.b[9], (ip.b[10] << 8) | ip.b[11], (ip.b[12] << 8) | ip.b[13], (ip.b[14] << 8) | ip.b[15]);
+                text = buf;
+                c.len_type = (uint32_t)text.size() | ((uint32_t)IT_IPV6 << 24);
+            }
+        } else {
+            c.len_type = (uint32_t)qn | ((uint32_t)IT_DOMAIN << 24);
+        }
+        ScanOutput so;
+        db->query_scanner->lookup_one(text, c, so);
+        if (so.hits.empty()) return strdup("[]");
+        const Hit& h = so.hits[0];
+        if (found) *found = 1;
+        std::string o = "[";
+        if (h.kind == 2) {
+            DataValue dv;
+            if (!db->img->decode_data(h.a, dv)) { set_error("query: cannot decode the data record"); return nullptr; }
+            if (dv.type == DataValue::MAP) {
+                dv.map["cidr"] = DataValue::String(format_cidr(ip, h.prefix_len));
+                dv.map["prefix_len"] = DataValue::Uint16(h.prefix_len);
+            }
+            to_json(dv, o);
+        } else {
+            bool any = false;
+            auto push = [&](uint32_t off) {
+                DataValue dv;
+                if (!db->img->decode_data(off, dv)) return;
+                if (any) o.push_back(',');
+                to_json(dv, o);
+                any = true;
+            };
+            uint32_t off;
+            if (h.a != 0xFFFFFFFFu && db->img->lit_data_offset(h.a, off)) push(off);
+            for (uint32_t k = 0; k < h.n_globs; ++k) if (db->img->glob_data_offset(so.ids[h.ids_off + k], off)) push(off);
+        }
+        o.push_back(']');
+        return strdup(o.c_str());
+    } catch (const HipError& e) { set_error(e.what); }
+    catch (const std::exception& e) { set_error(e.what()); }
+    return nullptr;
+}
 matchy_result_t matchy_query(const matchy_t* db, const char* query) {
     matchy_result_t r;
     matchy_query_into(db, query, &r);
@@ -469,7 +530,9 @@ int32_t matchy_builder_set_schema(matchy_builder_t* b, const char* name) {
 }
 
 // ------------------------------------------------------------------------------------------------ extractor
-matchy_extractor_t* matchy_extractor_create(uint32_t flags) {
+matchy_extractor_t* matchy_extractor_create(uint32_t flags) { return matchy_amd_extractor_create(flags, 2); }
+// ExtractorBuilder::min_domain_labels (matchy-extractor/src/lib.rs:101-104; `matchy extract --min-labels`)
+matchy_extractor_t* matchy_amd_extractor_create(uint32_t flags, uint32_t min_domain_labels) {
     try {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("matchy_amd: no HIP device available"); return nullptr; }
@@ -479,7 +542,7 @@ matchy_extractor_t* matchy_extractor_create(uint32_t flags) {
         e->img->node_count = 0;
         e->ddb = std::make_shared<DeviceDb>();
         e->ddb->upload(*e->img, 0);
-        e->scanner = std::make_unique<Scanner>(e->img, e->ddb, flags, 2);
+        e->scanner = std::make_unique<Scanner>(e->img, e->ddb, flags, min_domain_labels ? min_domain_labels : 2);
         return reinterpret_cast<matchy_extractor_t*>(e.release());
     } catch (const HipError& e) { set_error(e.what); return nullptr; }
     catch (const std::exception& e) { set_error(e.what()); return nullptr; }

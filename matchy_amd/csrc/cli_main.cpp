@@ -3,6 +3,9 @@
 //
 //   matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-v]
 //   matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N]
+//   matchy query <DATABASE> <QUERY> [-q]                                  (bin/commands/query_cmd.rs)
+//   matchy extract <INPUT>... [--format json|csv|text] [--types LIST] [--min-labels N] [-u] [-s] [--show-candidates]
+//                                                                          (bin/commands/extract_cmd.rs)
 //
 // `match` prints one JSON object per match on stdout (same records as the reference's parallel path,
 // match_processor/parallel.rs:297-369: sorted keys, timestamp "0.000") and, with -s, the [INFO] statistics block on
@@ -36,7 +39,9 @@ int usage() {
     fprintf(stderr,
             "usage:\n"
             "  matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-v]\n"
-            "  matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N]\n");
+            "  matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N]\n"
+            "  matchy query <DATABASE> <QUERY> [-q]\n"
+            "  matchy extract <INPUT>... [--format json|csv|text] [--types LIST] [--min-labels N] [-u] [-s] [--show-candidates]\n");
     return 2;
 }
 
@@ -425,6 +430,264 @@ int cmd_match(int argc, char** argv) {
     return 0;
 }
 
+// serde_json::to_string_pretty of a compact JSON text: two spaces per level, "key": value, empty containers stay "[]" / "{}"
+std::string json_pretty(const std::string& c) {
+    std::string o;
+    int depth = 0;
+    bool in_str = false;
+    auto nl = [&]() { o.push_back('\n'); o.append((size_t)depth * 2, ' '); };
+    for (size_t i = 0; i < c.size(); ++i) {
+        const char ch = c[i];
+        if (in_str) {
+            o.push_back(ch);
+            if (ch == '\\' && i + 1 < c.size()) o.push_back(c[++i]);
+            else if (ch == '"') in_str = false;
+            continue;
+        }
+        switch (ch) {
+            case '"': in_str = true; o.push_back(ch); break;
+            case '[': case '{':
+                o.push_back(ch);
+                if (i + 1 < c.size() && (c[i + 1] == ']' || c[i + 1] == '}')) { o.push_back(c[++i]); break; }
+                ++depth; nl();
+                break;
+            case ']': case '}': --depth; nl(); o.push_back(ch); break;
+            case ',': o.push_back(ch); nl(); break;
+            case ':': o += ": "; break;
+            default: o.push_back(ch);
+        }
+    }
+    return o;
+}
+
+// matchy query (bin/commands/query_cmd.rs:8-69): pretty JSON array on stdout, exit status 0 = found, 1 = not found
+int cmd_query(int argc, char** argv) {
+    std::vector<std::string> pos;
+    bool quiet = false;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-q" || a == "--quiet") quiet = true;
+        else if (a == "--") { for (++i; i < argc; ++i) pos.push_back(argv[i]); }
+        else if (a.size() > 1 && a[0] == '-' && pos.size() < 1) { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
+        else pos.push_back(a);
+    }
+    if (pos.size() != 2) return usage();
+    matchy_t* db = matchy_open(pos[0].c_str());
+    if (!db) { fprintf(stderr, "Error: Failed to load database: %s\n", pos[0].c_str()); return 1; }
+    int32_t found = 0;
+    char* js = matchy_amd_query_json(db, pos[1].c_str(), &found);
+    if (!js) { fprintf(stderr, "Error: Query failed for: %s: %s\n", pos[1].c_str(), matchy_amd_last_error()); matchy_close(db); return 1; }
+    if (!quiet) printf("%s\n", json_pretty(js).c_str());
+    matchy_free_string(js);
+    matchy_close(db);
+    return found ? 0 : 1;
+}
+
+// matchy extract (bin/commands/extract_cmd.rs:40-289). The reference extracts line by line (extract_from_line,
+// matchy-extractor/src/lib.rs:1471-1521: domains, IPv4, e-mails, IPv6, hashes, Bitcoin, Ethereum, Monero per line); its line
+// functions are the chunk functions applied to one line, no token crosses a newline, so every batch goes through
+// the GPU extractor once and the items are put back into line order here. LineScanner (bin/cli_utils.rs:9-110) trims ASCII
+// whitespace from both ends of a line and skips empty lines: form feeds in those margins — whitespace for the trim, not
+// a word boundary for the extractor — are turned into spaces first.
+struct ExtractStats { unsigned long long lines = 0, found = 0, v4 = 0, v6 = 0, dom = 0, mail = 0, bytes = 0; };
+inline bool is_ws(uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0x0C; }
+inline int line_rank(uint8_t t) {
+    switch (t) {
+        case MATCHY_ITEM_TYPE_DOMAIN: return 0;
+        case MATCHY_ITEM_TYPE_IPV4: return 1;
+        case MATCHY_ITEM_TYPE_EMAIL: return 2;
+        case MATCHY_ITEM_TYPE_IPV6: return 3;
+        case MATCHY_ITEM_TYPE_BITCOIN: return 5;
+        case MATCHY_ITEM_TYPE_ETHEREUM: return 6;
+        case MATCHY_ITEM_TYPE_MONERO: return 7;
+        default: return 4;   // the hash types
+    }
+}
+bool extract_batch(matchy_extractor_t* ex, uint8_t* data, size_t len, int fmt, bool show_cand, std::vector<std::string>* seen_sorted,
+                   std::vector<std::string>& seen_new, ExtractStats& st) {
+    if (!len) return true;
+    // line table: [start, end) of every trimmed, non-empty line
+    std::vector<std::pair<size_t, size_t>> lines;
+    for (size_t p = 0; p < len;) {
+        const uint8_t* nlp = (const uint8_t*)memchr(data + p, '\n', len - p);
+        size_t e = nlp ? (size_t)(nlp - data) : len, a = p, b = e;
+        while (a < b && is_ws(data[a])) { if (data[a] == 0x0C) data[a] = ' '; ++a; }
+        while (b > a && is_ws(data[b - 1])) { if (data[b - 1] == 0x0C) data[b - 1] = ' '; --b; }
+        if (b > a) { lines.push_back({a, b}); st.lines++; st.bytes += b - a; }
+        p = e + 1;
+    }
+    matchy_matches_t m;
+    memset(&m, 0, sizeof(m));
+    if (matchy_extractor_extract_chunk(ex, data, len, &m) != MATCHY_SUCCESS) {
+        fprintf(stderr, "[ERROR] extraction failed: %s\n", matchy_amd_last_error());
+        return false;
+    }
+    struct It { size_t line; int rank; size_t idx; };
+    std::vector<It> its(m.count);
+    for (size_t i = 0; i < m.count; ++i) {
+        const size_t s = m.items[i].start;
+        // the trimmed line that holds position s
+        size_t lo = 0, hi = lines.size();
+        while (lo < hi) { size_t mid = (lo + hi) / 2; if (lines[mid].second <= s) lo = mid + 1; else hi = mid; }
+        its[i] = It{lo, line_rank(m.items[i].item_type), i};
+    }
+    std::sort(its.begin(), its.end(), [&](const It& a, const It& b) {
+        if (a.line != b.line) return a.line < b.line;
+        if (a.rank != b.rank) return a.rank < b.rank;
+        return m.items[a.idx].start < m.items[b.idx].start;
+    });
+    std::string out;
+    for (const It& it : its) {
+        const matchy_match_t& mt = m.items[it.idx];
+        const std::string text((const char*)data + mt.start, mt.end - mt.start);
+        std::string tname = matchy_item_type_name(mt.item_type);
+        if (show_cand) {
+            const size_t ls = it.line < lines.size() ? lines[it.line].first : 0;
+            fprintf(stderr, "[CANDIDATE] %s at %zu-%zu: %s\n", tname.c_str(), (size_t)mt.start - ls, (size_t)mt.end - ls, text.c_str());
+        }
+        if (seen_sorted) {
+            if (std::binary_search(seen_sorted->begin(), seen_sorted->end(), text)) continue;
+            if (std::find(seen_new.begin(), seen_new.end(), text) != seen_new.end()) continue;
+            seen_new.push_back(text);
+            if (seen_new.size() >= 4096) {   // fold the recent ones into the sorted set
+                seen_sorted->insert(seen_sorted->end(), seen_new.begin(), seen_new.end());
+                std::sort(seen_sorted->begin(), seen_sorted->end());
+                seen_new.clear();
+            }
+        }
+        for (char& ch : tname) ch = (char)tolower((unsigned char)ch);
+        out.clear();
+        if (fmt == 0) {
+            out += "{\"type\":\"" + tname + "\",\"value\":\"";
+            for (char ch : text) { if (ch == '\\') out += "\\\\"; else if (ch == '"') out += "\\\""; else out.push_back(ch); }
+            out += "\"}\n";
+        } else if (fmt == 1) {
+            out += tname + ",\"";
+            for (char ch : text) { if (ch == '"') out += "\"\""; else out.push_back(ch); }
+            out += "\"\n";
+        } else {
+            out += text; out.push_back('\n');
+        }
+        fwrite(out.data(), 1, out.size(), stdout);
+        st.found++;
+        if (mt.item_type == MATCHY_ITEM_TYPE_IPV4) st.v4++;
+        else if (mt.item_type == MATCHY_ITEM_TYPE_IPV6) st.v6++;
+        else if (mt.item_type == MATCHY_ITEM_TYPE_DOMAIN) st.dom++;
+        else if (mt.item_type == MATCHY_ITEM_TYPE_EMAIL) st.mail++;
+    }
+    matchy_matches_free(&m);
+    return true;
+}
+
+int cmd_extract(int argc, char** argv) {
+    std::vector<std::string> inputs;
+    std::string format = "json", types;
+    bool have_types = false, unique = false, stats = false, show_cand = false;
+    uint32_t min_labels = 2;
+    size_t batch_bytes = (size_t)256 << 20;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&](const char* name) -> const char* { if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", name); exit(2); } return argv[++i]; };
+        auto eqval = [&](const char* name, std::string& out) {
+            size_t n = strlen(name);
+            if (a.compare(0, n, name) != 0) return false;
+            if (a.size() == n) { out = next(name); return true; }
+            if (a[n] == '=') { out = a.substr(n + 1); return true; }
+            return false;
+        };
+        std::string v;
+        if (eqval("--format", v)) format = v;
+        else if (eqval("--types", v)) { types = v; have_types = true; }
+        else if (eqval("--min-labels", v)) min_labels = (uint32_t)strtoul(v.c_str(), nullptr, 10);
+        else if (eqval("--batch-bytes", v)) { size_t b = strtoull(v.c_str(), nullptr, 10); if (b >= 4096) batch_bytes = b; }
+        else if (a == "--no-boundaries") { fprintf(stderr, "Error: --no-boundaries is not supported by this build\n"); return 1; }
+        else if (a == "-u" || a == "--unique") unique = true;
+        else if (a == "-s" || a == "--stats") stats = true;
+        else if (a == "--show-candidates") show_cand = true;
+        else if (a.size() > 1 && a[0] == '-') { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
+        else inputs.push_back(a);
+    }
+    if (inputs.empty()) return usage();
+    for (char& ch : format) ch = (char)tolower((unsigned char)ch);
+    const int fmt = format == "json" ? 0 : format == "csv" ? 1 : format == "text" ? 2 : -1;
+    if (fmt < 0) { fprintf(stderr, "Error: Invalid format '%s', expected: json, csv, or text\n", format.c_str()); return 1; }
+    bool v4 = true, v6 = true, dom = true, mail = true;
+    if (have_types) {
+        v4 = v6 = dom = mail = false;
+        std::string low = types;
+        for (char& ch : low) ch = (char)tolower((unsigned char)ch);
+        std::stringstream ss(low);
+        std::string part;
+        while (std::getline(ss, part, ',')) {
+            part = trim(part);
+            if (part == "ipv4" || part == "ip4") v4 = true;
+            else if (part == "ipv6" || part == "ip6") v6 = true;
+            else if (part == "domain" || part == "domains") dom = true;
+            else if (part == "email" || part == "emails") mail = true;
+            else if (part == "ip") v4 = v6 = true;
+            else if (part == "all") v4 = v6 = dom = mail = true;
+            else { fprintf(stderr, "Error: Unknown extraction type '%s', expected: ipv4, ipv6, ip, domain, email, all\n", part.c_str()); return 1; }
+        }
+        if (!v4 && !v6 && !dom && !mail) { fprintf(stderr, "Error: At least one extraction type must be enabled\n"); return 1; }
+    }
+    // the command only switches these four; hashes and the crypto-address extractors keep the builder's default (on)
+    uint32_t flags = MATCHY_EXTRACT_HASHES | MATCHY_EXTRACT_BITCOIN | MATCHY_EXTRACT_ETHEREUM | MATCHY_EXTRACT_MONERO;
+    if (v4) flags |= MATCHY_EXTRACT_IPV4;
+    if (v6) flags |= MATCHY_EXTRACT_IPV6;
+    if (dom) flags |= MATCHY_EXTRACT_DOMAINS;
+    if (mail) flags |= MATCHY_EXTRACT_EMAILS;
+    matchy_extractor_t* ex = matchy_amd_extractor_create(flags, min_labels);
+    if (!ex) { fprintf(stderr, "Error: Failed to create pattern extractor: %s\n", matchy_amd_last_error()); return 1; }
+    if (stats) {
+        std::string en;
+        for (auto& pr : {std::make_pair(v4, "IPv4"), std::make_pair(v6, "IPv6"), std::make_pair(dom, "domains"), std::make_pair(mail, "emails")})
+            if (pr.first) { if (!en.empty()) en += ", "; en += pr.second; }
+        fprintf(stderr, "[INFO] Extracting: %s\n", en.c_str());
+        if (dom) fprintf(stderr, "[INFO] Min domain labels: %u\n", min_labels);
+        fprintf(stderr, "[INFO] Word boundaries: true\n[INFO] Unique mode: %s\n", unique ? "true" : "false");
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    ExtractStats st;
+    std::vector<std::string> seen_sorted, seen_new;
+    if (fmt == 1) fputs("type,value\n", stdout);
+    bool ok = true;
+    for (const std::string& path : inputs) {
+        int fd = path == "-" ? 0 : open(path.c_str(), O_RDONLY);
+        if (fd < 0) { fprintf(stderr, "Error: Failed to open file: %s\n", path.c_str()); ok = false; break; }
+        std::vector<uint8_t> buf(batch_bytes + 16);
+        size_t have = 0;
+        for (;;) {
+            if (have == buf.size() - 16) buf.resize(buf.size() * 2);
+            const ssize_t n = read(fd, buf.data() + have, buf.size() - 16 - have);
+            if (n < 0) { fprintf(stderr, "Error: read failed on %s: %s\n", path.c_str(), strerror(errno)); ok = false; break; }
+            have += (size_t)n;
+            if (n == 0) { ok = extract_batch(ex, buf.data(), have, fmt, show_cand, unique ? &seen_sorted : nullptr, seen_new, st) && ok; break; }
+            if (have < batch_bytes) continue;
+            const void* nlp = memrchr(buf.data(), '\n', have);
+            if (!nlp) continue;
+            const size_t cut = (const uint8_t*)nlp - buf.data() + 1;
+            if (!extract_batch(ex, buf.data(), cut, fmt, show_cand, unique ? &seen_sorted : nullptr, seen_new, st)) { ok = false; break; }
+            memmove(buf.data(), buf.data() + cut, have - cut);
+            have -= cut;
+        }
+        if (fd) close(fd);
+        if (!ok) break;
+    }
+    fflush(stdout);
+    matchy_extractor_free(ex);
+    if (!ok) return 1;
+    if (stats) {
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "\n[INFO] === Extraction Complete ===\n[INFO] Lines processed: %s\n[INFO] Patterns found: %s\n", fmt_num(st.lines).c_str(), fmt_num(st.found).c_str());
+        if (v4 && st.v4) fprintf(stderr, "[INFO]   IPv4: %s\n", fmt_num(st.v4).c_str());
+        if (v6 && st.v6) fprintf(stderr, "[INFO]   IPv6: %s\n", fmt_num(st.v6).c_str());
+        if (dom && st.dom) fprintf(stderr, "[INFO]   Domains: %s\n", fmt_num(st.dom).c_str());
+        if (mail && st.mail) fprintf(stderr, "[INFO]   Emails: %s\n", fmt_num(st.mail).c_str());
+        fprintf(stderr, "[INFO] Throughput: %.2f MB/s\n[INFO] Total time: %.2fs\n", secs > 0 ? (double)st.bytes / 1e6 / secs : 0.0, secs);
+    }
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -432,6 +695,8 @@ int main(int argc, char** argv) {
     std::string cmd = argv[1];
     if (cmd == "build") return cmd_build(argc - 2, argv + 2);
     if (cmd == "match") return cmd_match(argc - 2, argv + 2);
+    if (cmd == "query") return cmd_query(argc - 2, argv + 2);
+    if (cmd == "extract") return cmd_extract(argc - 2, argv + 2);
     if (cmd == "--version" || cmd == "-V" || cmd == "version") { printf("matchy %s (MI355X build)\n", matchy_version()); return 0; }
     return usage();
 }

@@ -152,3 +152,99 @@ def test_reference_c_test_programs(prog, tmp_path):
     out = r.stdout.decode("utf-8", "replace")
     assert r.returncode == 0, out[-2000:] + r.stderr.decode("utf-8", "replace")[-500:]
     assert "passed" in out
+
+
+@pytest.mark.gpu
+def test_query_subcommand(cli, tmp_path, oracle):
+    """`matchy query` (bin/commands/query_cmd.rs:8-69): pretty JSON array, exit status 0 = found / 1 = not found."""
+    import ipaddress
+    import matchy_amd as M
+    b = M.DatabaseBuilder(build_epoch=9)
+    b.add_entry("192.0.2.0/24", {"net": "doc", "n": 24})
+    b.add_entry("192.0.2.7", {"host": True})
+    b.add_entry("2001:db8::/32", {"net": "doc6"})
+    b.add_entry("evil.example.com", {"why": "literal", "tags": ["a", "b"], "nested": {"k": 1}})
+    b.add_entry("*.example.com", {"why": "glob"})
+    b.add_entry("*evil*", {"why": "glob2", "s": "quote\" and \\ and é"})
+    b.add_entry("empty.example.org", {})
+    dbp = tmp_path / "q.mxy"
+    dbp.write_bytes(b.build())
+    odb = oracle.Database(dbp.read_bytes())
+    for q in ["192.0.2.7", "192.0.2.99", "198.51.100.1", "2001:db8::1", "2001:db9::1", "evil.example.com", "x.example.com", "devilish", "nothing.here",
+              "empty.example.org", ""]:
+        want = odb.lookup(q)
+        if want["kind"] == "ip":
+            net = ipaddress.ip_network(f"{q}/{want['prefix_len']}", strict=False)
+            exp = [dict(want["data"], cidr=str(net), prefix_len=want["prefix_len"])]
+            found = True
+        elif want["kind"] == "pattern":
+            exp = [d for d in want["data"] if d is not None]
+            found = True
+        else:
+            exp, found = [], False
+        r = _run([cli, "query", str(dbp), q])
+        assert r.returncode == (0 if found else 1), (q, r.stderr)
+        assert r.stdout.decode() == json.dumps(exp, indent=2, sort_keys=True, ensure_ascii=False) + "\n", q
+        rq = _run([cli, "query", str(dbp), q, "-q"])
+        assert rq.returncode == r.returncode and rq.stdout == b""
+    assert _run([cli, "query", str(tmp_path / "missing.mxy"), "x"]).returncode == 1
+
+
+_LINE_RANK = {"Domain": 0, "IPv4": 1, "Email": 2, "IPv6": 3, "Bitcoin": 5, "Ethereum": 6, "Monero": 7}
+
+
+def _extract_expected(oracle, text, types=None, min_labels=2):
+    """What extract_cmd.rs prints for `text`: LineScanner lines (trimmed of ASCII whitespace, empty ones skipped), per line the
+    items of extract_from_line (lib.rs:1471-1521: domains, IPv4, e-mails, IPv6, hashes, Bitcoin, Ethereum, Monero)."""
+    out = []
+    ws = b" \t\n\r\x0c"
+    for raw in text.split(b"\n"):
+        line = raw.strip(ws)
+        if not line:
+            continue
+        items = oracle.extract(line, min_labels=min_labels) if min_labels != 2 else oracle.extract(line)
+        items = [it for it in items if types is None or it[0] in types or it[0] not in ("Domain", "IPv4", "Email", "IPv6")]
+        items.sort(key=lambda it: (_LINE_RANK.get(it[0], 4), it[1]))
+        out += [(t, line[s:e].decode()) for t, s, e, v in items]
+    return out
+
+
+@pytest.mark.gpu
+def test_extract_subcommand(cli, tmp_path, oracle):
+    """`matchy extract` (bin/commands/extract_cmd.rs): line order, formats, --types, --unique, margins trimmed like LineScanner."""
+    from tools import synth
+    cfg = synth.config("c1")
+    text = synth.make_log(cfg, 0, 300)
+    text += (b"\x0c 10.1.2.3 mail bob@example.org and 2001:db8::5 then evil.example.com 5d41402abc4b2a76b9719d911017c592 \x0c\r\n"
+             b"\n   \n"
+             b"x\x0c10.9.9.9 inner form feed is no boundary; caf\xc3\xa9.example.fr \"q\\uote.example.com\" 0x52908400098527886E0F7030069857D2E4169EE7\n"
+             b"1BvBMSEYstWetqTFn5Au4m4GFg7xJaNVN2 last line without newline 8.8.8.8")
+    p = tmp_path / "in.log"
+    p.write_bytes(text)
+    exp = _extract_expected(oracle, text)
+    assert len({t for t, _ in exp}) >= 7
+    r = _run([cli, "extract", str(p), "-s"])
+    assert r.returncode == 0, r.stderr
+    got = [json.loads(l) for l in r.stdout.decode().splitlines()]
+    assert [(g["type"], g["value"]) for g in got] == [(t.lower(), v) for t, v in exp]
+    n_lines = sum(1 for raw in text.split(b"\n") if raw.strip(b" \t\n\r\x0c"))
+    assert f"[INFO] Lines processed: {n_lines:,}".encode() in r.stderr and f"[INFO] Patterns found: {len(exp):,}".encode() in r.stderr
+    # small batches and stdin: same output
+    r2 = _run([cli, "extract", "-", "--batch-bytes", "8192"], input=text)
+    assert r2.returncode == 0 and r2.stdout == r.stdout
+    # text and csv, unique
+    rt = _run([cli, "extract", str(p), "--format", "text", "-u"])
+    seen, uniq = set(), []
+    for _, v in exp:
+        if v not in seen:
+            seen.add(v); uniq.append(v)
+    assert rt.stdout.decode().splitlines() == uniq
+    rc = _run([cli, "extract", str(p), "--format=csv", "--types", "ip"])
+    lines = rc.stdout.decode().splitlines()
+    exp_ip = _extract_expected(oracle, text, types=("IPv4", "IPv6"))
+    assert lines[0] == "type,value" and lines[1:] == [f'{t.lower()},"{v}"' for t, v in exp_ip]
+    assert any(t == "MD5" for t, _ in exp_ip) and not any(t == "Domain" for t, _ in exp_ip)
+    # errors
+    assert _run([cli, "extract", str(p), "--format", "xml"]).returncode == 1
+    assert _run([cli, "extract", str(p), "--types", "bogus"]).returncode == 1
+    assert _run([cli, "extract", str(tmp_path / "missing.log")]).returncode == 1
