@@ -276,6 +276,8 @@ char *matchy_amd_query_json(const matchy_t *db, const char *query, int32_t *foun
  * `matchy extract --min-labels`); 0 = the default of 2. */
 matchy_extractor_t *matchy_amd_extractor_create(uint32_t flags, uint32_t min_domain_labels);
 const char *matchy_amd_last_error(void);
+/* HIP devices visible to the process (0 when there is none); `matchy match --devices all` */
+int32_t matchy_amd_device_count(void);
 /* Deterministic builds for tests: fixes the build_epoch metadata value. */
 int32_t matchy_builder_set_build_epoch(matchy_builder_t *b, uint64_t epoch);
 

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "matchy_scanner_set_profile", "matchy_scanner_get_timing", "matchy_amd_last_error", "matchy_builder_set_build_epoch",
     "matchy_get_stats", "matchy_clear_cache", "matchy_has_pattern_data", "matchy_result_get_entry", "matchy_aget_value",
     "matchy_get_entry_data_list", "matchy_free_entry_data_list", "matchy_validate", "matchy_builder_set_schema",
-    "matchy_amd_query_json", "matchy_amd_extractor_create",
+    "matchy_amd_query_json", "matchy_amd_extractor_create", "matchy_amd_device_count",
 ]
 
 

@@ -56,7 +56,7 @@ def build(force=False, verbose=False):
     # the `matchy` command line (build / match) on top of the library
     BINDIR.mkdir(exist_ok=True)
     cli = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", str(CSRC / "cli_main.cpp"), "-o", str(CLI),
-           f"-L{LIBDIR}", "-lmatchy_amd", "-lz", "-Wl,-rpath,$ORIGIN/../lib"]
+           f"-L{LIBDIR}", "-lmatchy_amd", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN/../lib"]
     subprocess.run(cli, check=True)
     return LIB
 

@@ -174,6 +174,10 @@ void fill_result(const FinalHit* fin, size_t n_fin, const uint32_t* ids, const l
 extern "C" {
 
 const char* matchy_amd_last_error(void) { return g_last_error.c_str(); }
+int32_t matchy_amd_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 const char* matchy_version(void) { return "matchy-amd 0.1.0 (reference matchy 1.2.2 surface)"; }
 
 // ------------------------------------------------------------------------------------------------ builder

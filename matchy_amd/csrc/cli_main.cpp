@@ -2,7 +2,7 @@
 // (crates/matchy/src/bin/matchy.rs:78-212):
 //
 //   matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-v]
-//   matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N]
+//   matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N | --devices LIST|all]
 //   matchy query <DATABASE> <QUERY> [-q]                                  (bin/commands/query_cmd.rs)
 //   matchy extract <INPUT>... [--format json|csv|text] [--types LIST] [--min-labels N] [-u] [-s] [--show-candidates]
 //                                                                          (bin/commands/extract_cmd.rs)
@@ -13,12 +13,19 @@
 // there is no CPU scan path. Flags that only tune the reference's CPU thread pool (-j, --readers, --cache-size, -p,
 // --debug-routing) are accepted and ignored; .gz inputs are decompressed on the host (zlib); -f/--follow is not supported.
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,7 +46,7 @@ int usage() {
     fprintf(stderr,
             "usage:\n"
             "  matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-v]\n"
-            "  matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N]\n"
+            "  matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N | --devices LIST|all]\n"
             "  matchy query <DATABASE> <QUERY> [-q]\n"
             "  matchy extract <INPUT>... [--format json|csv|text] [--types LIST] [--min-labels N] [-u] [-s] [--show-candidates]\n");
     return 2;
@@ -268,50 +275,171 @@ struct Totals {
     unsigned long long lines = 0, lines_with_matches = 0, matches = 0, candidates = 0, bytes = 0;
 };
 
-// Scan one newline-aligned batch, print its matches, update the totals. `base` = file offset of the batch.
-bool scan_batch(matchy_scanner_t* sc, const uint8_t* data, size_t len, const std::string& source, bool json, Totals& t) {
-    if (!len) return true;
-    matchy_scan_result_t r;
-    memset(&r, 0, sizeof(r));
-    if (matchy_scanner_scan(sc, data, len, &r) != MATCHY_SUCCESS) {
-        fprintf(stderr, "[ERROR] scan failed: %s\n", matchy_amd_last_error());
-        return false;
+// ---- `matchy match`: reader -> batches -> one worker per device entry -> ordered printer
+// The reader cuts every input into newline-aligned batches (FileReader::next_batch, processing/mod.rs:206-251) and hands
+// them out in sequence; every worker owns one scanner (= one GPU stream and its buffers) on its device; the printer
+// emits the rendered batches in sequence order, so the output is the same for every device list (line blocks
+// are independent, the database is replicated, the host gathers the hit records and sums the counters; no collective).
+// bytes without the value-initialisation of std::vector (a 256 MiB batch buffer would be zeroed before every read)
+struct RawBuf {
+    std::unique_ptr<uint8_t[]> p;
+    size_t cap = 0;
+    explicit RawBuf(size_t n = 0) : p(n ? new uint8_t[n] : nullptr), cap(n) {}
+    uint8_t* data() { return p.get(); }
+    void grow(size_t n, size_t keep) {
+        std::unique_ptr<uint8_t[]> q(new uint8_t[n]);
+        if (keep) memcpy(q.get(), p.get(), keep);
+        p = std::move(q); cap = n;
     }
-    t.lines += r.lines; t.candidates += r.candidates; t.bytes += len; t.matches += r.n_hits;
-    // lines with matches: hits come sorted by offset; a new line starts when a '\n' lies between two hit starts
-    size_t prev = (size_t)-1;
-    for (size_t i = 0; i < r.n_hits; ++i) {
-        const size_t s = (size_t)r.hits[i].start;
-        if (prev == (size_t)-1 || memchr(data + prev, '\n', s - prev)) ++t.lines_with_matches;
-        prev = s;
-        if (json) {
-            char* line = matchy_scan_hit_to_json(sc, &r, i, data, source.c_str());
-            if (line) { fputs(line, stdout); fputc('\n', stdout); matchy_free_string(line); }
+};
+// `ptr` points into `own` (inputs that are read: stdin, .gz) or into a file mapping that outlives the pipeline
+struct Batch { size_t seq = 0, input = 0; RawBuf own; const uint8_t* ptr = nullptr; size_t len = 0; };
+struct Done { std::string out; Totals t; bool ok = true; size_t input = 0; };
+
+struct MatchPipeline {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done, cv_space;
+    std::deque<Batch> q;
+    std::map<size_t, Done> done;
+    size_t max_q = 2, submitted = 0;
+    bool closed = false;
+    bool json = true;
+    std::vector<std::string> sources;
+
+    void submit(Batch&& b) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_space.wait(lk, [&] { return q.size() < max_q; });
+        b.seq = submitted++;
+        q.push_back(std::move(b));
+        cv_work.notify_one();
+    }
+    void close() { std::lock_guard<std::mutex> lk(mu); closed = true; cv_work.notify_all(); cv_done.notify_all(); }
+
+    // scan one batch and render its matches
+    void run_batch(matchy_scanner_t* sc, const Batch& b, Done& d) {
+        d.input = b.input;
+        if (!b.len) return;
+        matchy_scan_result_t r;
+        memset(&r, 0, sizeof(r));
+        if (matchy_scanner_scan(sc, b.ptr, b.len, &r) != MATCHY_SUCCESS) {
+            fprintf(stderr, "[ERROR] scan failed: %s\n", matchy_amd_last_error());
+            d.ok = false;
+            return;
+        }
+        Totals& t = d.t;
+        t.lines += r.lines; t.candidates += r.candidates; t.bytes += b.len; t.matches += r.n_hits;
+        // lines with matches: hits come sorted by offset; a new line starts when a '\n' lies between two hit starts
+        const uint8_t* data = b.ptr;
+        const std::string& source = sources[b.input];
+        size_t prev = (size_t)-1;
+        for (size_t i = 0; i < r.n_hits; ++i) {
+            const size_t s = (size_t)r.hits[i].start;
+            if (prev == (size_t)-1 || memchr(data + prev, '\n', s - prev)) ++t.lines_with_matches;
+            prev = s;
+            if (json) {
+                char* line = matchy_scan_hit_to_json(sc, &r, i, data, source.c_str());
+                if (line) { d.out += line; d.out.push_back('\n'); matchy_free_string(line); }
+            }
+        }
+        matchy_scan_result_free(&r);
+    }
+    void worker(matchy_scanner_t* sc) {
+        for (;;) {
+            Batch b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return closed || !q.empty(); });
+                if (q.empty()) return;
+                b = std::move(q.front());
+                q.pop_front();
+                cv_space.notify_one();
+            }
+            Done d;
+            run_batch(sc, b, d);
+            std::lock_guard<std::mutex> lk(mu);
+            done.emplace(b.seq, std::move(d));
+            cv_done.notify_all();
         }
     }
-    matchy_scan_result_free(&r);
-    return true;
-}
+    // prints in sequence order until `closed` and everything submitted has been printed
+    void printer(Totals& total, std::vector<char>& input_failed) {
+        size_t next = 0;
+        for (;;) {
+            Done d;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_done.wait(lk, [&] { return done.count(next) || (closed && next == submitted); });
+                if (!done.count(next)) return;
+                d = std::move(done[next]);
+                done.erase(next);
+            }
+            ++next;
+            if (!d.out.empty()) fwrite(d.out.data(), 1, d.out.size(), stdout);
+            total.lines += d.t.lines; total.lines_with_matches += d.t.lines_with_matches; total.matches += d.t.matches;
+            total.candidates += d.t.candidates; total.bytes += d.t.bytes;
+            if (!d.ok) input_failed[d.input] = 1;
+        }
+    }
+};
 
 // Inputs ending in .gz (case-insensitive) are decompressed on the fly like the reference's file reader does
-// (crates/matchy/src/file_reader.rs:45-75, by extension); "-" is stdin.
-bool process_input(matchy_scanner_t* sc, const std::string& path, size_t batch_bytes, bool json, Totals& t) {
+// (crates/matchy/src/file_reader.rs:45-75, by extension); "-" is stdin. Regular files are mapped and their batches are
+// views of the mapping (no copy on the host; the pages are pre-faulted one batch ahead of the workers). Returns false when
+// the input could not be read. Mappings go to `maps` and are released by the caller after the pipeline has drained.
+bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t batch_bytes, std::vector<std::pair<void*, size_t>>& maps) {
     const bool gz = ends_with_ci(path, ".gz");
     int fd = path == "-" ? 0 : open(path.c_str(), O_RDONLY);
     if (fd < 0) { fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), strerror(errno)); return false; }
+    struct stat sb;
+    if (!gz && fd != 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && !getenv("MATCHY_AMD_NO_MMAP")) {
+        const size_t size = (size_t)sb.st_size;
+        void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            close(fd);
+            maps.push_back({m, size});
+            (void)madvise(m, size, MADV_SEQUENTIAL);
+            const uint8_t* base = (const uint8_t*)m;
+            for (size_t pos = 0; pos < size;) {
+                size_t end = std::min(size, pos + batch_bytes);
+                if (end < size) {   // newline-aligned cut; a line longer than the batch extends it to that line's end
+                    const void* nl = memrchr(base + pos, '\n', end - pos);
+                    if (nl) end = (const uint8_t*)nl - base + 1;
+                    else {
+                        const void* fw = memchr(base + end, '\n', size - end);
+                        end = fw ? (size_t)((const uint8_t*)fw - base) + 1 : size;
+                    }
+                }
+#ifdef MADV_POPULATE_READ
+                {
+                    const size_t pg = 4096, a = pos & ~(pg - 1);
+                    (void)madvise((uint8_t*)m + a, end - a, MADV_POPULATE_READ);
+                }
+#endif
+                Batch b;
+                b.input = input; b.ptr = base + pos; b.len = end - pos;
+                pl.submit(std::move(b));
+                pos = end;
+            }
+            return true;
+        }
+    }
     gzFile zf = nullptr;
     if (gz) {
         zf = gzdopen(fd, "rb");
         if (!zf) { fprintf(stderr, "[ERROR] Failed to process %s: cannot start gzip decoder\n", path.c_str()); close(fd); return false; }
         gzbuffer(zf, 1u << 20);
     }
-    const std::string source = path == "-" ? "stdin" : path;
-    std::vector<uint8_t> buf(batch_bytes + 16);
+    RawBuf buf(batch_bytes + 16);
     size_t have = 0;
     bool ok = true;
+    auto send = [&](RawBuf&& data, size_t len) {
+        Batch b;
+        b.input = input; b.own = std::move(data); b.ptr = b.own.data(); b.len = len;
+        pl.submit(std::move(b));
+    };
     for (;;) {
-        if (have == buf.size() - 16) buf.resize(buf.size() * 2);  // a single line longer than the batch: grow
-        const size_t room = buf.size() - 16 - have;
+        if (have == buf.cap - 16) buf.grow(buf.cap * 2, have);  // a single line longer than the batch: grow
+        const size_t room = buf.cap - 16 - have;
         ssize_t n;
         if (gz) {
             n = gzread(zf, buf.data() + have, (unsigned)std::min<size_t>(room, 1u << 30));
@@ -321,14 +449,16 @@ bool process_input(matchy_scanner_t* sc, const std::string& path, size_t batch_b
             if (n < 0) { fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), strerror(errno)); ok = false; break; }
         }
         have += (size_t)n;
-        if (n == 0) { ok = scan_batch(sc, buf.data(), have, source, json, t); break; }
+        if (n == 0) { send(std::move(buf), have); break; }
         if (have < batch_bytes) continue;
-        // newline-aligned cut like FileReader::next_batch (processing/mod.rs:206-251): scan up to the last '\n', carry the rest
+        // newline-aligned cut: scan up to the last '\n', carry the rest into the next batch's buffer
         const void* nl = memrchr(buf.data(), '\n', have);
         if (!nl) continue;
         const size_t cut = (const uint8_t*)nl - buf.data() + 1;
-        if (!scan_batch(sc, buf.data(), cut, source, json, t)) { ok = false; break; }
-        memmove(buf.data(), buf.data() + cut, have - cut);
+        RawBuf nxt(std::max(batch_bytes, have - cut) + 16);
+        memcpy(nxt.data(), buf.data() + cut, have - cut);
+        send(std::move(buf), cut);
+        buf = std::move(nxt);
         have -= cut;
     }
     if (gz) gzclose(zf);   // closes fd as well
@@ -338,7 +468,7 @@ bool process_input(matchy_scanner_t* sc, const std::string& path, size_t batch_b
 
 int cmd_match(int argc, char** argv) {
     std::vector<std::string> pos;
-    std::string format = "json", extractors;
+    std::string format = "json", extractors, devices;
     bool stats = false;
     size_t batch_bytes = (size_t)256 << 20;  // GPU batches: large, so that one launch amortises PCIe latency
     int device = 0;
@@ -358,6 +488,7 @@ int cmd_match(int argc, char** argv) {
         else if (a == "-s" || a == "--stats") stats = true;
         else if (eqval("--batch-bytes", v)) { size_t b = strtoull(v.c_str(), nullptr, 10); if (b >= 4096) batch_bytes = b; }
         else if (eqval("--extractors", v)) extractors = v;
+        else if (eqval("--devices", v)) devices = v;
         else if (eqval("--device", v)) device = atoi(v.c_str());
         else if (eqval("--threads", v) || eqval("--readers", v) || eqval("--cache-size", v)) {}
         else if (a == "-j") (void)next("-j");
@@ -368,6 +499,24 @@ int cmd_match(int argc, char** argv) {
     }
     if (pos.size() < 2) return usage();
     if (format != "json" && format != "summary") { fprintf(stderr, "Error: Unknown format: %s. Use 'json' or 'summary'\n", format.c_str()); return 1; }
+    // device list: one worker (scanner) per entry; an entry may repeat (two scanners on one GPU overlap one batch's
+    // transfers with the other's kernels)
+    std::vector<int> devs;
+    if (devices.empty()) devs.push_back(device);
+    else if (devices == "all") {
+        const int n = matchy_amd_device_count();
+        if (n < 1) { fprintf(stderr, "Error: no HIP device available\n"); return 1; }
+        for (int d = 0; d < n; ++d) devs.push_back(d);
+    } else {
+        std::stringstream ss(devices);
+        std::string part;
+        while (std::getline(ss, part, ',')) {
+            part = trim(part);
+            if (part.empty() || part.find_first_not_of("0123456789") != std::string::npos) { fprintf(stderr, "Error: bad --devices entry '%s'\n", part.c_str()); return 1; }
+            devs.push_back(atoi(part.c_str()));
+        }
+        if (devs.empty()) { fprintf(stderr, "Error: --devices needs at least one device\n"); return 1; }
+    }
     const auto t0 = std::chrono::steady_clock::now();
     // database: .mxy file, or a .csv / .json source that is built in memory first (match_cmd.rs:20-31, 222-239)
     matchy_t* db = nullptr;
@@ -394,19 +543,47 @@ int cmd_match(int argc, char** argv) {
         std::string err;
         if (!parse_extractors(extractors, auto_mask, mask, err)) { fprintf(stderr, "Error: %s\n", err.c_str()); matchy_close(db); return 1; }
     }
-    matchy_scanner_t* sc = matchy_scanner_create(db, mask, device);
-    if (!sc) { fprintf(stderr, "Error: Failed to create the GPU scanner: %s\n", matchy_amd_last_error()); matchy_close(db); return 1; }
-    Totals t;
-    size_t processed = 0, failed = 0;
+    std::vector<matchy_scanner_t*> scanners;
+    for (int d : devs) {
+        matchy_scanner_t* sc = matchy_scanner_create(db, mask, d);
+        if (!sc) {
+            fprintf(stderr, "Error: Failed to create the GPU scanner on device %d: %s\n", d, matchy_amd_last_error());
+            for (auto* s2 : scanners) matchy_scanner_free(s2);
+            matchy_close(db);
+            return 1;
+        }
+        scanners.push_back(sc);
+    }
+    MatchPipeline pl;
+    pl.json = format == "json";
+    pl.max_q = scanners.size() + 1;
+    std::vector<std::string> paths;
     bool stdin_seen = false;
     for (size_t i = 1; i < pos.size(); ++i) {
         if (pos[i] == "-") {
             if (stdin_seen) { if (stats) fprintf(stderr, "[WARN] Skipping duplicate stdin argument\n"); continue; }
             stdin_seen = true;
         }
-        if (process_input(sc, pos[i], batch_bytes, format == "json", t)) ++processed; else ++failed;
+        paths.push_back(pos[i]);
+        pl.sources.push_back(pos[i] == "-" ? "stdin" : pos[i]);
     }
+    Totals t;
+    std::vector<char> input_failed(paths.size(), 0);
+    std::vector<std::pair<void*, size_t>> maps;
+    std::vector<std::thread> workers;
+    for (auto* sc : scanners) workers.emplace_back([&pl, sc] { pl.worker(sc); });
+    std::thread printer([&] { pl.printer(t, input_failed); });
+    for (size_t i = 0; i < paths.size(); ++i)
+        if (!read_input(pl, i, paths[i], batch_bytes, maps)) input_failed[i] = 1;
+    pl.close();
+    for (auto& w : workers) w.join();
+    pl.close();   // wake the printer once more now that every batch is in `done`
+    printer.join();
     fflush(stdout);
+    for (auto& mp : maps) munmap(mp.first, mp.second);
+    size_t failed = 0;
+    for (char f : input_failed) failed += f != 0;
+    const size_t processed = paths.size() - failed;
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (stats) {
         fprintf(stderr, "\n[INFO] === Processing Complete ===\n");
@@ -422,9 +599,12 @@ int cmd_match(int argc, char** argv) {
         fprintf(stderr, "[INFO] Throughput: %.2f MB/s\n", secs > 0 ? (double)t.bytes / 1e6 / secs : 0.0);
         fprintf(stderr, "[INFO] Total time: %.2fs\n", secs);
         fprintf(stderr, "[INFO] Query rate: %.0f queries/s\n", secs > 0 ? (double)t.candidates / secs : 0.0);
-        fprintf(stderr, "\n[INFO] === Device ===\n[INFO] HIP device: %d (one scanner, batches of %zu MiB)\n", device, batch_bytes >> 20);
+        std::string dl;
+        for (int d : devs) { if (!dl.empty()) dl += ","; dl += std::to_string(d); }
+        fprintf(stderr, "\n[INFO] === Devices ===\n[INFO] HIP devices: %s (%zu scanner%s, batches of %zu MiB)\n", dl.c_str(), scanners.size(),
+                scanners.size() == 1 ? "" : "s", batch_bytes >> 20);
     }
-    matchy_scanner_free(sc);
+    for (auto* sc : scanners) matchy_scanner_free(sc);
     matchy_close(db);
     if (failed) { fprintf(stderr, "Error: %zu file(s) failed to process\n", failed); return 1; }
     return 0;

@@ -135,6 +135,16 @@ def test_match_config1_end_to_end(cli, tmp_path, oracle):
     rz = _run([cli, "match", str(dbp), str(gzp), "--batch-bytes", "300000"])
     assert rz.returncode == 0
     assert [json.loads(l) | {"source": ""} for l in rz.stdout.decode().splitlines()] == [json.loads(l) | {"source": ""} for l in want_lines]
+    # several scanners (one worker per --devices entry; the same GPU twice here): batches are handed out in sequence and
+    # printed in sequence, so output and counters do not depend on the device list
+    rd = _run([cli, "match", str(dbp), str(logp), str(gzp), "--devices", "0,0,0", "--batch-bytes", "50000", "-s"])
+    assert rd.returncode == 0, rd.stderr
+    both = want_lines + [json.dumps(json.loads(l) | {"source": str(gzp)}, separators=(",", ":"), ensure_ascii=False) for l in want_lines]
+    assert [json.loads(l) for l in rd.stdout.decode().splitlines()] == [json.loads(l) for l in both]
+    assert b"[INFO] Lines processed: 20,000" in rd.stderr and b"3 scanners" in rd.stderr and b"[INFO] Files processed: 2" in rd.stderr
+    ra = _run([cli, "match", str(dbp), str(logp), "--devices", "all"])
+    assert ra.returncode == 0 and ra.stdout.decode().splitlines() == want_lines
+    assert _run([cli, "match", str(dbp), str(logp), "--devices", "0,x"]).returncode == 1
     r6 = _run([cli, "match", str(dbp), str(tmp_path / "nope.log"), str(logp)])
     assert r6.returncode != 0 and r6.stdout.decode().splitlines() == want_lines
 
