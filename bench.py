@@ -123,7 +123,7 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/prof.sh; FETCH_SIZE x2 on gfx950)
         tj = json.load(open(ROOT / "profiles" / "r01_traffic.json"))
         if tj.get("bytes_per_gpu") == nbytes:
-            key = {"k_anchor": "mxy::k_anchor", "k_validate_dom+k_validate": "mxy::k_validate_dom", "k_rare": "mxy::k_rare", "k_lookup+k_pack": "mxy::k_lookup<false>"}[dom_name]
+            key = {"k_anchor": "mxy::k_anchor", "k_validate_dom+k_validate": "mxy::k_validate_dom<false>", "k_rare": "mxy::k_rare", "k_lookup+k_pack": "mxy::k_lookup<false>"}[dom_name]
             traffic = tj["kernels"][key]["hbm_bytes"]
             tr_note = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
     except Exception:

@@ -244,7 +244,10 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     auto load_block = [&](uint32_t b, uint32_t (&w)[4]) {
         const uint32_t pos0 = b + lane * 16;
         if (pos0 + 16 <= len) {
-            const uint4 v = *reinterpret_cast<const uint4*>(p.log + pos0);
+            // streamed once: a non-temporal load keeps the log from pushing the database's /24 bitmap (the one table
+            // this kernel reads at random) out of L2
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.log + pos0));
             w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
         } else {
 #pragma unroll
