@@ -293,7 +293,7 @@ struct RawBuf {
     }
 };
 // `ptr` points into `own` (inputs that are read: stdin, .gz) or into a file mapping that outlives the pipeline
-struct Batch { size_t seq = 0, input = 0; RawBuf own; const uint8_t* ptr = nullptr; size_t len = 0; };
+struct Batch { size_t seq = 0, input = 0; RawBuf own; const uint8_t* ptr = nullptr; size_t len = 0; bool mapped = false; };
 struct Done { std::string out; Totals t; bool ok = true; size_t input = 0; };
 
 struct MatchPipeline {
@@ -319,6 +319,12 @@ struct MatchPipeline {
     void run_batch(matchy_scanner_t* sc, const Batch& b, Done& d) {
         d.input = b.input;
         if (!b.len) return;
+#ifdef MADV_POPULATE_READ
+        if (b.mapped) {   // pre-fault the batch's pages in one call (in the worker: the workers run side by side)
+            const uintptr_t a = (uintptr_t)b.ptr & ~(uintptr_t)4095;
+            (void)madvise((void*)a, (uintptr_t)b.ptr + b.len - a, MADV_POPULATE_READ);
+        }
+#endif
         matchy_scan_result_t r;
         memset(&r, 0, sizeof(r));
         if (matchy_scanner_scan(sc, b.ptr, b.len, &r) != MATCHY_SUCCESS) {
@@ -384,7 +390,7 @@ struct MatchPipeline {
 
 // Inputs ending in .gz (case-insensitive) are decompressed on the fly like the reference's file reader does
 // (crates/matchy/src/file_reader.rs:45-75, by extension); "-" is stdin. Regular files are mapped and their batches are
-// views of the mapping (no copy on the host; the pages are pre-faulted one batch ahead of the workers). Returns false when
+// views of the mapping (no copy on the host; each worker pre-faults its batch's pages). Returns false when
 // the input could not be read. Mappings go to `maps` and are released by the caller after the pipeline has drained.
 bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t batch_bytes, std::vector<std::pair<void*, size_t>>& maps) {
     const bool gz = ends_with_ci(path, ".gz");
@@ -409,14 +415,8 @@ bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t
                         end = fw ? (size_t)((const uint8_t*)fw - base) + 1 : size;
                     }
                 }
-#ifdef MADV_POPULATE_READ
-                {
-                    const size_t pg = 4096, a = pos & ~(pg - 1);
-                    (void)madvise((uint8_t*)m + a, end - a, MADV_POPULATE_READ);
-                }
-#endif
                 Batch b;
-                b.input = input; b.ptr = base + pos; b.len = end - pos;
+                b.input = input; b.ptr = base + pos; b.len = end - pos; b.mapped = true;
                 pl.submit(std::move(b));
                 pos = end;
             }

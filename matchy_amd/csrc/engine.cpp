@@ -326,6 +326,7 @@ Scanner::~Scanner() {
     if (pinned_) (void)hipHostFree(pinned_);
     if (mirror_) (void)hipHostFree(mirror_);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    if (host_stream_) (void)hipStreamDestroy(host_stream_);
 }
 
 void Scanner::ensure_capacity(uint32_t len) {
@@ -581,6 +582,9 @@ void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_
                         std::vector<FinalHit>* fin, std::vector<uint32_t>* fin_ids, std::vector<long long>* fin_offs) {
     // Cut into < 2^30-byte pieces at newlines (N4 in SURVEY §8a: no candidate class admits '\n').
     const size_t MAXC = (size_t)1 << 30;
+    // copies and kernels of a host-buffer scan go to a stream of this scanner's own, so that several scanners on one
+    // device (one per host thread, `matchy match --devices 0,0`) overlap one batch's transfer with another's kernels
+    if (!host_stream_) { MXY_HIP(hipSetDevice(ddb_->device)); MXY_HIP(hipStreamCreateWithFlags(&host_stream_, hipStreamNonBlocking)); }
     out = ScanOutput();
     size_t pos = 0;
     std::vector<Candidate> all_cands;
@@ -594,10 +598,10 @@ void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_
             n = (const uint8_t*)nl - (data + pos) + 1;
         }
         if (staging_.n < n + 16) staging_.alloc(n + 16 + n / 8);
-        if (n) MXY_HIP(hipMemcpy(staging_.p, data + pos, n, hipMemcpyHostToDevice));
-        scan_device(staging_.p, (uint32_t)n, lookup, nullptr);
+        if (n) MXY_HIP(hipMemcpyAsync(staging_.p, data + pos, n, hipMemcpyHostToDevice, host_stream_));
+        scan_device(staging_.p, (uint32_t)n, lookup, host_stream_);
         ScanOutput part;
-        fetch(part, want_cands, nullptr, lookup && fin ? HITS_FINAL : HITS_NONE, true);
+        fetch(part, want_cands, host_stream_, lookup && fin ? HITS_FINAL : HITS_NONE, true);
         out.lines += part.lines; out.n_cand += part.n_cand; out.n_hits += part.n_hits;
         for (int t = 0; t < IT_COUNT; ++t) out.by_type[t] += part.by_type[t];
         if (fin && part.n_fin) {

@@ -123,6 +123,7 @@ private:
     void ensure_capacity(uint32_t len);
     std::shared_ptr<const DbImage> img_;
     std::shared_ptr<DeviceDb> ddb_;
+    hipStream_t host_stream_ = nullptr;   // scan_host: this scanner's own non-blocking stream
     uint32_t flags_, min_labels_;
     DevBuf<Candidate> cands_;
     DevBuf<RareAnchor> rare_, tok_, heavy_;

@@ -53,8 +53,16 @@ def lib():
     global _lib
     if _lib is None:
         if not LIB.exists() or LIB.stat().st_mtime < SRC.stat().st_mtime:
+            # several ranks of one node may get here at once: build under a lock, into a private file, rename into place
+            import fcntl
+            import os
             LIB.parent.mkdir(exist_ok=True)
-            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(LIB), str(SRC)], check=True)
+            with open(LIB.parent / ".synthgen.lock", "w") as lk:
+                fcntl.flock(lk, fcntl.LOCK_EX)
+                if not LIB.exists() or LIB.stat().st_mtime < SRC.stat().st_mtime:
+                    tmp = LIB.with_suffix(f".{os.getpid()}.tmp")
+                    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(tmp), str(SRC)], check=True)
+                    os.replace(tmp, LIB)
         L = C.CDLL(str(LIB))
         L.synth_log.argtypes = [C.POINTER(Cfg), C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]
         L.synth_log.restype = C.c_size_t
