@@ -258,6 +258,12 @@ int32_t matchy_scanner_scan(matchy_scanner_t *scanner, const uint8_t *data, size
 #define MATCHY_SCAN_FETCH_SORTED 3u
 int32_t matchy_scanner_scan_device(matchy_scanner_t *scanner, const void *device_ptr, size_t len, void *hip_stream,
                                    uint32_t fetch_mode, matchy_scan_result_t *out);
+/* The two halves of matchy_scanner_scan_device: submit launches one batch on `hip_stream` and returns, wait blocks until
+ * it is done and hands out its result (one batch in flight per scanner). Two scanners on two streams let one batch's
+ * result transfer overlap the next batch's streaming kernel. */
+int32_t matchy_scanner_submit_device(matchy_scanner_t *scanner, const void *device_ptr, size_t len, void *hip_stream,
+                                     uint32_t fetch_mode);
+int32_t matchy_scanner_wait(matchy_scanner_t *scanner, matchy_scan_result_t *out);
 void matchy_scan_result_free(matchy_scan_result_t *result);
 /* The NDJSON record `matchy match` prints for hit i (match_processor/parallel.rs:297-369). `text` points at the
  * scanned bytes on the host. Returned string: matchy_free_string(). */

@@ -38,7 +38,8 @@ EXPORTED_SYMBOLS = [
     "matchy_scanner_set_profile", "matchy_scanner_get_timing", "matchy_amd_last_error", "matchy_builder_set_build_epoch",
     "matchy_get_stats", "matchy_clear_cache", "matchy_has_pattern_data", "matchy_result_get_entry", "matchy_aget_value",
     "matchy_get_entry_data_list", "matchy_free_entry_data_list", "matchy_validate", "matchy_builder_set_schema",
-    "matchy_amd_query_json", "matchy_amd_extractor_create", "matchy_amd_device_count",
+    "matchy_amd_query_json", "matchy_amd_extractor_create", "matchy_amd_device_count", "matchy_scanner_submit_device",
+    "matchy_scanner_wait",
 ]
 
 
@@ -140,6 +141,8 @@ def lib():
         "matchy_scanner_free": (None, [vp]),
         "matchy_scanner_scan": (C.c_int32, [vp, vp, C.c_size_t, C.POINTER(_ScanResult)]),
         "matchy_scanner_scan_device": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_uint32, C.POINTER(_ScanResult)]),
+        "matchy_scanner_submit_device": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_uint32]),
+        "matchy_scanner_wait": (C.c_int32, [vp, C.POINTER(_ScanResult)]),
         "matchy_scan_result_free": (None, [C.POINTER(_ScanResult)]),
         "matchy_scan_hit_to_json": (vp, [vp, C.POINTER(_ScanResult), C.c_size_t, cp, cp]),
         "matchy_scanner_set_profile": (None, [vp, C.c_bool]),
@@ -442,6 +445,18 @@ class Scanner:
         rc = lib().matchy_scanner_scan_device(self._h, device_ptr, nbytes, stream, fetch_mode, C.byref(raw))
         if rc != 0:
             raise RuntimeError(f"matchy_scanner_scan_device failed: rc={rc} {last_error()}")
+        return ScanResult(self, raw)
+
+    def submit_device(self, device_ptr: int, nbytes: int, stream: int = 0, fetch_mode=1):
+        rc = lib().matchy_scanner_submit_device(self._h, device_ptr, nbytes, stream, fetch_mode)
+        if rc != 0:
+            raise RuntimeError(f"matchy_scanner_submit_device failed: rc={rc} {last_error()}")
+
+    def wait(self) -> ScanResult:
+        raw = _ScanResult()
+        rc = lib().matchy_scanner_wait(self._h, C.byref(raw))
+        if rc != 0:
+            raise RuntimeError(f"matchy_scanner_wait failed: rc={rc} {last_error()}")
         return ScanResult(self, raw)
 
     def timing_ms(self):

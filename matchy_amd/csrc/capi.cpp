@@ -67,6 +67,11 @@ struct MatchesInternal {
 struct ScannerH {
     const Db* db;
     std::unique_ptr<Scanner> sc;
+    // matchy_scanner_submit_device -> matchy_scanner_wait
+    bool pending = false;
+    size_t pending_len = 0;
+    uint32_t pending_mode = 0;
+    void* pending_stream = nullptr;
 };
 
 struct ScanResultInternal {
@@ -656,6 +661,39 @@ int32_t matchy_scanner_scan_device(matchy_scanner_t* s, const void* dptr, size_t
         h->sc->fetch(so, false, st, (fetch_mode & 1) ? HITS_FINAL : HITS_NONE, sorted);
         fill_result(so.fin, so.n_fin, so.fin_ids, so.fin_offs, so.n_fin_ids, so.lines, so.n_cand, len, !sorted, sorted, out);
         if (!(fetch_mode & 1)) out->n_hits = so.n_hits;  // count only; `hits` stays NULL
+        return MATCHY_SUCCESS;
+    } catch (const HipError& e) { set_error(e.what); return MATCHY_ERROR_IO; }
+    catch (const std::exception& e) { set_error(e.what()); return MATCHY_ERROR_IO; }
+}
+
+// The two halves of matchy_scanner_scan_device: submit launches the kernels of one batch on `stream` and returns; wait
+// blocks until that batch is done and hands out its result. A host that keeps two scanners busy (each on its own stream)
+// overlaps one batch's result transfer and latency-bound kernels with the next batch's streaming kernel.
+int32_t matchy_scanner_submit_device(matchy_scanner_t* s, const void* dptr, size_t len, void* stream, uint32_t fetch_mode) {
+    if (!s || !dptr) return MATCHY_ERROR_INVALID_PARAM;
+    if (len >= 0x7FFF0000ull) return MATCHY_ERROR_INVALID_PARAM;
+    ScannerH* h = reinterpret_cast<ScannerH*>(s);
+    try {
+        const bool sorted = (fetch_mode & 2) != 0;
+        h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, reinterpret_cast<hipStream_t>(stream), (fetch_mode & 1) && !sorted);
+        h->pending = true; h->pending_len = len; h->pending_mode = fetch_mode; h->pending_stream = stream;
+        return MATCHY_SUCCESS;
+    } catch (const HipError& e) { set_error(e.what); return MATCHY_ERROR_IO; }
+    catch (const std::exception& e) { set_error(e.what()); return MATCHY_ERROR_IO; }
+}
+int32_t matchy_scanner_wait(matchy_scanner_t* s, matchy_scan_result_t* out) {
+    if (!s || !out) return MATCHY_ERROR_INVALID_PARAM;
+    ScannerH* h = reinterpret_cast<ScannerH*>(s);
+    if (!h->pending) { set_error("matchy_scanner_wait: nothing was submitted"); return MATCHY_ERROR_INVALID_PARAM; }
+    h->pending = false;
+    try {
+        const uint32_t fetch_mode = h->pending_mode;
+        const bool sorted = (fetch_mode & 2) != 0;
+        hipStream_t st = reinterpret_cast<hipStream_t>(h->pending_stream);
+        ScanOutput so;
+        h->sc->fetch(so, false, st, (fetch_mode & 1) ? HITS_FINAL : HITS_NONE, sorted);
+        fill_result(so.fin, so.n_fin, so.fin_ids, so.fin_offs, so.n_fin_ids, so.lines, so.n_cand, h->pending_len, !sorted, sorted, out);
+        if (!(fetch_mode & 1)) out->n_hits = so.n_hits;
         return MATCHY_SUCCESS;
     } catch (const HipError& e) { set_error(e.what); return MATCHY_ERROR_IO; }
     catch (const std::exception& e) { set_error(e.what()); return MATCHY_ERROR_IO; }

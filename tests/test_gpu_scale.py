@@ -139,3 +139,47 @@ def test_scan_device_fetch_modes(M, oracle, cfgname, mirror, monkeypatch):
         assert sorted(h1, key=key) == sorted(want, key=key)
     sc.close(); db.close()
     hip.hipFree(dptr)
+
+
+def test_submit_wait_overlapping_batches(M, oracle):
+    """matchy_scanner_submit_device / matchy_scanner_wait: three scanners, each on its own stream, with different batches in
+    flight at the same time; every batch's result equals the oracle's (and the synchronous entry's)."""
+    import ctypes
+    from tools import synth
+    cfg = synth.config("c4/10")
+    blob = synth.build_db(cfg)
+    logs = [synth.make_log(cfg, a, 40000) for a in (0, 40000, 80000)]
+    odb = oracle.Database(blob)
+    wants = [odb.scan(lg, want_json=False) for lg in logs]
+    db = M.Database(blob)
+    hip = ctypes.CDLL("libamdhip64.so")
+    scs, ptrs, streams = [], [], []
+    for lg in logs:
+        scs.append(M.Scanner(db))
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(len(lg) + 64)) == 0
+        assert hip.hipMemcpy(p, lg, ctypes.c_size_t(len(lg)), 1) == 0
+        ptrs.append(p)
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0   # hipStreamNonBlocking
+        streams.append(st)
+    for rep in range(3):
+        for sc, p, st, lg in zip(scs, ptrs, streams, logs):
+            sc.submit_device(p.value, len(lg), stream=st.value, fetch_mode=3 if rep else 1)
+        for sc, (want, _, stats) in zip(scs, wants):
+            r = sc.wait()
+            hits = r.hits()
+            assert (r.lines, r.candidates, r.n_hits) == (stats.lines, stats.candidates, len(want))
+            r.close()
+            key = lambda h: (h["start"], h["end"], h["type"])
+            assert sorted(hits, key=key) == sorted(want, key=key)
+            if rep:
+                assert hits == want
+    with pytest.raises(RuntimeError):
+        scs[0].wait()   # nothing submitted
+    for sc in scs:
+        sc.close()
+    for p, st in zip(ptrs, streams):
+        hip.hipStreamDestroy(st)
+        hip.hipFree(p)
+    db.close()
