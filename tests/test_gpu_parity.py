@@ -505,6 +505,47 @@ def test_glob_differential_fuzz(M, oracle, seed):
     assert len(gh) > 100
 
 
+def _mutated_log(seed, lines, count=400):
+    """Lines of a synthetic access log with random byte-level damage: delimiters swapped in, bytes dropped, dots / dashes /
+    '@' / '::' / '0x' spliced in, pieces duplicated, raw bytes — candidates that almost parse."""
+    rng = random.Random(seed)
+    out = bytearray()
+    for ln in rng.sample(lines, min(count, len(lines))):
+        b = bytearray(ln)
+        for _ in range(rng.choice([0, 1, 1, 2, 5])):
+            if not b:
+                break
+            k = rng.randrange(len(b))
+            r = rng.random()
+            if r < 0.3:
+                b[k] = rng.choice(b" ./:@-_=\"'[](){}<>,;\t\xc3\xa9\xff0aZ9")
+            elif r < 0.5:
+                del b[k]
+            elif r < 0.7:
+                b[k:k] = rng.choice([b".", b"..", b"-.", b".-", b"@", b"::", b"0x", b" ", b"1.1.1.1", b".com", b"\xe2\x80\x9c", b"a" * 30])
+            elif r < 0.8:
+                b[k:k] = b[max(0, k - 20):k]
+            else:
+                b[k] = rng.randrange(256)
+        out += b + rng.choice([b"\n", b"\n", b"\r\n", b" ", b""])
+    return bytes(out)
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_mutated_log_fuzz(M, oracle, seed):
+    """Damaged access-log lines through the extractor and through a scan against the config-4 mix (globs, literals, IPs)."""
+    from tools import synth
+    cfg = synth.config("c4/50")
+    blob = synth.build_db(cfg)
+    buf = _mutated_log(seed, synth.make_log(cfg, 0, 3000).split(b"\n"), 1500)
+    ex = M.Extractor()
+    got, want = norm(ex.extract_from_chunk(buf)), norm(oracle.extract(buf))
+    ex.close()
+    assert got == want
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, buf)
+    assert gs == ws and gh == wh and gl == wl
+
+
 REFERENCE_BEHAVIOUR = [
     # (entries, queries) — the behavioural vectors of the reference's own tests (test_ip_longest_prefix_match.rs,
     # test_literal_hash.rs, paraglob_offset.rs:1890-1944, matchy-paraglob/tests/integration_tests.rs), as in
