@@ -181,10 +181,12 @@ def _take_string(ptr) -> str:
 class DatabaseBuilder:
     """Mirror of the reference builder behind matchy_builder_* (host-side, no GPU needed)."""
 
-    def __init__(self, build_epoch=None):
+    def __init__(self, build_epoch=None, case_insensitive=False):
         self._h = lib().matchy_builder_new()
         if build_epoch is not None:
             lib().matchy_builder_set_build_epoch(self._h, build_epoch)
+        if case_insensitive:
+            lib().matchy_builder_set_case_insensitive(self._h, True)
 
     def add_entry(self, key: str, data: dict):
         rc = lib().matchy_builder_add(self._h, key.encode("utf-8"), json.dumps(data).encode("utf-8"))

@@ -291,6 +291,30 @@ char* matchy_get_pattern_string(const matchy_t* db, uint32_t id) {
 void matchy_free_string(char* s) { free(s); }
 
 // ------------------------------------------------------------------------------------------------ single query
+// Database::lookup (database.rs:725-804): a query that parses as an IP address takes the trie, anything else the string
+// path. Fills the one-candidate "scan" both single-query entries run through the lookup kernels. False: query too long.
+static bool query_candidate(const char* query, size_t qn, IpAddr& ip, bool& is_ip, std::string& text, Candidate& c) {
+    text.assign(query, qn);
+    c = Candidate{0, 0, 0, 0};
+    is_ip = parse_ip(query, qn, ip);
+    if (is_ip) {
+        if (!ip.v6) {
+            c.v4 = ((uint32_t)ip.b[0] << 24) | ((uint32_t)ip.b[1] << 16) | ((uint32_t)ip.b[2] << 8) | ip.b[3];
+            c.len_type = (uint32_t)qn | ((uint32_t)IT_IPV4 << 24);
+        } else {
+            char buf[64];
+            snprintf(buf, sizeof(buf), "%x:%x:%x:%x:%x:%x:%x:%x", (ip.b[0] << 8) | ip.b[1], (ip.b[2] << 8) | ip.b[3], (ip.b[4] << 8) | ip.b[5],
+                     (ip.b[6] << 8) | ip.b[7], (ip.b[8] << 8) | ip.b[9], (ip.b[10] << 8) | ip.b[11], (ip.b[12] << 8) | ip.b[13], (ip.b[14] << 8) | ip.b[15]);
+            text = buf;
+            c.len_type = (uint32_t)text.size() | ((uint32_t)IT_IPV6 << 24);
+        }
+        return true;
+    }
+    if (qn >= (1u << 24)) return false;
+    c.len_type = (uint32_t)qn | ((uint32_t)IT_DOMAIN << 24);
+    return true;
+}
+
 void matchy_query_into(const matchy_t* dbc, const char* query, matchy_result_t* result) {
     if (!result) return;
     *result = matchy_result_t{false, 0, nullptr, nullptr};
@@ -301,23 +325,11 @@ void matchy_query_into(const matchy_t* dbc, const char* query, matchy_result_t* 
     try {
         std::lock_guard<std::mutex> lk(db->mu);
         if (!db->query_scanner) db->query_scanner = std::make_unique<Scanner>(db->img, db->device_db(db->default_device), EX_ALL, 2);
-        // Database::lookup (database.rs:725-804): try IpAddr first, otherwise the string path
         IpAddr ip;
-        std::string text(query, qn);
-        Candidate c{0, 0, 0, 0};
-        if (parse_ip(query, qn, ip)) {
-            if (!ip.v6) { c.v4 = ((uint32_t)ip.b[0] << 24) | ((uint32_t)ip.b[1] << 16) | ((uint32_t)ip.b[2] << 8) | ip.b[3]; c.len_type = (uint32_t)qn | ((uint32_t)IT_IPV4 << 24); }
-            else {
-                char buf[64];
-                snprintf(buf, sizeof(buf), "%x:%x:%x:%x:%x:%x:%x:%x", (ip.b[0] << 8) | ip.b[1], (ip.b[2] << 8) | ip.b[3], (ip.b[4] << 8) | ip.b[5],
-                         (ip.b[6] << 8) | ip.b[7], (ip.b[8] << 8) | ip.b[9], (ip.b[10] << 8) | ip.b[11], (ip.b[12] << 8) | ip.b[13], (ip.b[14] << 8) | ip.b[15]);
-                text = buf;
-                c.len_type = (uint32_t)text.size() | ((uint32_t)IT_IPV6 << 24);
-            }
-        } else {
-            if (qn >= (1u << 24)) return;
-            c.len_type = (uint32_t)qn | ((uint32_t)IT_DOMAIN << 24);
-        }
+        bool is_ip;
+        std::string text;
+        Candidate c;
+        if (!query_candidate(query, qn, ip, is_ip, text, c)) return;
         ScanOutput so;
         db->query_scanner->lookup_one(text, c, so);
         db->st_total++;
@@ -351,26 +363,15 @@ char* matchy_amd_query_json(const matchy_t* dbc, const char* query, int32_t* fou
     if (!dbc || !query) return nullptr;
     Db* db = const_cast<Db*>(reinterpret_cast<const Db*>(dbc));
     const size_t qn = strlen(query);
-    if (!valid_utf8_host((const uint8_t*)query, qn) || qn >= (1u << 24)) return strdup("[]");
+    if (!valid_utf8_host((const uint8_t*)query, qn)) return strdup("[]");
     try {
         std::lock_guard<std::mutex> lk(db->mu);
         if (!db->query_scanner) db->query_scanner = std::make_unique<Scanner>(db->img, db->device_db(db->default_device), EX_ALL, 2);
         IpAddr ip;
-        std::string text(query, qn);
-        Candidate c{0, 0, 0, 0};
-        const bool is_ip = parse_ip(query, qn, ip);
-        if (is_ip) {
-            if (!ip.v6) { c.v4 = ((uint32_t)ip.b[0] << 24) | ((uint32_t)ip.b[1] << 16) | ((uint32_t)ip.b[2] << 8) | ip.b[3]; c.len_type = (uint32_t)qn | ((uint32_t)IT_IPV4 << 24); }
-            else {
-                char buf[64];
-                snprintf(buf, sizeof(buf), "%x:%x:%x:%x:%x:%x:%x:%x", (ip.b[0] << 8) | ip.b[1], (ip.b[2] << 8) | ip.b[3], (ip.b[4] << 8) | ip.b[5],
-                         (ip.b[6] << 8) | ip.b[7], (ip.b[8] << 8) | ip.b[9], (ip.b[10] << 8) | ip.b[11], (ip.b[12] << 8) | ip.b[13], (ip.b[14] << 8) | ip.b[15]);
-                text = buf;
-                c.len_type = (uint32_t)text.size() | ((uint32_t)IT_IPV6 << 24);
-            }
-        } else {
-            c.len_type = (uint32_t)qn | ((uint32_t)IT_DOMAIN << 24);
-        }
+        bool is_ip;
+        std::string text;
+        Candidate c;
+        if (!query_candidate(query, qn, ip, is_ip, text, c)) return strdup("[]");
         ScanOutput so;
         db->query_scanner->lookup_one(text, c, so);
         if (so.hits.empty()) return strdup("[]");

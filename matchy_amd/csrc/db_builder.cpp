@@ -1,4 +1,5 @@
 #include "db_builder.h"
+#include "unicode_lower.h"
 
 #include <algorithm>
 #include <cmath>
@@ -159,11 +160,14 @@ struct AcState {
 };
 struct AcResult { std::vector<uint8_t> buf; size_t node_count = 0; };
 
-AcResult build_ac(const std::vector<std::string>& pats) {
+// `ci`: the bytes that go into the trie are the lower-cased literal (matchy-ac/src/lib.rs:204-210: `to_lowercase()`), the
+// text is ASCII-lower-cased at search time instead of doubling the transitions.
+AcResult build_ac(const std::vector<std::string>& pats, bool ci) {
     std::vector<AcState> st(1);
     for (size_t pid = 0; pid < pats.size(); ++pid) {
         uint32_t cur = 0;
-        for (unsigned char ch : pats[pid]) {
+        const std::string bytes = ci ? LowerTable::get().to_lowercase(pats[pid]) : pats[pid];
+        for (unsigned char ch : bytes) {
             auto it = st[cur].tr.find(ch);
             if (it != st[cur].tr.end()) cur = it->second;
             else {
@@ -273,6 +277,7 @@ struct ParaglobBuilder {
     struct Pat { std::string text; int cls; std::vector<std::string> lits; };  // cls: 0 literal, 1 glob, 2 pure wildcard
     std::vector<Pat> pats;
     std::unordered_map<std::string, uint32_t> index;
+    bool case_insensitive = false;
 
     bool add(const std::string& p, uint32_t& id, std::string& err) {
         auto it = index.find(p);
@@ -307,7 +312,7 @@ struct ParaglobBuilder {
             else if (p.cls == 1) for (const auto& l : p.lits) { if (l.size() < 3) continue; add_lit(l, pid); }
         }
         AcResult ac;
-        if (!ac_lits.empty()) ac = build_ac(ac_lits);
+        if (!ac_lits.empty()) ac = build_ac(ac_lits, case_insensitive);
         ac_nodes = ac.node_count;
 
         // ACLH (literal_hash.rs:121-200)
@@ -389,7 +394,7 @@ struct ParaglobBuilder {
 
         memcpy(buffer.data(), "PARAGLOB", 8);
         set32(buffer, 8, 5);
-        set32(buffer, 12, 0);  // match_mode: CaseSensitive
+        set32(buffer, 12, case_insensitive ? 1 : 0);  // match_mode (paraglob_offset.rs:720-723)
         set32(buffer, 16, (uint32_t)ac.node_count);
         set32(buffer, 20, (uint32_t)ac_start);
         set32(buffer, 24, (uint32_t)ac_size);
@@ -713,7 +718,6 @@ bool DatabaseBuilder::add_glob(const std::string& s, const DataValue& data_map) 
 
 // DatabaseBuilder::build (mmdb_builder.rs:432-760)
 bool DatabaseBuilder::build(std::vector<uint8_t>& db) {
-    if (case_insensitive_) { error_ = "case-insensitive databases are not supported yet (SURVEY §8 f2)"; return false; }
     std::vector<uint8_t> data_section = encoder_.bytes();
     std::vector<const Entry*> ips, lits, globs;
     for (const Entry& e : entries_) (e.kind == EntryKind::IP ? ips : e.kind == EntryKind::LITERAL ? lits : globs).push_back(&e);
@@ -762,6 +766,7 @@ bool DatabaseBuilder::build(std::vector<uint8_t>& db) {
     std::vector<uint8_t> glob_section;
     if (has_globs) {
         ParaglobBuilder pb;
+        pb.case_insensitive = case_insensitive_;
         std::vector<uint32_t> offsets;
         for (auto* e : globs) {
             uint32_t id;
@@ -783,7 +788,17 @@ bool DatabaseBuilder::build(std::vector<uint8_t>& db) {
     if (has_literals) {
         std::vector<std::pair<const std::string*, uint32_t>> l;
         std::vector<std::pair<uint32_t, uint32_t>> pd;
-        for (size_t i = 0; i < lits.size(); ++i) { l.emplace_back(&lits[i]->text, (uint32_t)i); pd.emplace_back((uint32_t)i, lits[i]->data_offset); }
+        // case-insensitive: LiteralHashBuilder::add_pattern stores and hashes the lower-cased key
+        // (matchy-literal-hash/src/lib.rs:158-167)
+        std::vector<std::string> lowered;
+        if (case_insensitive_) {
+            lowered.reserve(lits.size());
+            for (auto* e : lits) lowered.push_back(LowerTable::get().to_lowercase(e->text));
+        }
+        for (size_t i = 0; i < lits.size(); ++i) {
+            l.emplace_back(case_insensitive_ ? &lowered[i] : &lits[i]->text, (uint32_t)i);
+            pd.emplace_back((uint32_t)i, lits[i]->data_offset);
+        }
         literal_section = build_literal_hash(l, pd);
     }
 
@@ -825,7 +840,7 @@ bool DatabaseBuilder::build(std::vector<uint8_t>& db) {
     meta.map["ip_entry_count"] = DataValue::Uint32((uint32_t)ips.size());
     meta.map["literal_entry_count"] = DataValue::Uint32((uint32_t)lits.size());
     meta.map["glob_entry_count"] = DataValue::Uint32((uint32_t)globs.size());
-    meta.map["match_mode"] = DataValue::Uint16(0);
+    meta.map["match_mode"] = DataValue::Uint16(case_insensitive_ ? 1 : 0);   // mmdb_builder.rs:676-680
     meta.map["pattern_section_offset"] = DataValue::Uint32((uint32_t)pattern_offset);
     meta.map["literal_section_offset"] = DataValue::Uint32((uint32_t)literal_offset);
     DataEncoder menc;

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "crypto.h"
+#include "unicode_lower.h"
 
 namespace orc {
 
@@ -495,7 +496,15 @@ struct Database {
     }
 
     // ---- literal hash (literal-hash/lib.rs:467-575)
-    bool lh_lookup(const uint8_t* q, size_t qn, uint32_t& pattern_id) const {
+    bool lh_lookup(const uint8_t* q0, size_t qn0, uint32_t& pattern_id) const {
+        // case-insensitive: the query is lower-cased the way the keys were (lib.rs:469-472: `query.to_lowercase()`)
+        std::string lowered;
+        const uint8_t* q = q0;
+        size_t qn = qn0;
+        if (match_mode == 1) {
+            lowered = Lowercase::table().to_lowercase(std::string((const char*)q0, qn0));
+            q = (const uint8_t*)lowered.data(); qn = lowered.size();
+        }
         uint64_t hash = xxh64(q, qn, 0);
         size_t shard = (size_t)(hash % lh_num_shards);
         size_t s0 = lh_shard_offsets[shard], s1 = lh_shard_offsets[shard + 1];
@@ -568,12 +577,13 @@ struct Database {
             default: return -1;
         }
     }
-    // run_ac_matching_into_static (paraglob_offset.rs:1186-1266), case-sensitive only
+    // run_ac_matching_into_static (paraglob_offset.rs:1186-1266); case-insensitive: the text is ASCII-lower-cased (:1198-1206)
     void run_ac(const uint8_t* ac, size_t ac_len, const uint8_t* text, size_t tn, std::set<uint32_t>& out) const {
         if (ac_len == 0 || tn == 0) return;
         size_t cur = 0;
         for (size_t i = 0; i < tn; ++i) {
             uint8_t ch = text[i];
+            if (match_mode == 1 && ch >= 'A' && ch <= 'Z') ch = (uint8_t)(ch + 32);
             for (;;) {
                 long nx = ac_transition(ac, ac_len, cur, ch);
                 if (nx >= 0) { cur = (size_t)nx; break; }
@@ -622,7 +632,8 @@ struct Database {
         for (size_t k = 1; k < adv; ++k) cp = (cp << 6) | (s[k] & 0x3F);
         return cp;
     }
-    // match_segments_impl (paraglob_offset.rs:1402-1639), case-sensitive only
+    static uint32_t ascii_lower_char(uint32_t c) { return (c >= 'A' && c <= 'Z') ? c + 32 : c; }
+    // match_segments_impl (paraglob_offset.rs:1402-1639)
     bool match_segments(const uint8_t* text, size_t tn, size_t first_seg, size_t seg_count, size_t pos, size_t seg, size_t& steps) const {
         if (steps == 0) return false;
         --steps;
@@ -636,6 +647,22 @@ struct Database {
             case 0: {
                 if (doff + dlen > pg_len) return false;
                 if (!valid_utf8_local(pg + doff, dlen)) return false;  // Err(..) is treated as no match by callers
+                if (match_mode == 1) {
+                    // :1456-1478: literal and text are walked char by char with eq_ignore_ascii_case; the text advances by the
+                    // bytes of its own characters
+                    size_t lp = 0, tp = pos;
+                    bool ok = true;
+                    while (tp < tn) {
+                        if (lp >= dlen) break;
+                        size_t la, ta;
+                        uint32_t lc = utf8_decode(pg + doff + lp, dlen - lp, la), tc = utf8_decode(text + tp, tn - tp, ta);
+                        if (ascii_lower_char(lc) != ascii_lower_char(tc)) { ok = false; break; }
+                        lp += la; tp += ta;
+                    }
+                    if (ok && lp < dlen) ok = false;
+                    if (ok) return match_segments(text, tn, first_seg, seg_count, tp, seg + 1, steps);
+                    return false;
+                }
                 if (tn - pos >= dlen && memcmp(text + pos, pg + doff, dlen) == 0)
                     return match_segments(text, tn, first_seg, seg_count, pos + dlen, seg + 1, steps);
                 return false;
@@ -658,6 +685,7 @@ struct Database {
                 if (pos >= tn) return false;
                 size_t adv;
                 uint32_t ch = utf8_decode(text + pos, tn - pos, adv);
+                if (match_mode == 1) ch = ascii_lower_char(ch);   // :1552-1555
                 size_t items = dlen / 12;
                 if (doff + dlen > pg_len) return false;
                 bool negated = (fl & 1) != 0, in_class = false;
@@ -665,6 +693,7 @@ struct Database {
                     const uint8_t* it = pg + doff + k * 12;
                     uint32_t c1 = rd32le(it + 4), c2 = rd32le(it + 8);
                     auto is_char = [](uint32_t c) { return c < 0xD800 || (c > 0xDFFF && c <= 0x10FFFF); };
+                    if (match_mode == 1) { if (is_char(c1)) c1 = ascii_lower_char(c1); if (is_char(c2)) c2 = ascii_lower_char(c2); }   // :1584-1607
                     bool m = false;
                     if (it[0] == 0) m = is_char(c1) && ch == c1;
                     else if (it[0] == 1) m = is_char(c1) && is_char(c2) && ch >= c1 && ch <= c2;

@@ -177,7 +177,18 @@ extern "C" {
 int orc_init(const char* psl_path) {
     if (g.psl_ok) return 0;
     g.psl_ok = g.psl.load(psl_path);
+    // the Unicode lower-case table lies beside the suffix list (case-insensitive databases only)
+    std::string lp = psl_path;
+    const size_t k = lp.rfind('/');
+    lp = (k == std::string::npos ? std::string() : lp.substr(0, k + 1)) + "lowercase.bin";
+    try { Lowercase::table().load(lp.c_str()); } catch (const std::exception&) {}
     return g.psl_ok ? 0 : -1;
+}
+// Rust str::to_lowercase of valid UTF-8; returns the length of the result (call again with a larger buffer if > cap)
+size_t orc_to_lowercase(const uint8_t* s, size_t n, uint8_t* out, size_t cap) {
+    const std::string r = Lowercase::table().to_lowercase(std::string((const char*)s, n));
+    if (r.size() <= cap) memcpy(out, r.data(), r.size());
+    return r.size();
 }
 size_t orc_psl_count() { return g.psl.set.size(); }
 int orc_psl_contains(const char* s, size_t n) { return g.psl.contains((const uint8_t*)s, n) ? 1 : 0; }

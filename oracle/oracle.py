@@ -49,6 +49,8 @@ def lib():
             build()
         L = C.CDLL(str(LIB))
         L.orc_init.argtypes = [C.c_char_p]
+        L.orc_to_lowercase.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.orc_to_lowercase.restype = C.c_size_t
         L.orc_psl_count.restype = C.c_size_t
         L.orc_psl_contains.argtypes = [C.c_char_p, C.c_size_t]
         L.orc_xxh64.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
@@ -102,6 +104,14 @@ def format_ip(ip: bytes, v6: bool) -> str:
     buf = C.create_string_buffer(64)
     lib().orc_format_ip(1 if v6 else 0, bytes(ip), buf, 64)
     return buf.value.decode()
+
+
+def to_lowercase(text: str) -> str:
+    """Rust str::to_lowercase as restated in oracle/unicode_lower.h."""
+    b = text.encode("utf-8")
+    out = C.create_string_buffer(len(b) * 3 + 8)
+    n = lib().orc_to_lowercase(b, len(b), out, len(out))
+    return out.raw[:n].decode("utf-8")
 
 
 def extract(data: bytes, flags=EX_ALL, min_labels=2):

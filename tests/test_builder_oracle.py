@@ -256,3 +256,60 @@ def test_wider_tree_records_read_back_identically(oracle, monkeypatch, bits):
         assert a == b, q
         hits += a is not None and a.get("kind") == "ip"
     assert hits > 300
+
+
+def build_ci(entries, epoch=1700000000):
+    b = M.DatabaseBuilder(build_epoch=epoch, case_insensitive=True)
+    for k, v in entries:
+        b.add_entry(k, v)
+    blob = b.build()
+    b.close()
+    return blob
+
+
+def test_lowercase_table_matches_the_interpreter(oracle):
+    """matchy_amd/data/lowercase.bin through the oracle's restatement of Rust's str::to_lowercase (per-character mapping,
+    Final_Sigma rule) against Python's str.lower(), which implements the same Unicode default case conversion."""
+    for s in ["HELLO", "ÉCOLE.Example.COM", "İstanbul", "ǅ", "ẞ", "K", "ΣΑΣ", "ΑΣ", "Σ", "ΑΣ.Β", "ΑΣ́", "́Σ", "aΣb", "ὈΔΥΣΣΕΎΣ", "A.Σ", "Σ.A", "",
+              "mixed ÀÉÎÕÜ ΑΒΓ АБВ ԱԲԳ ᏣᎳᎩ \U00010400\U00010401 🌍"]:
+        assert oracle.to_lowercase(s) == s.lower(), s
+    bad = [cp for cp in range(0x80, 0x30000) if not 0xD800 <= cp <= 0xDFFF and oracle.to_lowercase(chr(cp) + "x") != (chr(cp) + "x").lower()]
+    assert not bad, [hex(c) for c in bad[:10]]
+
+
+def test_case_insensitive_reference_vectors(oracle):
+    """The reference's own case-insensitive vectors (matchy-paraglob/tests/integration_tests.rs:99-119,
+    paraglob_offset.rs:1928-1935, glob.rs:473-480, 641-648) through a database written with
+    matchy_builder_set_case_insensitive and read by the oracle."""
+    db = oracle.Database(build_ci([("Test*", {"p": 0}), ("glob:HELLO", {"p": 1})]))
+    assert db.metadata()["match_mode"] == 1
+    for q in ("Test123", "test123", "HELLO", "hello"):
+        assert db.lookup(q)["kind"] == "pattern", q
+    assert db.lookup("tes")["kind"] != "pattern"
+    db = oracle.Database(build_ci([("glob:Hello", {"p": 0}), ("*.TXT", {"p": 1})]))
+    r = db.lookup("hello test.txt")
+    assert r["kind"] == "pattern" and len(r["data"]) == 2
+    db = oracle.Database(build_ci([("glob:hello", {"p": 0}), ("abc[a-z]def", {"p": 1}), ("pre[!A-C]post", {"p": 2})]))
+    for q, found in [("hello", True), ("HELLO", True), ("HeLLo", True), ("abcadef", True), ("abcAdef", True), ("ABCZDEF", True), ("abc1def", False),
+                     ("predpost", True), ("preBpost", False), ("prebpost", False), ("PREDPOST", True)]:
+        assert (db.lookup(q)["kind"] == "pattern") == found, q
+    # literal keys: stored and queried through to_lowercase (matchy-literal-hash/src/lib.rs:158-167, 469-472)
+    db = oracle.Database(build_ci([("Evil.Example.COM", {"k": 1}), ("ÉCOLE.example", {"k": 2}), ("ΟΔΥΣΣΕΥΣ.example", {"k": 3})]))
+    for q, k in [("evil.example.com", 1), ("EVIL.EXAMPLE.COM", 1), ("école.example", 2), ("École.EXAMPLE", 2), ("οδυσσευσ.example", 3),
+                 ("ΟΔΥΣΣΕΥΣ.EXAMPLE", 3)]:
+        r = db.lookup(q)
+        assert r["kind"] == "pattern" and r["data"] == [{"k": k}], q
+    assert db.lookup("evil.example.org")["kind"] != "pattern"
+    # Final_Sigma looks through the case-ignorable '.': the capital sigma before ".example" is followed by a cased letter, so the
+    # key holds a medial sigma and the spelling with a final one is a different string
+    assert db.lookup("οδυσσευς.example")["kind"] != "pattern"
+    # globs: the AC literal is to_lowercase()d, the text only ASCII-lower-cased (matchy-ac/src/lib.rs:209,
+    # paraglob_offset.rs:1198-1206): a non-ASCII capital in the text does not reach the literal
+    db = oracle.Database(build_ci([("*.ÉCOLE.example", {"g": 1})]))
+    assert db.lookup("www.école.EXAMPLE")["kind"] != "pattern"      # literal segment "ÉCOLE" != "école" (ASCII folding only)
+    assert db.lookup("www.École.example")["kind"] != "pattern"      # AC: text keeps "É", the automaton holds "é"
+    db = oracle.Database(build_ci([("*.école.Example", {"g": 1})]))
+    assert db.lookup("WWW.école.EXAMPLE")["kind"] == "pattern"
+    # case-sensitive databases are untouched
+    db = oracle.Database(build([("Test*", {"p": 0})]))
+    assert db.metadata()["match_mode"] == 0 and db.lookup("test1")["kind"] != "pattern" and db.lookup("Test1")["kind"] == "pattern"
