@@ -1,7 +1,7 @@
 // `matchy` command line for the MI355X build: the two subcommands of the reference CLI that sit on the hot path
 // (crates/matchy/src/bin/matchy.rs:78-212):
 //
-//   matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-v]
+//   matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-i] [-v]
 //   matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N | --devices LIST|all]
 //   matchy query <DATABASE> <QUERY> [-q]                                  (bin/commands/query_cmd.rs)
 //   matchy extract <INPUT>... [--format json|csv|text] [--types LIST] [--min-labels N] [-u] [-s] [--show-candidates]
@@ -45,7 +45,7 @@ namespace {
 int usage() {
     fprintf(stderr,
             "usage:\n"
-            "  matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-v]\n"
+            "  matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-i] [-v]\n"
             "  matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N | --devices LIST|all]\n"
             "  matchy query <DATABASE> <QUERY> [-q]\n"
             "  matchy extract <INPUT>... [--format json|csv|text] [--types LIST] [--min-labels N] [-u] [-s] [--show-candidates]\n");
@@ -208,7 +208,7 @@ bool add_inputs(DatabaseBuilder& b, const std::vector<std::string>& inputs, cons
 int cmd_build(int argc, char** argv) {
     std::vector<std::string> inputs;
     std::string out, format = "text", dbtype, desc, lang = "en";
-    bool verbose = false;
+    bool verbose = false, case_insensitive = false;
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&](const char* name) -> const char* { if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", name); exit(2); } return argv[++i]; };
@@ -218,12 +218,12 @@ int cmd_build(int argc, char** argv) {
         else if (a == "-d" || a == "--description") desc = next("-d");
         else if (a == "--desc-lang") lang = next("--desc-lang");
         else if (a == "-v" || a == "--verbose" || a == "--debug") verbose = true;
-        else if (a == "-i" || a == "--case-insensitive") { fprintf(stderr, "Error: case-insensitive databases are not supported by this build\n"); return 1; }
+        else if (a == "-i" || a == "--case-insensitive") case_insensitive = true;
         else if (!a.empty() && a[0] == '-' && a != "-") { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
         else inputs.push_back(a);
     }
     if (inputs.empty() || out.empty()) return usage();
-    DatabaseBuilder b;
+    DatabaseBuilder b(case_insensitive);
     if (!dbtype.empty()) b.set_database_type(dbtype);
     if (!desc.empty()) b.set_description(lang, desc);
     if (const char* e = getenv("MATCHY_BUILD_EPOCH")) b.set_build_epoch(strtoull(e, nullptr, 10));  // reproducible builds

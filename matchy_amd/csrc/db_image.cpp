@@ -47,7 +47,6 @@ bool DbImage::open(std::vector<uint8_t>&& data, std::string& err) {
     has_ip = true;
     auto mm = metadata.map.find("match_mode");
     if (mm != metadata.map.end() && mm->second.type == DataValue::UINT16) match_mode = mm->second.u == 1 ? 1 : 0;
-    if (match_mode == 1) { err = "case-insensitive databases are not supported yet"; return false; }
 
     auto po = metadata.map.find("pattern_section_offset");
     auto lo = metadata.map.find("literal_section_offset");
@@ -64,7 +63,8 @@ bool DbImage::open(std::vector<uint8_t>&& data, std::string& err) {
         if (pg_off + pg_len > n || pg_len < 112) { err = "Paraglob section extends beyond file"; return false; }
         const uint8_t* pg = d + pg_off;
         if (memcmp(pg, "PARAGLOB", 8) != 0 || rd32(pg + 8) != 5) { err = "Unsupported paraglob header/version"; return false; }
-        if (rd32(pg + 12) != 0) { err = "case-insensitive paraglob sections are not supported yet"; return false; }
+        // the section's own match_mode field (offset 12) is not consulted: like the reference (database.rs:1297-1304,
+        // 1323-1361) the mode comes from the metadata
         pattern_count = rd32(pg + 32);
         uint32_t ac_start = rd32(pg + 20), ac_size = rd32(pg + 24), patterns_off = rd32(pg + 36), gso = rd32(pg + 104);
         if ((size_t)ac_start + ac_size > pg_len || (ac_start & 3)) { err = "AC section out of bounds"; return false; }

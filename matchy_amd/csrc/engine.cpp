@@ -1,4 +1,5 @@
 #include "engine.h"
+#include "unicode_lower.h"
 
 #include <dlfcn.h>
 
@@ -236,6 +237,11 @@ void DeviceDb::upload(const DbImage& img, int dev) {
             view.lit_bm = lit_bm.p; view.lit_bm_mask = bmask;
             bytes_uploaded += bm.size() * 4;
         }
+        // longest stored key: a query that is longer after lower-casing cannot match any literal
+        uint32_t max_len = 0;
+        for (const LitSlot& sl : slots)
+            if (sl.str_off != 0xFFFFFFFFu && (size_t)sl.str_off + 2 <= pv.size()) max_len = std::max<uint32_t>(max_len, (uint32_t)pv[sl.str_off] | ((uint32_t)pv[sl.str_off + 1] << 8));
+        view.lit_max_len = max_len;
         view.lit_slots = lit_slots.p; view.lit_mask = mask; view.has_literal = 1;
         view.lit_pool = lit_pool.p; view.lit_pool_size = img.lh_strings_size;
         bytes_uploaded += slots.size() * sizeof(LitSlot) + pv.size();
@@ -268,6 +274,9 @@ void DeviceDb::upload(const DbImage& img, int dev) {
             size_t limit = (size_t)8 << 30;
             if (const char* env = getenv("MATCHY_AMD_DFA_MAX_MB")) limit = (size_t)atoll(env) << 20;
             if (img.build_ac_dfa(nx, cls, k, noff, limit)) {
+                // case-insensitive: the automaton holds lower-cased literals and the text is ASCII-lower-cased while it is
+                // walked (paraglob_offset.rs:1198-1206) — here by giving 'A'..'Z' the classes of 'a'..'z'
+                if (img.match_mode == 1) for (int c = 'A'; c <= 'Z'; ++c) cls[c] = cls[c + 32];
                 dfa.upload(nx); dfa_node.upload(noff); dfa_cls.upload(cls);
                 view.dfa = dfa.p; view.dfa_node = dfa_node.p; view.dfa_cls = dfa_cls.p; view.dfa_k = k;
                 view.dfa_states = (uint32_t)noff.size();
@@ -275,6 +284,25 @@ void DeviceDb::upload(const DbImage& img, int dev) {
             }
         }
         bytes_uploaded += pv.size() + (off.size() + ids.size()) * 4;
+    }
+    view.ci = img.match_mode == 1 ? 1u : 0u;
+    if (view.ci) {
+        const LowerTable& lt = LowerTable::get();
+        std::vector<uint32_t> m;
+        m.reserve(lt.map.size() * 3);
+        for (const LowerMapEntry& e : lt.map) {
+            m.push_back(e.cp);
+            m.push_back((uint32_t)e.len | ((uint32_t)e.utf8[0] << 8) | ((uint32_t)e.utf8[1] << 16) | ((uint32_t)e.utf8[2] << 24));
+            m.push_back((uint32_t)e.utf8[3] | ((uint32_t)e.utf8[4] << 8) | ((uint32_t)e.utf8[5] << 16) | ((uint32_t)e.utf8[6] << 24));
+        }
+        std::vector<uint2> ri, rc;
+        for (const CpRange& r : lt.ignorable) ri.push_back(make_uint2(r.first, r.last));
+        for (const CpRange& r : lt.cased) rc.push_back(make_uint2(r.first, r.last));
+        lc_map.upload(m); lc_ign.upload(ri); lc_cased.upload(rc);
+        view.lc_map = lc_map.p; view.lc_n = (uint32_t)lt.map.size();
+        view.lc_ign = lc_ign.p; view.lc_n_ign = (uint32_t)ri.size();
+        view.lc_cased = lc_cased.p; view.lc_n_cased = (uint32_t)rc.size();
+        bytes_uploaded += m.size() * 4 + (ri.size() + rc.size()) * 8;
     }
     {
         // pattern id -> data offset tables for k_pack
@@ -474,6 +502,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     if (c.error & 1) throw HipError{"scan: a candidate matched more than MAX_GLOB_RESULTS glob patterns"};
     if (c.error & 2) throw HipError{"scan: a glob pattern nests more than MAX_GLOB_STARS '*' segments"};
     if (c.error & 4) throw HipError{"scan: a candidate is longer than 16 MiB (24-bit length field)"};
+    if (c.error & 8) throw HipError{"scan: a non-ASCII candidate longer than 256 bytes met a case-insensitive database whose literal keys are that long"};
     const double t_counters = since();
     if (trace)
         fprintf(stderr, "[matchy_amd] lines=%llu n_dom=%u n_rare=%u n_tok=%u n_heavy=%u n_cand=%u (true %u) n_hits=%u (true %u) n_ids=%u glob_work=%u final=%u\n",

@@ -71,6 +71,8 @@ struct DeviceDb {
     DevBuf<uint32_t> lit2pat_off, lit2pat, bloom;
     DevBuf<uint32_t> lit_offsets, glob_offsets;  // pattern id -> data-section offset (k_pack)
     DevBuf<PslSlot> psl_slots;
+    DevBuf<uint32_t> lc_map;
+    DevBuf<uint2> lc_ign, lc_cased;
     uint32_t n_lit_offsets = 0, n_glob_offsets = 0;
     size_t bytes_uploaded = 0;
     void upload(const DbImage& img, int dev);

@@ -56,13 +56,23 @@ MXY_HD uint64_t xxh64_fetch(Fetch f, size_t len, uint64_t seed) {
     return h;
 }
 
+// ASCII lower-casing of 8 packed bytes ('A'..'Z' get bit 5; bytes >= 0x80 and everything else stay)
+MXY_HD uint64_t ascii_lower8(uint64_t v) {
+    const uint64_t t = v & 0x7F7F7F7F7F7F7F7Full;
+    const uint64_t up = (t + 0x3F3F3F3F3F3F3F3Full) & ~(t + 0x2525252525252525ull) & ~v & 0x8080808080808080ull;   // 0x41 <= byte <= 0x5A
+    return v | (up >> 2);
+}
+MXY_HD uint32_t ascii_lower1(uint32_t c) { return (c - 'A' < 26u) ? c + 32 : c; }
+
 // XXH64 over contiguous memory: 8- and 4-byte lanes are read with one (unaligned) load each. Host and gfx950 are
-// little-endian, which is the byte order XXH64 specifies for its lanes.
+// little-endian, which is the byte order XXH64 specifies for its lanes. FOLD hashes the ASCII-lower-cased bytes instead
+// (literal queries of case-insensitive databases whose text is pure ASCII).
+template <bool FOLD = false>
 MXY_HD uint64_t xxh64(const uint8_t* p, size_t len, uint64_t seed) {
     const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL,
                    P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
-    auto rd64 = [&](size_t o) { uint64_t v; __builtin_memcpy(&v, p + o, 8); return v; };
-    auto rd32 = [&](size_t o) { uint32_t v; __builtin_memcpy(&v, p + o, 4); return (uint64_t)v; };
+    auto rd64 = [&](size_t o) { uint64_t v; __builtin_memcpy(&v, p + o, 8); return FOLD ? ascii_lower8(v) : v; };
+    auto rd32 = [&](size_t o) { uint32_t v; __builtin_memcpy(&v, p + o, 4); return FOLD ? (ascii_lower8((uint64_t)v) & 0xFFFFFFFFull) : (uint64_t)v; };
     auto round = [&](uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl64(acc, 31); return acc * P1; };
     auto merge = [&](uint64_t acc, uint64_t val) { val = round(0, val); acc ^= val; return acc * P1 + P4; };
     size_t q = 0;
@@ -82,7 +92,7 @@ MXY_HD uint64_t xxh64(const uint8_t* p, size_t len, uint64_t seed) {
     h += (uint64_t)len;
     while (q + 8 <= len) { h ^= round(0, rd64(q)); h = rotl64(h, 27) * P1 + P4; q += 8; }
     if (q + 4 <= len) { h ^= rd32(q) * P1; h = rotl64(h, 23) * P2 + P3; q += 4; }
-    while (q < len) { h ^= (uint64_t)p[q] * P5; h = rotl64(h, 11) * P1; ++q; }
+    while (q < len) { h ^= (uint64_t)(FOLD ? ascii_lower1(p[q]) : (uint32_t)p[q]) * P5; h = rotl64(h, 11) * P1; ++q; }
     h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
     return h;
 }

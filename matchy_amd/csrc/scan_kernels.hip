@@ -783,6 +783,10 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
                     for (int k = 0; k < 4; ++k)
                         ln[k] = (uint64_t)__builtin_amdgcn_alignbyte(wd[2 * k + 1], wd[2 * k], sh) |
                                 ((uint64_t)__builtin_amdgcn_alignbyte(wd[2 * k + 2], wd[2 * k + 1], sh) << 32);
+                    if (db.ci) {   // the keys were lower-cased when the table was built; names decided here are pure ASCII
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) ln[k] = ascii_lower8(ln[k]);
+                    }
                     const uint64_t h = xxh64_lanes31(ln[0], ln[1], ln[2], ln[3], n);
                     const uint32_t b = lit_bm_bit(h) & db.lit_bm_mask;
                     pend_word = db.lit_bm ? db.lit_bm[b >> 5] : 0u;
@@ -1002,9 +1006,99 @@ __device__ bool trie_v6(const DevDb& db, const uint16_t seg[8], uint32_t& data_o
     return false;
 }
 
-// LiteralHash::lookup (lh:467-525) over the re-hashed device table
-__device__ bool lit_lookup(const DevDb& db, const uint8_t* s, uint32_t n, uint32_t& pattern_id) {
-    uint64_t h = xxh64(s, n, 0);
+// ---- case-insensitive databases: Rust str::to_lowercase on the device (texts with non-ASCII characters only; pure ASCII is
+// folded inline). The character data comes from matchy_amd/data/lowercase.bin (DevDb::lc_*).
+constexpr uint32_t CI_LOWER_MAX = 256;   // bytes of a lower-cased non-ASCII text that can still be compared with a key (error bit 3 beyond)
+__device__ __forceinline__ uint32_t d_utf8_decode(const uint8_t* s, uint32_t& cp) {   // valid UTF-8 only
+    const uint32_t c = s[0];
+    if (c < 0x80) { cp = c; return 1; }
+    if (c < 0xE0) { cp = ((c & 0x1Fu) << 6) | (s[1] & 0x3Fu); return 2; }
+    if (c < 0xF0) { cp = ((c & 0x0Fu) << 12) | ((s[1] & 0x3Fu) << 6) | (s[2] & 0x3Fu); return 3; }
+    cp = ((c & 0x07u) << 18) | ((s[1] & 0x3Fu) << 12) | ((s[2] & 0x3Fu) << 6) | (s[3] & 0x3Fu);
+    return 4;
+}
+__device__ bool d_cp_in_ranges(const uint2* r, uint32_t n, uint32_t cp) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (r[mid].y < cp) lo = mid + 1; else hi = mid; }
+    return lo < n && r[lo].x <= cp;
+}
+// case_ignorable_then_cased (alloc/src/str.rs) over text[0, i) right to left / text[i, n) left to right
+__device__ bool d_cased_behind(const DevDb& db, const uint8_t* s, uint32_t i) {
+    while (i > 0) {
+        uint32_t j = i - 1;
+        while (j > 0 && (s[j] & 0xC0) == 0x80) --j;
+        uint32_t cp;
+        d_utf8_decode(s + j, cp);
+        if (!d_cp_in_ranges(db.lc_ign, db.lc_n_ign, cp)) return d_cp_in_ranges(db.lc_cased, db.lc_n_cased, cp);
+        i = j;
+    }
+    return false;
+}
+__device__ bool d_cased_ahead(const DevDb& db, const uint8_t* s, uint32_t i, uint32_t n) {
+    while (i < n) {
+        uint32_t cp;
+        const uint32_t a = d_utf8_decode(s + i, cp);
+        if (!d_cp_in_ranges(db.lc_ign, db.lc_n_ign, cp)) return d_cp_in_ranges(db.lc_cased, db.lc_n_cased, cp);
+        i += a;
+    }
+    return false;
+}
+// Lower-cases s[0, n) into out[0, CI_LOWER_MAX) and returns the length of the lower-cased text; bytes past CI_LOWER_MAX are
+// counted but not stored.
+__device__ uint32_t d_to_lowercase(const DevDb& db, const uint8_t* s, uint32_t n, uint8_t* out) {
+    uint32_t o = 0;
+    for (uint32_t i = 0; i < n;) {
+        uint32_t cp;
+        const uint32_t a = d_utf8_decode(s + i, cp);
+        uint32_t len = a, w0 = 0, w1 = 0;
+        bool mapped = false;
+        if (cp < 0x80) {
+            if (o < CI_LOWER_MAX) out[o] = (uint8_t)ascii_lower1(cp);
+            ++o;
+            i += a;
+            continue;
+        }
+        if (cp == 0x3A3) {   // capital sigma: final form iff preceded by a cased letter and not followed by one
+            const bool fin = d_cased_behind(db, s, i) && !d_cased_ahead(db, s, i + a, n);
+            len = 2; w0 = 0xCFu | ((fin ? 0x82u : 0x83u) << 8); mapped = true;
+        } else {
+            uint32_t lo = 0, hi = db.lc_n;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (db.lc_map[mid * 3] < cp) lo = mid + 1; else hi = mid; }
+            if (lo < db.lc_n && db.lc_map[lo * 3] == cp) {
+                const uint32_t e1 = db.lc_map[lo * 3 + 1];
+                len = e1 & 0xFF; w0 = e1 >> 8; w1 = db.lc_map[lo * 3 + 2]; mapped = true;
+            }
+        }
+        const uint64_t bytes = (uint64_t)w0 | ((uint64_t)w1 << 24);
+        for (uint32_t k = 0; k < len; ++k)
+            if (o + k < CI_LOWER_MAX) out[o + k] = mapped ? (uint8_t)(bytes >> (8 * k)) : s[i + k];
+        o += len;
+        i += a;
+    }
+    return o;
+}
+
+// LiteralHash::lookup (lh:467-525) over the re-hashed device table. Case-insensitive databases (lh:469-472): the query is
+// lower-cased first — pure-ASCII text inline while it is hashed and compared, anything else through d_to_lowercase.
+__device__ bool lit_lookup(const DevDb& db, const uint8_t* s0, uint32_t n0, uint32_t& pattern_id, uint32_t* err) {
+    const uint8_t* s = s0;
+    uint32_t n = n0;
+    bool fold = false;
+    uint8_t lowbuf[CI_LOWER_MAX];
+    if (db.ci) {
+        uint64_t hi = 0;
+        uint32_t k = 0;
+        for (; k + 8 <= n0; k += 8) { uint64_t x; __builtin_memcpy(&x, s0 + k, 8); hi |= x; }
+        for (; k < n0; ++k) hi |= s0[k];
+        if ((hi & 0x8080808080808080ull) == 0) fold = true;
+        else {
+            n = d_to_lowercase(db, s0, n0, lowbuf);
+            if (n > db.lit_max_len) return false;                      // longer than every key
+            if (n > CI_LOWER_MAX) { atomicOr(err, 8u); return false; }  // a database with keys this long and such a query
+            s = lowbuf;
+        }
+    }
+    const uint64_t h = fold ? xxh64<true>(s, n, 0) : xxh64<false>(s, n, 0);
     uint32_t slot = (uint32_t)(h ^ (h >> 32)) & db.lit_mask;
     for (;;) {
         LitSlot e = db.lit_slots[slot];
@@ -1020,9 +1114,9 @@ __device__ bool lit_lookup(const DevDb& db, const uint8_t* s, uint32_t n, uint32
                     uint64_t x, y;
                     __builtin_memcpy(&x, q + 2 + k, 8);
                     __builtin_memcpy(&y, s + k, 8);
-                    diff |= x ^ y;
+                    diff |= x ^ (fold ? ascii_lower8(y) : y);
                 }
-                for (; k < n; ++k) diff |= (uint64_t)(q[2 + k] ^ s[k]);
+                for (; k < n; ++k) diff |= (uint64_t)(q[2 + k] ^ (fold ? ascii_lower1(s[k]) : (uint32_t)s[k]));
                 if (diff == 0) { pattern_id = e.pattern_id; return true; }
             }
         }
@@ -1107,6 +1201,7 @@ __device__ __forceinline__ TextView text_stage(const uint8_t* log, uint32_t log_
 // same segment once per text position.
 __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView& text, uint32_t* err) {
     const uint8_t* pg = db.pg;
+    const bool ci = db.ci != 0;
     const uint32_t tn = text.n;
     uint32_t io = db.glob_seg_off + pattern_id * 8;
     if (io + 8 > db.pg_len) return false;
@@ -1136,6 +1231,9 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
                     if ((c_h0 & 0xFF) == 0 && c_doff + c_dlen <= db.pg_len) {
                         if (c_dlen >= 8) __builtin_memcpy(&c_lit8, pg + c_doff, 8);
                         else for (uint32_t k = 0; k < c_dlen; ++k) c_lit8 |= (uint64_t)pg[c_doff + k] << (8 * k);
+                        // case-insensitive (pg:1456-1478): characters compare with eq_ignore_ascii_case, which on UTF-8 bytes
+                        // is ASCII folding of both sides (the bytes of other characters are >= 0x80 and must be equal)
+                        if (ci) c_lit8 = ascii_lower8(c_lit8);
                     }
                 }
                 const uint32_t st = c_h0 & 0xFF, fl = (c_h0 >> 8) & 0xFF, dlen = c_dlen, doff = c_doff;
@@ -1143,14 +1241,16 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
                     bool ok = doff + dlen <= db.pg_len && tn - pos >= dlen;
                     if (ok && dlen) {
                         const uint64_t m0 = dlen >= 8 ? ~0ull : (1ull << (dlen * 8)) - 1;
-                        uint64_t diff = (text.load8(pos) ^ c_lit8) & m0;
+                        const uint64_t t0 = text.load8(pos);
+                        uint64_t diff = ((ci ? ascii_lower8(t0) : t0) ^ c_lit8) & m0;
                         if (diff == 0) {
                             for (uint32_t k = 8; k < dlen; k += 8) {   // no early exit: the loads are independent
                                 const uint32_t r = dlen - k;
                                 uint64_t x = 0;
                                 if (r >= 8) __builtin_memcpy(&x, pg + doff + k, 8);
                                 else for (uint32_t b = 0; b < r; ++b) x |= (uint64_t)pg[doff + k + b] << (8 * b);
-                                diff |= (text.load8(pos + k) ^ x) & (r >= 8 ? ~0ull : (1ull << (r * 8)) - 1);
+                                const uint64_t tk = text.load8(pos + k);
+                                diff |= ((ci ? ascii_lower8(tk) : tk) ^ (ci ? ascii_lower8(x) : x)) & (r >= 8 ? ~0ull : (1ull << (r * 8)) - 1);
                             }
                         }
                         ok = diff == 0;
@@ -1171,10 +1271,12 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
                         uint32_t c = text.at(pos), adv = utf8_adv(c);
                         uint32_t cp = adv == 1 ? c : adv == 2 ? (c & 0x1F) : adv == 3 ? (c & 0x0F) : (c & 0x07);
                         for (uint32_t k = 1; k < adv && pos + k < tn; ++k) cp = (cp << 6) | (text.at(pos + k) & 0x3F);
+                        if (ci) cp = ascii_lower1(cp);   // pg:1552-1555
                         bool in_class = false;
                         for (uint32_t k = 0; k < dlen / 12 && !in_class; ++k) {
                             const uint8_t* it = pg + doff + k * 12;
                             uint32_t ty = it[0], c1 = ld32(it + 4), c2 = ld32(it + 8);
+                            if (ci) { c1 = ascii_lower1(c1); c2 = ascii_lower1(c2); }   // pg:1584-1607 (values that are no chars fail is_rust_char either way)
                             if (ty == 0) in_class = is_rust_char(c1) && cp == c1;
                             else if (ty == 1) in_class = is_rust_char(c1) && is_rust_char(c2) && cp >= c1 && cp <= c2;
                         }
@@ -1269,6 +1371,7 @@ __device__ uint32_t glob_find_all(const DevDb& db, const DfaView& dv, const Text
             uint32_t cur = 0;
             for (uint32_t i = 0; i < tn; ++i) {
                 uint32_t ch = text.at(i);
+                if (db.ci) ch = ascii_lower1(ch);   // pg:1198-1206
                 for (;;) {
                     uint32_t nx = ac_transition(ac, db.ac_size, cur, ch);
                     if (nx != 0xFFFFFFFFu) { cur = nx; break; }
@@ -1352,7 +1455,7 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
                 if (!GLOB && p.ac_filter && ac_touches_output(db, dv, text, tl)) defer = true;
                 else {
                     uint32_t pid = 0xFFFFFFFFu;
-                    if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q)) pid = q; }
+                    if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q, &p.counters->error)) pid = q; }
                     if constexpr (GLOB) ng = glob_find_all(db, dv, text_stage(p.log, p.len, c.start, tl, twin + threadIdx.x * GLOB_WIN_WORDS), outq + threadIdx.x * GLOB_OUTQ, globs, &p.counters->error);
                     if (pid != 0xFFFFFFFFu || ng) { h.kind = 3; h.a = pid; h.n_globs = (uint16_t)ng; emit = true; }
                 }

@@ -68,6 +68,7 @@ struct DevDb {
     uint32_t lit_bm_mask;
     const uint8_t* lit_pool;  // LHSH string pool: {u16 len, bytes, NUL}
     uint32_t lit_pool_size;
+    uint32_t lit_max_len;     // longest key in the pool
     // paraglob buffer as stored on disk + a dense literal-id -> pattern-id list (from the ACLH table)
     const uint8_t* pg;
     uint32_t pg_len;
@@ -97,6 +98,15 @@ struct DevDb {
     // 4..6 | flags << 24 (0x80 occupied, 0x01 the label alone is a public suffix); slot = tld_tab_slot(x, y & 0xFFFFFF)
     const uint2* tld_tab;
     uint32_t tld_first[8];        // 256-bit set: bytes that start the last label of at least one suffix
+    // case-insensitive databases (metadata match_mode = 1): Unicode lower-case data for literal queries with non-ASCII
+    // characters (Rust str::to_lowercase: per-character mapping + the Final_Sigma rule); ASCII is folded inline
+    uint32_t ci;
+    const uint32_t* lc_map;       // lc_n entries of 3 words: code point, then len | utf8[0..2] << 8, then utf8[3..6]
+    uint32_t lc_n;
+    const uint2* lc_ign;          // Case_Ignorable ranges {first, last}, sorted
+    uint32_t lc_n_ign;
+    const uint2* lc_cased;        // Cased ranges
+    uint32_t lc_n_cased;
 };
 
 constexpr uint32_t DFA_LDS_ENTRIES = 8192;      // 32 KiB of transition rows per workgroup of k_lookup
@@ -114,7 +124,7 @@ struct ScanCounters {
     uint32_t n_dom;                  // domain anchors (first byte of a label that follows a dot)
     uint32_t n_hits;
     uint32_t n_ids;
-    uint32_t error;                  // bit0: glob result list overflow, bit1: glob star-stack overflow, bit2: candidate > 16 MiB
+    uint32_t error;                  // bit0: glob result list overflow, bit1: glob star-stack overflow, bit2: candidate > 16 MiB, bit3: lower-cased non-ASCII candidate > 256 B (case-insensitive DB)
     uint32_t cand_true;              // candidates really written (n_cand counts chunk-allocated slots incl. padding)
     uint32_t hits_true;
     uint32_t n_final;                // dense final hit records written by k_pack

@@ -82,14 +82,28 @@ def test_build_text_and_json(cli, tmp_path, oracle):
     assert db2.lookup("a.bad.net")["kind"] == "pattern"
 
 
+def test_build_case_insensitive(cli, tmp_path, oracle):
+    """cli_tests.rs:141-160 (`matchy build --case-insensitive`) + what the flag means for lookups."""
+    (tmp_path / "patterns.txt").write_text("*.EVIL.COM\nBad.Example.ORG\n")
+    out = tmp_path / "ci.mxy"
+    r = _run([cli, "build", str(tmp_path / "patterns.txt"), "-o", str(out), "--case-insensitive"])
+    assert r.returncode == 0 and out.exists(), r.stderr
+    db = oracle.Database(out.read_bytes())
+    assert db.metadata()["match_mode"] == 1
+    assert db.lookup("www.evil.com")["kind"] == "pattern" and db.lookup("WWW.Evil.Com")["kind"] == "pattern"
+    assert db.lookup("bad.example.org")["kind"] == "pattern" and db.lookup("BAD.EXAMPLE.ORG")["kind"] == "pattern"
+    out2 = tmp_path / "cs.mxy"
+    assert _run([cli, "build", str(tmp_path / "patterns.txt"), "-o", str(out2)]).returncode == 0
+    db2 = oracle.Database(out2.read_bytes())
+    assert db2.metadata()["match_mode"] == 0 and db2.lookup("www.evil.com")["kind"] != "pattern" and db2.lookup("www.EVIL.COM")["kind"] == "pattern"
+
+
 def test_build_errors(cli, tmp_path):
     (tmp_path / "bad.csv").write_text("a,b\n1,2\n")
     r = _run([cli, "build", str(tmp_path / "bad.csv"), "-o", str(tmp_path / "x.mxy"), "-f", "csv"])
     assert r.returncode != 0 and b"'entry' or 'key' column" in r.stderr
     r = _run([cli, "build", str(tmp_path / "missing.txt"), "-o", str(tmp_path / "x.mxy")])
     assert r.returncode != 0
-    r = _run([cli, "build", str(tmp_path / "bad.csv"), "-o", str(tmp_path / "x.mxy"), "-i"])
-    assert r.returncode != 0 and b"case-insensitive" in r.stderr
     assert _run([cli]).returncode == 2
     assert _run([cli, "build", str(tmp_path / "bad.csv")]).returncode == 2  # no -o
 
