@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--config", default="c2", help="indicator mix (tools/synth.py): c2 = 100K mixed IoCs")
     ap.add_argument("--cpu-lines", type=int, default=3_000_000, help="lines of the same log timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--case-insensitive", action="store_true", help="build the database with match_mode 1 (matchy build -i)")
     ap.add_argument("--pipelined", type=int, default=3, help="after the timed steps, time the same K steps again with this many batches in flight per GPU "
                     "(scanners on their own streams); reported as the extra object `pipelined`; 0 = skip")
     ap.add_argument("--extract-flags", type=int, default=0, help="diagnostics only: MATCHY_EXTRACT_* bit mask (0 = what the DB needs)")
@@ -58,7 +59,9 @@ def main():
     base_name = args.config.split("/")[0]
     cfg_index = {"c1": 0, "c2": 1, "c3": 2, "c3b": 2, "c4": 3, "c5": 4}[base_name]
     cfg_note = (" (AC-forced variant, glob: keys)" if base_name == "c3b" else "") + (f" (indicators scaled 1/{args.config.split('/')[1]})" if "/" in args.config else "")
-    blob = synth.build_db(cfg)
+    blob = synth.build_db(cfg, case_insensitive=args.case_insensitive)
+    if args.case_insensitive:
+        cfg_note += " (case-insensitive database)"
     db = M.Database(blob)
     scanner = M.Scanner(db, extract_flags=args.extract_flags, device=local_rank, profile=True)
 

@@ -109,10 +109,10 @@ def ioc_entries(cfg: Cfg):
             yield key, db.value
 
 
-def build_db(cfg: Cfg, epoch=1700000000) -> bytes:
+def build_db(cfg: Cfg, epoch=1700000000, case_insensitive=False) -> bytes:
     import matchy_amd as M
     ML = M.lib()
-    b = M.DatabaseBuilder(build_epoch=epoch)
+    b = M.DatabaseBuilder(build_epoch=epoch, case_insensitive=case_insensitive)
     # the whole feed runs in C++ (tools/synthgen.cpp calls matchy_builder_add directly: 10M entries for C5)
     fed = lib().synth_ioc_feed(C.byref(cfg), 1 if getattr(cfg, "glob_prefix", False) else 0,
                                C.cast(ML.matchy_builder_add, C.c_void_p), b._h)
