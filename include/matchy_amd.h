@@ -95,7 +95,7 @@ typedef struct matchy_matches_t {
 
 /* ---- builder (replaces c_api/matchy.rs:300-600; matchy.h:578-753) */
 matchy_builder_t *matchy_builder_new(void);                                            /* matchy.h:578 */
-int32_t matchy_builder_set_case_insensitive(matchy_builder_t *b, bool case_insensitive); /* matchy.h:605 (true is rejected at build: f2) */
+int32_t matchy_builder_set_case_insensitive(matchy_builder_t *b, bool case_insensitive); /* matchy.h:605 */
 int32_t matchy_builder_add(matchy_builder_t *b, const char *key, const char *json_data); /* matchy.h:670, c_api/matchy.rs:401-455 */
 int32_t matchy_builder_set_description(matchy_builder_t *b, const char *description);   /* matchy.h:687 */
 int32_t matchy_builder_save(matchy_builder_t *b, const char *filename);                 /* matchy.h:711 */
