@@ -62,7 +62,7 @@ ok = True
 last = t0
 while ok and time.time() - t0 < budget:
     rng = random.Random(seed)
-    kind = seed % 5
+    kind = seed % 6
     if kind == 0:
         ok = check_extract(tgp._long_domain_runs(seed, 150), f"long domains seed {seed}")
     elif kind == 1:
@@ -75,6 +75,17 @@ while ok and time.time() - t0 < budget:
     elif kind == 3:
         buf = tgp._mutated_log(seed, lines)
         ok = check_extract(buf, f"mutated log seed {seed}") and check_scan(buf, f"mutated log seed {seed}")
+    elif kind == 5:
+        entries, log, _ = tgp._ci_case(seed)
+        log = log + tgp._mutated_log(seed, log.split(b"\n"), 100)
+        b = M.DatabaseBuilder(build_epoch=7, case_insensitive=True)
+        for k, v in entries:
+            b.add_entry(k, v)
+        gh, gl, gs, wh, wl, ws = tgp._scan_both(M, oracle, b.build(), log)
+        b.close()
+        if not (gs == ws and gh == wh):
+            print(f"MISMATCH case-insensitive seed {seed}: {len(gh)} vs {len(wh)}", flush=True)
+            ok = False
     else:
         pats, log = tgp._glob_fuzz_case(seed)
         b = M.DatabaseBuilder(build_epoch=6)
