@@ -41,15 +41,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # BENCH_REHEARSE=1: rehearsal of the multi-rank path on a box with ONE GPU — every rank uses device 0 and the two
+    # collectives (barrier, reduction of the per-rank scalars) run over gloo on the CPU. The numbers of such a run mean nothing.
+    rehearse = os.environ.get("BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     os.environ["MATCHY_AMD_DEVICE"] = str(local_rank)
 
     import torch
     import torch.distributed as dist
 
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = torch.device("cpu") if rehearse else dev   # where the reduced scalars live
 
     import matchy_amd as M
     from matchy_amd import sharding
@@ -142,7 +151,7 @@ def main():
         tok_ms.append(t["anchor"]); look_ms.append(t["lookup"]); rare_ms.append(t["rare"]); val_ms.append(t["validate"])
     barrier()
     elapsed = time.perf_counter() - t0
-    agg = sharding.aggregate(dist, world, dev, elapsed, nbytes, counts[0], counts[2], counts[1])
+    agg = sharding.aggregate(dist, world, coll_dev, elapsed, nbytes, counts[0], counts[2], counts[1])
     elapsed = agg["elapsed_s"]
     total_bytes, total_lines = float(agg["bytes"]), float(agg["lines"])
 
@@ -164,7 +173,7 @@ def main():
         pcounts = drain()
         barrier()
         pel = time.perf_counter() - tp0
-        pagg = sharding.aggregate(dist, world, dev, pel, nbytes, pcounts[0], pcounts[2], pcounts[1])
+        pagg = sharding.aggregate(dist, world, coll_dev, pel, nbytes, pcounts[0], pcounts[2], pcounts[1])
         pipelined = {"batches_in_flight": len(scanners), "value": round(float(pagg["bytes"]) / (pagg["elapsed_s"] / args.steps) / 1e9, 3), "unit": "GB/s",
                      "ms_per_step": round(pagg["elapsed_s"] / args.steps * 1e3, 4), "steps": args.steps,
                      "same_counts": bool(tuple(pcounts) == tuple(counts))}
