@@ -177,6 +177,26 @@ def test_scan_wide_tree_records(M, oracle, monkeypatch, bits):
     assert len(gh) > 50
 
 
+@pytest.mark.parametrize("cfgname,lines", [("c1", 10000), ("c2", 1000), ("c3", 1000), ("c3b", 1000), ("c4", 1000), ("c5/100", 1000)])
+def test_scan_matches_committed_golden(M, cfgname, lines):
+    """GPU scan against the committed match sets of the BASELINE configs (tests/golden/config_*.ndjson)."""
+    import json
+    from pathlib import Path
+    from tools import synth
+    rows = (Path(__file__).parent / "golden" / f"config_{cfgname.replace('/', '_')}.ndjson").read_text().splitlines()
+    head, want = json.loads(rows[0]), rows[1:]
+    cfg = synth.config(cfgname)
+    db = M.Database(synth.build_db(cfg))
+    sc = M.Scanner(db)
+    text = synth.make_log(cfg, 0, lines)
+    res = sc.scan(text)
+    got = res.ndjson(text, source="access.log")
+    stats = (res.lines, res.candidates, len(got))
+    res.close(); sc.close(); db.close()
+    assert stats == (head["lines"], head["candidates"], head["matches"])
+    assert got == want
+
+
 def test_single_query_api(M, oracle):
     from tools import synth
     cfg = synth.config("c1")

@@ -73,3 +73,26 @@ def test_ipv6_display_and_parse(oracle):
     assert parse("1::2::3") is None
     assert parse("1:::2") is None
     assert parse("::") == "::"
+
+
+GOLDEN_CONFIGS = [("c1", 10000), ("c2", 1000), ("c3", 1000), ("c3b", 1000), ("c4", 1000), ("c5/100", 1000)]
+
+
+def _golden(cfgname):
+    import json
+    from pathlib import Path
+    p = Path(__file__).parent / "golden" / f"config_{cfgname.replace('/', '_')}.ndjson"
+    rows = p.read_text().splitlines()
+    return json.loads(rows[0]), rows[1:]
+
+
+@pytest.mark.parametrize("cfgname,lines", GOLDEN_CONFIGS)
+def test_oracle_reproduces_config_golden(oracle, cfgname, lines):
+    """tests/golden/config_*.ndjson (tests/golden/make_config_golden.py): the BASELINE configs' match sets — database built by
+    the product's builder, log from the counter-based generator, scan by the oracle — stay what they were when committed."""
+    from tools import synth
+    head, want = _golden(cfgname)
+    cfg = synth.config(cfgname)
+    hits, ndjson, st = oracle.Database(synth.build_db(cfg)).scan(synth.make_log(cfg, 0, lines), source="access.log")
+    assert (st.lines, st.candidates, len(ndjson)) == (head["lines"], head["candidates"], head["matches"])
+    assert ndjson == want
