@@ -11,8 +11,9 @@
 // match_processor/parallel.rs:297-369: sorted keys, timestamp "0.000") and, with -s, the [INFO] statistics block on
 // stderr (commands/match_cmd.rs:514-581). Every batch is scanned on the GPU through the C ABI (matchy_scanner_scan);
 // there is no CPU scan path. Flags that only tune the reference's CPU thread pool (-j, --readers, --cache-size, -p,
-// --debug-routing) are accepted and ignored; .gz inputs are decompressed on the host (zlib); -f/--follow is not supported.
+// --debug-routing) are accepted and ignored; .gz inputs are decompressed on the host (zlib); -f/--follow polls the files.
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -46,7 +47,7 @@ int usage() {
     fprintf(stderr,
             "usage:\n"
             "  matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-i] [-v]\n"
-            "  matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N | --devices LIST|all]\n"
+            "  matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N | --devices LIST|all] [-f]\n"
             "  matchy query <DATABASE> <QUERY> [-q]\n"
             "  matchy extract <INPUT>... [--format json|csv|text] [--types LIST] [--min-labels N] [-u] [-s] [--show-candidates]\n");
     return 2;
@@ -466,10 +467,87 @@ bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t
     return ok;
 }
 
+// -f / --follow (match_processor/follow.rs:20-264): after the existing content, keep watching the files and scan what is
+// appended — from the last known size to the new one, whatever it ends with, as the reference's `reader.lines()` does; a
+// file that shrank is read again from the start; a file that disappeared is reported once. Records carry the wall-clock
+// time of their batch as `timestamp` (the parallel path's constant "0.000" everywhere else). Ends on SIGINT / SIGTERM.
+volatile sig_atomic_t g_stop = 0;
+void on_stop(int) { g_stop = 1; }
+
+void follow_inputs(MatchPipeline& pl, matchy_scanner_t* sc, const std::vector<std::string>& paths, bool stats, Totals& total) {
+    struct Tail { std::string path; size_t input; off_t pos; bool gone; };
+    std::vector<Tail> tails;
+    for (size_t i = 0; i < paths.size(); ++i) {
+        struct stat sb;
+        tails.push_back({paths[i], i, stat(paths[i].c_str(), &sb) == 0 ? sb.st_size : 0, false});
+    }
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = on_stop;
+    sigaction(SIGINT, &sa, nullptr);
+    sigaction(SIGTERM, &sa, nullptr);
+    if (stats) fprintf(stderr, "[INFO] Watching for new content (Ctrl+C to stop)...\n");
+    while (!g_stop) {
+        bool any = false;
+        for (Tail& tl : tails) {
+            struct stat sb;
+            if (stat(tl.path.c_str(), &sb) != 0) {
+                if (!tl.gone && stats) fprintf(stderr, "[WARN] File deleted/rotated: %s\n", tl.path.c_str());
+                tl.gone = true;
+                continue;
+            }
+            tl.gone = false;
+            if (sb.st_size < tl.pos) tl.pos = 0;          // truncated: start over
+            if (sb.st_size == tl.pos) continue;
+            const int fd = open(tl.path.c_str(), O_RDONLY);
+            if (fd < 0) continue;
+            Batch b;
+            b.input = tl.input;
+            b.own = RawBuf((size_t)(sb.st_size - tl.pos) + 16);
+            size_t have = 0;
+            while (have < (size_t)(sb.st_size - tl.pos)) {
+                const ssize_t n = pread(fd, b.own.data() + have, (size_t)(sb.st_size - tl.pos) - have, tl.pos + (off_t)have);
+                if (n <= 0) break;
+                have += (size_t)n;
+            }
+            close(fd);
+            tl.pos += (off_t)have;
+            if (!have) continue;
+            any = true;
+            b.ptr = b.own.data(); b.len = have;
+            Done d;
+            pl.run_batch(sc, b, d);
+            if (!d.out.empty()) {
+                // this batch's records carry the current time
+                char ts[48];
+                struct timespec now;
+                clock_gettime(CLOCK_REALTIME, &now);
+                snprintf(ts, sizeof(ts), "\"timestamp\":\"%.3f\"}", (double)now.tv_sec + (double)now.tv_nsec * 1e-9);
+                static const std::string fixed = "\"timestamp\":\"0.000\"}";
+                std::string out;
+                size_t from = 0;
+                for (;;) {
+                    const size_t k = d.out.find(fixed + "\n", from);
+                    if (k == std::string::npos) { out.append(d.out, from, std::string::npos); break; }
+                    out.append(d.out, from, k - from);
+                    out += ts;
+                    from = k + fixed.size();
+                }
+                fwrite(out.data(), 1, out.size(), stdout);
+                fflush(stdout);
+            }
+            total.lines += d.t.lines; total.lines_with_matches += d.t.lines_with_matches; total.matches += d.t.matches;
+            total.candidates += d.t.candidates; total.bytes += d.t.bytes;
+        }
+        if (!any) usleep(100 * 1000);
+    }
+    if (stats) fprintf(stderr, "[INFO] Follow mode stopped\n");
+}
+
 int cmd_match(int argc, char** argv) {
     std::vector<std::string> pos;
     std::string format = "json", extractors, devices;
-    bool stats = false;
+    bool stats = false, follow = false;
     size_t batch_bytes = (size_t)256 << 20;  // GPU batches: large, so that one launch amortises PCIe latency
     int device = 0;
     if (const char* d = getenv("MATCHY_AMD_DEVICE")) device = atoi(d);
@@ -493,12 +571,14 @@ int cmd_match(int argc, char** argv) {
         else if (eqval("--threads", v) || eqval("--readers", v) || eqval("--cache-size", v)) {}
         else if (a == "-j") (void)next("-j");
         else if (a == "-p" || a == "--progress" || a == "--debug-routing") {}
-        else if (a == "-f" || a == "--follow") { fprintf(stderr, "Error: --follow is not supported by this build\n"); return 1; }
+        else if (a == "-f" || a == "--follow") follow = true;
         else if (a.size() > 1 && a[0] == '-') { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
         else pos.push_back(a);
     }
     if (pos.size() < 2) return usage();
     if (format != "json" && format != "summary") { fprintf(stderr, "Error: Unknown format: %s. Use 'json' or 'summary'\n", format.c_str()); return 1; }
+    if (follow && stats) fprintf(stderr, "[INFO] Processing existing file content...\n");
+    if (follow) for (size_t i = 1; i < pos.size(); ++i) if (pos[i] == "-") { fprintf(stderr, "Error: --follow mode not supported with stdin\n"); return 1; }
     // device list: one worker (scanner) per entry; an entry may repeat (two scanners on one GPU overlap one batch's
     // transfers with the other's kernels)
     std::vector<int> devs;
@@ -581,6 +661,7 @@ int cmd_match(int argc, char** argv) {
     printer.join();
     fflush(stdout);
     for (auto& mp : maps) munmap(mp.first, mp.second);
+    if (follow) follow_inputs(pl, scanners[0], paths, stats, t);
     size_t failed = 0;
     for (char f : input_failed) failed += f != 0;
     const size_t processed = paths.size() - failed;

@@ -272,3 +272,48 @@ def test_extract_subcommand(cli, tmp_path, oracle):
     assert _run([cli, "extract", str(p), "--format", "xml"]).returncode == 1
     assert _run([cli, "extract", str(p), "--types", "bogus"]).returncode == 1
     assert _run([cli, "extract", str(tmp_path / "missing.log")]).returncode == 1
+
+
+@pytest.mark.gpu
+def test_match_follow(cli, tmp_path, oracle):
+    """`matchy match -f` (match_processor/follow.rs): existing content first, then what is appended (also after a truncation),
+    records stamped with the wall clock, statistics on SIGINT."""
+    import signal
+    import time
+    from tools import synth
+    cfg, rows = _c1_csv(tmp_path / "c1.csv")
+    dbp = tmp_path / "c1.mxy"
+    assert _run([cli, "build", str(tmp_path / "c1.csv"), "-o", str(dbp), "-f", "csv"]).returncode == 0
+    odb = oracle.Database(dbp.read_bytes())
+    part = [synth.make_log(cfg, a, 2000) for a in (0, 2000, 4000)]
+    logp = tmp_path / "live.log"
+    logp.write_bytes(part[0])
+    assert _run([cli, "match", str(dbp), "-", "--follow"], input=b"").returncode == 1      # not with stdin
+    outp = tmp_path / "out.ndjson"
+    with open(outp, "wb") as out:
+        pr = subprocess.Popen([cli, "match", str(dbp), str(logp), "--follow", "-s"], stdout=out, stderr=subprocess.PIPE)
+        try:
+            def wait_lines(n, timeout=60):
+                t0 = time.time()
+                while time.time() - t0 < timeout:
+                    if len(outp.read_bytes().splitlines()) >= n:
+                        return True
+                    time.sleep(0.1)
+                return False
+            want = [odb.scan(p, source=str(logp))[1] for p in part]
+            assert wait_lines(len(want[0]))
+            with open(logp, "ab") as f:
+                f.write(part[1])
+            assert wait_lines(len(want[0]) + len(want[1]))
+            logp.write_bytes(part[2])                      # truncated and rewritten: read again from the start
+            assert wait_lines(len(want[0]) + len(want[1]) + len(want[2]))
+        finally:
+            pr.send_signal(signal.SIGINT)
+            err = pr.communicate(timeout=60)[1]
+    assert pr.returncode == 0, err
+    got = [json.loads(l) for l in outp.read_bytes().decode().splitlines()]
+    exp = [json.loads(l) for w in want for l in w]
+    assert [dict(g, timestamp="") for g in got] == [dict(e, timestamp="") for e in exp]
+    assert all(g["timestamp"] == "0.000" for g in got[:len(want[0])])
+    assert all(float(g["timestamp"]) > 1.6e9 for g in got[len(want[0]):])
+    assert b"Watching for new content" in err and b"Follow mode stopped" in err and b"[INFO] Lines processed: 6,000" in err
