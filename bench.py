@@ -33,8 +33,9 @@ def main():
     ap.add_argument("--cpu-lines", type=int, default=3_000_000, help="lines of the same log timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--case-insensitive", action="store_true", help="build the database with match_mode 1 (matchy build -i)")
-    ap.add_argument("--pipelined", type=int, default=3, help="after the timed steps, time the same K steps again with this many batches in flight per GPU "
-                    "(scanners on their own streams); reported as the extra object `pipelined`; 0 = skip")
+    ap.add_argument("--pipelined", type=int, default=0, help="N > 1: after the timed steps, time the same K steps again with N batches in flight per GPU "
+                    "(scanners on their own streams) and report it as the extra object `pipelined`. Off by default so that a profile "
+                    "of the default command shows every kernel running alone")
     ap.add_argument("--extract-flags", type=int, default=0, help="diagnostics only: MATCHY_EXTRACT_* bit mask (0 = what the DB needs)")
     args = ap.parse_args()
 
