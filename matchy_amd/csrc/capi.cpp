@@ -148,7 +148,7 @@ matchy_t* open_bytes(std::vector<uint8_t>&& bytes) {
 
 static_assert(sizeof(FinalHit) == sizeof(matchy_scan_hit_t) && sizeof(FinalHit) == 16 && offsetof(FinalHit, value) == offsetof(matchy_scan_hit_t, value) &&
                   offsetof(FinalHit, n_ids) == offsetof(matchy_scan_hit_t, n_ids) && offsetof(FinalHit, kind) == offsetof(matchy_scan_hit_t, kind),
-              "k_pack writes matchy_scan_hit_t records directly");
+              "pack_record writes matchy_scan_hit_t records directly");
 
 // Hand the dense records to the caller. borrowed=true: pointers go straight to the scanner's pinned buffers (no per-hit
 // host work at all); otherwise the arrays are copied into the result and optionally put into canonical order.

@@ -305,7 +305,7 @@ void DeviceDb::upload(const DbImage& img, int dev) {
         bytes_uploaded += m.size() * 4 + (ri.size() + rc.size()) * 8;
     }
     {
-        // pattern id -> data offset tables for k_pack
+        // pattern id -> data offset tables for pack_record
         std::vector<uint32_t> lo, go;
         if (img.has_literal) {
             if (!img.lit_data_offsets.empty()) lo = img.lit_data_offsets;
@@ -403,8 +403,8 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.heavy = heavy_.p; tp.heavy_cap = (uint32_t)heavy_.n;
     tp.dom_list = dom_list_.p; tp.dom_cap = (uint32_t)dom_slots_;
     tp.counters = counters_.p;
-    // workgroups per CU for k_anchor / k_validate / k_lookup / k_pack: what is resident at once (grid-stride kernels; a
-    // larger grid only adds a partially filled second round). MATCHY_AMD_GRID=a,v,l,p overrides for experiments.
+    // workgroups per CU for k_anchor / k_validate / k_lookup: what is resident at once (grid-stride kernels; a
+    // larger grid only adds a partially filled second round). MATCHY_AMD_GRID=a,v,l overrides for experiments.
     // k_anchor: two full rounds of resident workgroups; k_validate: one; k_lookup: 2 per CU measured best (every wave
     // pads its last hit chunk, and more waves in flight only add contention on the random table accesses).
     static const int occ_a = anchor_blocks_per_cu(), occ_v = validate_blocks_per_cu(false), occ_v_ac = validate_blocks_per_cu(true);
@@ -434,7 +434,6 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
             lp.glob_work = glob_work_.p; lp.glob_work_cap = (uint32_t)glob_work_.n;
         }
         lp.counters = counters_.p;
-        launch_lookup(lp, ddb_->view, n_cu_ * gm[2], stream);
         PackParams pp{};
         pp.hits = hits_.p; pp.hit_cap = (uint32_t)hits_.n; pp.ids = ids_.p; pp.ids_cap = (uint32_t)ids_.n;
         pp.lit_offsets = ddb_->lit_offsets.p; pp.n_lit = ddb_->n_lit_offsets;
@@ -453,7 +452,11 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
             mirror_used_ = true;
         }
         pp.counters = counters_.p;
-        launch_pack(pp, n_cu_ * gm[3], stream);
+        // k_lookup writes the final records itself (the PCIe writes of the mirror overlap the lookups); only the
+        // single-query path (lookup_one) reads the raw hit list
+        lp.direct = 1u;
+        lp.pk = pp;
+        launch_lookup(lp, ddb_->view, n_cu_ * gm[2], stream);
     }
     if (profile_) MXY_HIP(hipEventRecord(ev_[4], stream));
 }
@@ -477,7 +480,8 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
         MXY_HIP(hipStreamSynchronize(stream));
         const ScanCounters& c = host_counters_;
-        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_dom > dom_slots_;
+        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_dom > dom_slots_ ||
+                    c.n_final > final_.n || c.n_final_ids > final_ids_.n;
         if (!over) break;
         if (trace) fprintf(stderr, "[matchy_amd] work buffers overflow (attempt %d): regrow and rescan\n", attempt);
         if (single_) throw HipError{"lookup_one: work buffers overflow"};
@@ -493,8 +497,11 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         }
         if (c.n_hits > hits_.n || hits_.n < cands_.n / 4) hits_.alloc(std::max<size_t>((size_t)c.n_hits + c.n_hits / 4 + 1024, cands_.n / 4));
         if (c.n_ids > ids_.n) ids_.alloc((size_t)c.n_ids + c.n_ids / 4 + 1024);
-        if (final_.n < hits_.n) final_.alloc(hits_.n);
-        if (final_ids_.n < hits_.n + ids_.n) { final_ids_.alloc(hits_.n + ids_.n); final_offs_.alloc(hits_.n + ids_.n); }
+        if (final_.n < hits_.n || c.n_final > final_.n) final_.alloc(std::max<size_t>(hits_.n, (size_t)c.n_final + c.n_final / 4 + 1024));
+        if (final_ids_.n < hits_.n + ids_.n || c.n_final_ids > final_ids_.n) {
+            const size_t want = std::max<size_t>(hits_.n + ids_.n, (size_t)c.n_final_ids + c.n_final_ids / 4 + 1024);
+            final_ids_.alloc(want); final_offs_.alloc(want);
+        }
         scan_device(last_ptr_, last_len_, last_lookup_, stream, last_mirror_);
         if (attempt == 5) throw HipError{"scan: work buffers still overflow after regrowing"};
     }
@@ -530,7 +537,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         }
     }
     if (get_fin && !sorted && mirror_used_ && c.n_final <= mirror_cap_ && c.n_final_ids <= mirror_ids_cap_) {
-        // k_pack has already written the records into pinned host memory
+        // k_lookup (pack_record) has already written the records into pinned host memory
         uint8_t* mb = (uint8_t*)mirror_;
         out.fin = (const FinalHit*)mb; out.n_fin = c.n_final;
         out.fin_ids = (const uint32_t*)(mb + (size_t)mirror_cap_ * sizeof(FinalHit));

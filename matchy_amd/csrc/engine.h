@@ -19,7 +19,6 @@ void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t st
 void launch_validate(const TokParams& p, const DevDb& db, int grid, int n_cu, hipStream_t stream);
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_lookup(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream);
-void launch_pack(const PackParams& p, int grid, hipStream_t stream);
 
 struct HipError { std::string what; };
 #define MXY_HIP(expr)                                                                                   \
@@ -69,7 +68,7 @@ struct DeviceDb {
     DevBuf<LitSlot> lit_slots;
     DevBuf<uint8_t> lit_pool, pg, psl_pool;
     DevBuf<uint32_t> lit2pat_off, lit2pat, bloom;
-    DevBuf<uint32_t> lit_offsets, glob_offsets;  // pattern id -> data-section offset (k_pack)
+    DevBuf<uint32_t> lit_offsets, glob_offsets;  // pattern id -> data-section offset (pack_record)
     DevBuf<PslSlot> psl_slots;
     DevBuf<uint32_t> lc_map;
     DevBuf<uint2> lc_ign, lc_cased;
@@ -78,7 +77,7 @@ struct DeviceDb {
     void upload(const DbImage& img, int dev);
 };
 
-struct ScanTiming { float anchor_ms = 0, validate_ms = 0, rare_ms = 0, lookup_ms = 0, total_ms = 0; };  // lookup includes k_pack
+struct ScanTiming { float anchor_ms = 0, validate_ms = 0, rare_ms = 0, lookup_ms = 0, total_ms = 0; };  // lookup includes the record packing
 
 enum HitMode { HITS_NONE = 0, HITS_FINAL = 1, HITS_RAW = 2 };
 
@@ -86,7 +85,7 @@ struct ScanOutput {
     std::vector<Candidate> cands;  // filled only when requested
     std::vector<Hit> hits;         // HITS_RAW (single-query path)
     std::vector<uint32_t> ids;
-    // HITS_FINAL: dense records produced by k_pack, BORROWED from the scanner's pinned buffers
+    // HITS_FINAL: dense records produced by pack_record, BORROWED from the scanner's pinned buffers
     // (valid until the next scan on that scanner)
     const FinalHit* fin = nullptr;
     const uint32_t* fin_ids = nullptr;
@@ -104,7 +103,7 @@ public:
     ~Scanner();
     // Scan `len` bytes already resident in device memory (16-byte aligned). len < 2^31.
     // lookup=false stops after extraction. Results stay on the device until fetch().
-    // host_mirror: k_pack also writes the final records into pinned host memory (unsorted fetches then need no copy)
+    // host_mirror: pack_record also writes the final records into pinned host memory (unsorted fetches then need no copy)
     void scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror = false);
     // Copies counters (and hits / candidates) back. Call after scan_device; synchronises the stream.
     // sorted: the final records are put into canonical order on the GPU (sort_hits.hip) before they are copied back
@@ -142,7 +141,7 @@ private:
     DevBuf<FinalHit> final_sorted_;
     DevBuf<ScanCounters> counters_;
     DevBuf<uint8_t> staging_;  // scan_host only
-    // pinned mirror of the final records written by k_pack itself: FinalHit[mirror_cap_] | u32 ids[mirror_ids_cap_] | i64 offs[..]
+    // pinned mirror of the final records written by the lookup kernels themselves: FinalHit[mirror_cap_] | u32 ids[mirror_ids_cap_] | i64 offs[..]
     void* mirror_ = nullptr;
     uint32_t mirror_cap_ = 0, mirror_ids_cap_ = 0;
     bool mirror_used_ = false, last_mirror_ = false;

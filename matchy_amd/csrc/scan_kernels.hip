@@ -9,7 +9,7 @@
 //               EIP-55, Monero) — one lane per prefiltered token.
 //   k_lookup    stage B: one lane per candidate: MMDB trie walk / XXH64 literal probe / Aho-Corasick DFA + glob
 //               verification, hits compacted through wave-private chunks.
-//   k_pack      dense matchy_scan_hit_t records + pattern-id -> data-offset resolution.
+//   (pack_record, called from k_lookup: dense matchy_scan_hit_t records + pattern-id -> data-offset resolution)
 //
 // Semantics follow the reference CPU path; every rule cites the reference function it reproduces
 // (matchy-extractor/src/lib.rs = "ext", matchy-format/src/mmdb/tree.rs = "tree", matchy-literal-hash/src/lib.rs
@@ -1406,6 +1406,69 @@ __device__ __forceinline__ bool ac_touches_output(const DevDb& db, const DfaView
     return (any >> 31) != 0;
 }
 
+// One lane's hit -> dense FinalHit record (+ its pattern ids and data offsets), device copy and pinned host mirror: the body of
+// k_pack, also called straight from k_lookup for bulk scans (LookupParams::direct), where it overlaps the PCIe writes of
+// the records with the lookups instead of running as a kernel of its own afterwards. Wave-uniform call; `valid` marks the
+// lanes that hold a hit. Glob ids come from `globs` (k_lookup's own result list) or, when that is null, from pp.ids.
+// Pattern results follow Database::lookup_string_uncached (database.rs:911-981): the literal id counts only if it has a data
+// mapping, then the glob ids in ascending order; a literal without mapping and no glob is NotFound.
+__device__ __forceinline__ void pack_record(const PackParams& pp, bool valid, const Hit& h, const uint32_t* globs) {
+    const uint32_t lane = lane_id();
+    uint32_t nid = 0, lit_off = 0xFFFFFFFFu;
+    if (valid && h.kind == 3) {
+        if (h.a != 0xFFFFFFFFu && h.a < pp.n_lit) lit_off = pp.lit_offsets[h.a];
+        nid = (lit_off != 0xFFFFFFFFu ? 1u : 0u) + h.n_globs;
+        if (nid == 0) valid = false;
+    }
+    // dense slot for the record: one atomic per wave
+    const uint64_t vm = __ballot(valid);
+    if (vm == 0) return;
+    uint32_t slot0 = 0;
+    if (lane == 0) slot0 = atomicAdd(&pp.counters->n_final, (uint32_t)__popcll(vm));
+    slot0 = __builtin_amdgcn_readfirstlane(slot0);
+    const uint32_t slot = slot0 + (uint32_t)__popcll(vm & lanemask_lt());
+    // side-array space for pattern ids: wave exclusive scan of nid, one atomic per wave
+    uint32_t scan = valid ? nid : 0u;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)scan, off);
+        if ((int)lane >= off) scan += t;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)scan, 63);
+    uint32_t ids0 = 0;
+    if (total) {
+        if (lane == 0) ids0 = atomicAdd(&pp.counters->n_final_ids, total);
+        ids0 = __builtin_amdgcn_readfirstlane(ids0);
+    }
+    if (valid) {
+        const uint32_t my_ids = ids0 + scan - nid;
+        FinalHit f{};
+        f.start = h.start;
+        f.len_type = h.len_type;
+        f.kind = h.kind;
+        f.prefix_len = h.prefix_len;
+        if (h.kind == 2) f.value = h.a;
+        else {
+            f.n_ids = (uint16_t)nid;
+            f.value = my_ids;
+            uint32_t w = my_ids;
+            if (lit_off != 0xFFFFFFFFu) {
+                if (w < pp.out_ids_cap) { pp.out_ids[w] = h.a; pp.out_offs[w] = (long long)lit_off; }
+                if (w < pp.host_ids_cap) { pp.host_ids[w] = h.a; pp.host_offs[w] = (long long)lit_off; }
+                ++w;
+            }
+            for (uint32_t k = 0; k < h.n_globs; ++k, ++w) {
+                const uint32_t pid = globs ? globs[k] : ((h.ids_off + k < pp.ids_cap) ? pp.ids[h.ids_off + k] : 0u);
+                const long long go = pid < pp.n_glob ? (long long)pp.glob_offsets[pid] : -1ll;
+                if (w < pp.out_ids_cap) { pp.out_ids[w] = pid; pp.out_offs[w] = go; }
+                if (w < pp.host_ids_cap) { pp.host_ids[w] = pid; pp.host_offs[w] = go; }
+            }
+        }
+        if (slot < pp.out_cap) pp.out[slot] = f;
+        if (slot < pp.host_cap) pp.host_out[slot] = f;
+    }
+}
+
 // GLOB=false carries no glob state and stays register-lean: databases without a PARAGLOB section, and the first pass of
 // the two-pass lookup (p.ac_filter): IP and literal lookups plus one DFA walk per string candidate; candidates that
 // touch an AC output state are deferred to the GLOB=true pass through p.glob_work. GLOB=true does the full
@@ -1461,12 +1524,17 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
                 }
             }
         }
-        if (GLOB && emit && ng) {
-            uint32_t io = atomicAdd(&p.counters->n_ids, ng);
-            h.ids_off = io;
-            for (uint32_t k = 0; k < ng; ++k) if (io + k < p.ids_cap) p.ids[io + k] = globs[k];
+        if (p.direct) {
+            // bulk scans: the record goes out right here (device copy + pinned host mirror), no hit list, no k_pack
+            pack_record(p.pk, emit, h, GLOB ? globs : nullptr);
+        } else {
+            if (GLOB && emit && ng) {
+                uint32_t io = atomicAdd(&p.counters->n_ids, ng);
+                h.ids_off = io;
+                for (uint32_t k = 0; k < ng; ++k) if (io + k < p.ids_cap) p.ids[io + k] = globs[k];
+            }
+            cw.append(emit, h, p.hits, p.hit_cap, &p.counters->n_hits, SH);
         }
-        cw.append(emit, h, p.hits, p.hit_cap, &p.counters->n_hits, SH);
         if (!GLOB && p.ac_filter) ww.append(defer, i, p.glob_work, p.glob_work_cap, &p.counters->n_glob_work, 0xFFFFFFFFu);
     }
     cw.pad_rest(p.hits, p.hit_cap, SH);
@@ -1474,80 +1542,7 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->hits_true, cw.total);
 }
 
-// k_pack — compacts the chunk-allocated hit list into dense FinalHit records (the layout the C ABI hands out) and
-// resolves pattern ids to data offsets, so the host does no per-hit work. Pattern results follow
-// Database::lookup_string_uncached (database.rs:911-981): the literal id counts only if it has a data mapping, then
-// the glob ids in ascending order; a literal without mapping and no glob is NotFound.
-__global__ __launch_bounds__(256) void k_pack(PackParams p) {
-    const uint32_t n = min(p.counters->n_hits, p.hit_cap);
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t lane = lane_id();
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
-        const uint32_t i = base + threadIdx.x;
-        Hit h{};
-        h.kind = 0xFF;
-        if (i < n) h = p.hits[i];
-        bool valid = h.kind != 0xFF;
-        uint32_t nid = 0, lit_off = 0xFFFFFFFFu;
-        if (valid && h.kind == 3) {
-            if (h.a != 0xFFFFFFFFu && h.a < p.n_lit) lit_off = p.lit_offsets[h.a];
-            nid = (lit_off != 0xFFFFFFFFu ? 1u : 0u) + h.n_globs;
-            if (nid == 0) valid = false;
-        }
-        // dense slot for the record: one atomic per wave
-        const uint64_t vm = __ballot(valid);
-        if (vm == 0) continue;
-        uint32_t slot0 = 0;
-        if (lane == 0) slot0 = atomicAdd(&p.counters->n_final, (uint32_t)__popcll(vm));
-        slot0 = __builtin_amdgcn_readfirstlane(slot0);
-        const uint32_t slot = slot0 + (uint32_t)__popcll(vm & lanemask_lt());
-        // side-array space for pattern ids: wave exclusive scan of nid, one atomic per wave
-        uint32_t scan = valid ? nid : 0u;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)scan, off);
-            if ((int)lane >= off) scan += t;
-        }
-        const uint32_t total = (uint32_t)__shfl((int)scan, 63);
-        uint32_t ids0 = 0;
-        if (total) {
-            if (lane == 0) ids0 = atomicAdd(&p.counters->n_final_ids, total);
-            ids0 = __builtin_amdgcn_readfirstlane(ids0);
-        }
-        if (valid) {
-            const uint32_t my_ids = ids0 + scan - nid;
-            FinalHit f{};
-            f.start = h.start;
-            f.len_type = h.len_type;
-            f.kind = h.kind;
-            f.prefix_len = h.prefix_len;
-            if (h.kind == 2) f.value = h.a;
-            else {
-                f.n_ids = (uint16_t)nid;
-                f.value = my_ids;
-                uint32_t w = my_ids;
-                if (lit_off != 0xFFFFFFFFu) {
-                    if (w < p.out_ids_cap) { p.out_ids[w] = h.a; p.out_offs[w] = (long long)lit_off; }
-                    if (w < p.host_ids_cap) { p.host_ids[w] = h.a; p.host_offs[w] = (long long)lit_off; }
-                    ++w;
-                }
-                for (uint32_t k = 0; k < h.n_globs; ++k, ++w) {
-                    const uint32_t pid = (h.ids_off + k < p.ids_cap) ? p.ids[h.ids_off + k] : 0u;
-                    const long long go = pid < p.n_glob ? (long long)p.glob_offsets[pid] : -1ll;
-                    if (w < p.out_ids_cap) { p.out_ids[w] = pid; p.out_offs[w] = go; }
-                    if (w < p.host_ids_cap) { p.host_ids[w] = pid; p.host_offs[w] = go; }
-                }
-            }
-            if (slot < p.out_cap) p.out[slot] = f;
-            if (slot < p.host_cap) p.host_out[slot] = f;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ launch wrappers
-void launch_pack(const PackParams& p, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, stream, p);
-}
 int validate_blocks_per_cu(bool ac) {
     int n = 0;
     const hipError_t e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate_dom<true>, 256, 0)

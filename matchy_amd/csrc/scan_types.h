@@ -127,7 +127,7 @@ struct ScanCounters {
     uint32_t error;                  // bit0: glob result list overflow, bit1: glob star-stack overflow, bit2: candidate > 16 MiB, bit3: lower-cased non-ASCII candidate > 256 B (case-insensitive DB)
     uint32_t cand_true;              // candidates really written (n_cand counts chunk-allocated slots incl. padding)
     uint32_t hits_true;
-    uint32_t n_final;                // dense final hit records written by k_pack
+    uint32_t n_final;                // dense final hit records written by pack_record
     uint32_t n_final_ids;            // entries of the pattern-id / data-offset side arrays
     uint32_t n_heavy;                // tokens that need a checksum validator (Base58Check, Bech32, EIP-55, Monero)
     uint32_t n_glob_work;            // candidates whose text reaches an output state of the AC automaton (glob work list)
@@ -160,23 +160,6 @@ struct TokParams {
     ScanCounters* counters;
 };
 
-struct LookupParams {
-    const uint8_t* log;
-    uint32_t len;
-    const Candidate* cands;
-    uint32_t cand_cap;
-    Hit* hits;
-    uint32_t hit_cap;
-    uint32_t* ids;
-    uint32_t ids_cap;
-    // two-pass glob lookup: the lean pass (ac_filter = 1) lists the candidates that touch an AC output state in
-    // glob_work; the glob pass (from_work = 1) handles exactly those. Both 0: one pass over all candidates.
-    uint32_t* glob_work;
-    uint32_t glob_work_cap;
-    uint32_t ac_filter, from_work;
-    ScanCounters* counters;
-};
-
 // Final hit record, bit-identical to matchy_scan_hit_t in include/matchy_amd.h (checked by static_assert in capi.cpp).
 struct FinalHit {
     uint32_t start;
@@ -186,7 +169,7 @@ struct FinalHit {
     uint16_t n_ids;
 };
 
-// k_pack: compacts the chunked hit list into dense FinalHit records and resolves pattern ids to data offsets.
+// pack_record (called from k_lookup): dense FinalHit records, pattern ids resolved to data offsets.
 struct PackParams {
     const Hit* hits;
     uint32_t hit_cap;
@@ -210,6 +193,28 @@ struct PackParams {
     uint32_t host_ids_cap;
     ScanCounters* counters;
 };
+
+struct LookupParams {
+    const uint8_t* log;
+    uint32_t len;
+    const Candidate* cands;
+    uint32_t cand_cap;
+    Hit* hits;
+    uint32_t hit_cap;
+    uint32_t* ids;
+    uint32_t ids_cap;
+    // two-pass glob lookup: the lean pass (ac_filter = 1) lists the candidates that touch an AC output state in
+    // glob_work; the glob pass (from_work = 1) handles exactly those. Both 0: one pass over all candidates.
+    uint32_t* glob_work;
+    uint32_t glob_work_cap;
+    uint32_t ac_filter, from_work;
+    // bulk scans: direct = 1 -> every hit is written as its final record at once (pack_record) instead of going through
+    // the hit list and k_pack
+    uint32_t direct;
+    PackParams pk;
+    ScanCounters* counters;
+};
+
 
 // Output lists are filled through wave-private chunks (one atomic per chunk, not per append); unused slots of a
 // chunk hold a sentinel (anchor 0xFFFFFFFF, Candidate.len_type 0xFFFFFFFF, RareAnchor kind 0xFF, Hit.kind 0xFF).
