@@ -182,7 +182,7 @@ def main():
     # every kernel of the pass (each launch covers the whole batch). `roofline` is the DOMINANT (slowest) kernel,
     # timed live with HIP events on the launch stream; `roofline_pipeline` prices the sum of all kernels of one pass.
     kern = {"k_anchor": sum(tok_ms) / len(tok_ms), "k_validate_dom+k_validate": sum(val_ms) / len(val_ms),
-            "k_rare": sum(rare_ms) / len(rare_ms), "k_lookup+k_pack": sum(look_ms) / len(look_ms)}
+            "k_rare": sum(rare_ms) / len(rare_ms), "k_lookup": sum(look_ms) / len(look_ms)}
     dom_name = max(kern, key=kern.get)
     achieved = nbytes / (kern[dom_name] * 1e-3) / 1e9
     pipe_ms = sum(kern.values())
@@ -193,7 +193,7 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/prof.sh; FETCH_SIZE x2 on gfx950)
         tj = json.load(open(ROOT / "profiles" / "r01_traffic.json"))
         if tj.get("bytes_per_gpu") == nbytes:
-            key = {"k_anchor": "mxy::k_anchor", "k_validate_dom+k_validate": "mxy::k_validate_dom<false>", "k_rare": "mxy::k_rare", "k_lookup+k_pack": "mxy::k_lookup<false>"}[dom_name]
+            key = {"k_anchor": "mxy::k_anchor", "k_validate_dom+k_validate": "mxy::k_validate_dom<false>", "k_rare": "mxy::k_rare", "k_lookup": "mxy::k_lookup<false>"}[dom_name]
             traffic = tj["kernels"][key]["hbm_bytes"]
             tr_note = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
     except Exception:
