@@ -6,6 +6,7 @@
 //   matchy query <DATABASE> <QUERY> [-q]                                  (bin/commands/query_cmd.rs)
 //   matchy extract <INPUT>... [--format json|csv|text] [--types LIST] [--min-labels N] [-u] [-s] [--show-candidates]
 //                                                                          (bin/commands/extract_cmd.rs)
+//   matchy inspect <DATABASE> [-j] [-v]          matchy validate <DATABASE> [-l standard|strict] [-j]      (host only)
 //
 // `match` prints one JSON object per match on stdout (same records as the reference's parallel path,
 // match_processor/parallel.rs:297-369: sorted keys, timestamp "0.000") and, with -s, the [INFO] statistics block on
@@ -30,7 +31,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fstream>
+#include <iterator>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -38,6 +41,7 @@
 #include "../../include/matchy_amd.h"
 #include "data_codec.h"
 #include "db_builder.h"
+#include "db_image.h"
 
 using namespace mxy;
 
@@ -49,7 +53,9 @@ int usage() {
             "  matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-i] [-v]\n"
             "  matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N | --devices LIST|all] [-f]\n"
             "  matchy query <DATABASE> <QUERY> [-q]\n"
-            "  matchy extract <INPUT>... [--format json|csv|text] [--types LIST] [--min-labels N] [-u] [-s] [--show-candidates]\n");
+            "  matchy extract <INPUT>... [--format json|csv|text] [--types LIST] [--min-labels N] [-u] [-s] [--show-candidates]\n"
+            "  matchy inspect <DATABASE> [-j] [-v]\n"
+            "  matchy validate <DATABASE> [-l standard|strict] [-j]\n");
     return 2;
 }
 
@@ -949,6 +955,143 @@ int cmd_extract(int argc, char** argv) {
     return 0;
 }
 
+// matchy inspect (bin/commands/inspect_cmd.rs:10-119): what the file holds, from its metadata; no GPU involved
+bool meta_uint_of(const DataValue& m, const char* key, unsigned long long& out) {
+    if (m.type != DataValue::MAP) return false;
+    auto it = m.map.find(key);
+    if (it == m.map.end()) return false;
+    const DataValue& v = it->second;
+    if (v.type == DataValue::UINT16 || v.type == DataValue::UINT32 || v.type == DataValue::UINT64) { out = v.u; return true; }
+    return false;
+}
+std::string fmt_unix_time(unsigned long long ts) {   // bin/cli_utils.rs:255-283
+    time_t t = (time_t)ts;
+    struct tm g;
+    gmtime_r(&t, &g);
+    char b[64];
+    snprintf(b, sizeof(b), "%04d-%02d-%02d %02d:%02d:%02d UTC", g.tm_year + 1900, g.tm_mon + 1, g.tm_mday, g.tm_hour, g.tm_min, g.tm_sec);
+    return b;
+}
+std::string fmt_data_value(const DataValue& v, const std::string& indent) {   // bin/cli_utils.rs:322-364
+    std::string o;
+    switch (v.type) {
+        case DataValue::STRING: return "\"" + v.str + "\"";
+        case DataValue::MAP:
+            if (v.map.empty()) return "{}";
+            o = "{\n";
+            for (auto& kv : v.map) o += indent + "  " + kv.first + ": " + fmt_data_value(kv.second, indent + "  ") + ",\n";
+            return o + indent + "}";
+        case DataValue::ARRAY:
+            if (v.arr.empty()) return "[]";
+            o = "[";
+            for (size_t i = 0; i < v.arr.size(); ++i) { if (i) o += ", "; o += fmt_data_value(v.arr[i], indent); }
+            return o + "]";
+        default: { std::string j; to_json(v, j); return j; }
+    }
+}
+int cmd_inspect(int argc, char** argv) {
+    std::vector<std::string> pos;
+    bool json = false, verbose = false;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-j" || a == "--json") json = true;
+        else if (a == "-v" || a == "--verbose") verbose = true;
+        else if (a.size() > 1 && a[0] == '-') { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
+        else pos.push_back(a);
+    }
+    if (pos.size() != 1) return usage();
+    std::vector<uint8_t> bytes;
+    {
+        std::ifstream f(pos[0], std::ios::binary);
+        if (!f) { fprintf(stderr, "Error: Failed to load database: %s\n", pos[0].c_str()); return 1; }
+        bytes.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    }
+    DbImage img;
+    std::string err;
+    if (!img.open(std::move(bytes), err)) { fprintf(stderr, "Error: Failed to load database: %s: %s\n", pos[0].c_str(), err.c_str()); return 1; }
+    // counts as Database::ip_count / literal_count / glob_count report them (database.rs:1147-1210): metadata first
+    unsigned long long ipc = 0, litc = 0, globc = 0;
+    if (!meta_uint_of(img.metadata, "ip_entry_count", ipc)) (void)meta_uint_of(img.metadata, "node_count", ipc);
+    (void)meta_uint_of(img.metadata, "literal_entry_count", litc);
+    if (!meta_uint_of(img.metadata, "glob_entry_count", globc)) globc = img.pattern_count;
+    const bool has_string = img.has_literal || img.has_glob;
+    if (json) {
+        std::string o = "{\"file\":";
+        auto esc = [&](const std::string& x) { std::string q; to_json(DataValue::String(x), q); return q; };
+        o += esc(pos[0]) + ",\"format\":" + esc(img.format_name());
+        o += std::string(",\"glob_count\":") + std::to_string(globc) + ",\"has_glob_data\":" + (img.has_glob ? "true" : "false");
+        o += std::string(",\"has_ip_data\":") + (img.has_ip ? "true" : "false") + ",\"has_literal_data\":" + (img.has_literal ? "true" : "false");
+        o += std::string(",\"has_string_data\":") + (has_string ? "true" : "false") + ",\"ip_count\":" + std::to_string(ipc) + ",\"literal_count\":" + std::to_string(litc);
+        if (img.metadata.type == DataValue::MAP) { o += ",\"metadata\":"; to_json(img.metadata, o); }
+        o += "}";
+        printf("%s\n", json_pretty(o).c_str());
+        return 0;
+    }
+    printf("Database: %s\n", pos[0].c_str());
+    printf("Format:   %s\n\n", ipc > 0 && (litc > 0 || globc > 0) ? "Combined IP+String database" : ipc > 0 ? "IP database" : (litc > 0 || globc > 0) ? "String database" : "Empty database");
+    printf("Capabilities:\n");
+    if (ipc > 0) printf("  IP lookups:      \xE2\x9C\x93\n    Entries:       %llu\n", ipc);
+    else printf("  IP lookups:      \xE2\x9C\x97\n");
+    printf("  String lookups:  %s\n", has_string ? "\xE2\x9C\x93" : "\xE2\x9C\x97");
+    if (img.has_literal) printf("    Literals:      \xE2\x9C\x93 (%llu strings)\n", litc);
+    if (img.has_glob) printf("    Globs:         \xE2\x9C\x93 (%llu patterns)\n", globc);
+    if (img.metadata.type == DataValue::MAP) {
+        printf("\nMetadata:\n");
+        auto it = img.metadata.map.find("database_type");
+        if (it != img.metadata.map.end() && it->second.type == DataValue::STRING) printf("  Database type:   %s\n", it->second.str.c_str());
+        it = img.metadata.map.find("description");
+        if (it != img.metadata.map.end() && it->second.type == DataValue::MAP) {
+            printf("  Description:\n");
+            for (auto& kv : it->second.map) if (kv.second.type == DataValue::STRING) printf("    %s: %s\n", kv.first.c_str(), kv.second.str.c_str());
+        }
+        unsigned long long v;
+        if (meta_uint_of(img.metadata, "build_epoch", v)) printf("  Build time:      %s (%llu)\n", fmt_unix_time(v).c_str(), v);
+        if (meta_uint_of(img.metadata, "ip_version", v)) printf("  IP version:      IPv%llu\n", v);
+        if (verbose) printf("\nFull metadata:\n%s\n", fmt_data_value(img.metadata, "  ").c_str());
+    }
+    return 0;
+}
+
+// matchy validate (bin/commands/validate_cmd.rs): the structural checks of matchy_validate (= what opening the file checks:
+// section bounds, headers, metadata); exit status 0 = valid. The reference's detailed statistics block is not reproduced.
+int cmd_validate(int argc, char** argv) {
+    std::vector<std::string> pos;
+    std::string level = "strict";
+    bool json = false;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-j" || a == "--json") json = true;
+        else if (a == "-v" || a == "--verbose") {}
+        else if (a == "-l" || a == "--level") { if (i + 1 >= argc) return usage(); level = argv[++i]; }
+        else if (a.compare(0, 8, "--level=") == 0) level = a.substr(8);
+        else if (a.size() > 1 && a[0] == '-') { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
+        else pos.push_back(a);
+    }
+    if (pos.size() != 1) return usage();
+    for (char& ch : level) ch = (char)tolower((unsigned char)ch);
+    if (level != "standard" && level != "strict") { fprintf(stderr, "Error: Invalid validation level: '%s'. Must be: standard or strict\n", level.c_str()); return 1; }
+    char* msg = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int32_t rc = matchy_validate(pos[0].c_str(), level == "strict" ? MATCHY_VALIDATION_STRICT : MATCHY_VALIDATION_STANDARD, &msg);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const bool valid = rc == MATCHY_SUCCESS;
+    if (json) {
+        std::string o = "{\"database\":";
+        std::string q;
+        to_json(DataValue::String(pos[0]), q);
+        o += q + ",\"duration_ms\":" + std::to_string((long long)ms) + ",\"errors\":[";
+        if (!valid) { q.clear(); to_json(DataValue::String(msg ? msg : "validation failed"), q); o += q; }
+        o += std::string("],\"is_valid\":") + (valid ? "true" : "false") + ",\"validation_level\":\"" + level + "\"}";
+        printf("%s\n", json_pretty(o).c_str());
+    } else {
+        printf("Validating: %s\nLevel:      %s\n\n", pos[0].c_str(), level.c_str());
+        if (!valid) printf("\xE2\x9D\x8C ERRORS (1):\n  \xE2\x80\xA2 %s\n\n", msg ? msg : "validation failed");
+        printf("%s\n", valid ? "\xE2\x9C\x85 VALIDATION PASSED" : "\xE2\x9D\x8C VALIDATION FAILED");
+    }
+    if (msg) matchy_free_string(msg);
+    return valid ? 0 : 1;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -958,6 +1101,8 @@ int main(int argc, char** argv) {
     if (cmd == "match") return cmd_match(argc - 2, argv + 2);
     if (cmd == "query") return cmd_query(argc - 2, argv + 2);
     if (cmd == "extract") return cmd_extract(argc - 2, argv + 2);
+    if (cmd == "inspect") return cmd_inspect(argc - 2, argv + 2);
+    if (cmd == "validate") return cmd_validate(argc - 2, argv + 2);
     if (cmd == "--version" || cmd == "-V" || cmd == "version") { printf("matchy %s (MI355X build)\n", matchy_version()); return 0; }
     return usage();
 }

@@ -317,3 +317,32 @@ def test_match_follow(cli, tmp_path, oracle):
     assert all(g["timestamp"] == "0.000" for g in got[:len(want[0])])
     assert all(float(g["timestamp"]) > 1.6e9 for g in got[len(want[0]):])
     assert b"Watching for new content" in err and b"Follow mode stopped" in err and b"[INFO] Lines processed: 6,000" in err
+
+
+def test_inspect_and_validate(cli, tmp_path):
+    """`matchy inspect` (inspect_cmd.rs; cli_tests.rs:163-205 ask for "Database:" and "Capabilities:") and `matchy validate`
+    (exit status) — host-only subcommands."""
+    (tmp_path / "p.txt").write_text("192.168.1.0/24\n*.evil.com\nbad.example.org\n")
+    dbp = tmp_path / "t.mxy"
+    r = _run([cli, "build", str(tmp_path / "p.txt"), "-o", str(dbp), "-d", "demo feed", "-t", "Threats"], env=dict(os.environ, MATCHY_BUILD_EPOCH="1700000000"))
+    assert r.returncode == 0, r.stderr
+    out = _run([cli, "inspect", str(dbp)]).stdout.decode()
+    assert f"Database: {dbp}" in out and "Format:   Combined IP+String database" in out and "Capabilities:" in out
+    assert "    Entries:       1" in out and "Literals:      ✓ (1 strings)" in out and "Globs:         ✓ (1 patterns)" in out
+    assert "Database type:   Threats" in out and "    en: demo feed" in out and "Build time:      2023-11-14 22:13:20 UTC (1700000000)" in out
+    assert "IP version:      IPv4" in out
+    assert "Full metadata:" in _run([cli, "inspect", str(dbp), "-v"]).stdout.decode()
+    js = json.loads(_run([cli, "inspect", str(dbp), "--json"]).stdout)
+    assert js["file"] == str(dbp) and js["has_ip_data"] and js["has_glob_data"] and js["has_string_data"]
+    assert (js["ip_count"], js["literal_count"], js["glob_count"]) == (1, 1, 1) and js["metadata"]["database_type"] == "Threats"
+    assert _run([cli, "inspect", str(tmp_path / "missing.mxy")]).returncode == 1
+    v = _run([cli, "validate", str(dbp)])
+    assert v.returncode == 0 and b"VALIDATION PASSED" in v.stdout
+    vj = json.loads(_run([cli, "validate", str(dbp), "--json", "--level", "standard"]).stdout)
+    assert vj["is_valid"] is True and vj["errors"] == [] and vj["validation_level"] == "standard"
+    bad = tmp_path / "bad.mxy"
+    bad.write_bytes(dbp.read_bytes()[:200])
+    vb = _run([cli, "validate", str(bad)])
+    assert vb.returncode == 1 and b"VALIDATION FAILED" in vb.stdout
+    assert json.loads(_run([cli, "validate", str(bad), "-j"]).stdout)["is_valid"] is False
+    assert _run([cli, "validate", str(dbp), "--level", "paranoid"]).returncode == 1
