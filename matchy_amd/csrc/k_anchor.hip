@@ -32,7 +32,6 @@ namespace mxy {
 
 constexpr int AW = 4;                   // waves per workgroup
 constexpr uint32_t BLK_BYTES = 1024;    // bytes per wave iteration
-constexpr uint32_t CS_PREFIX = 16;      // class bytes kept in front of the block (the last 4 are used)
 constexpr uint32_t QCAP = 128;          // ring entries per wave and type
 constexpr uint32_t RAW_BYTES = 4096;    // raw-byte window per wave (circular, block granular)
 constexpr uint32_t RAW_DW = RAW_BYTES / 4;
