@@ -39,7 +39,7 @@ bool read_file(const std::string& path, std::vector<uint8_t>& out) {
     return true;
 }
 
-uint32_t tld_hash(const uint8_t* s, size_t n) {  // must match tld_hash_step/tld_hash_bit in scan_kernels.hip
+uint32_t tld_hash(const uint8_t* s, size_t n) {  // must match tld_hash_step/tld_hash_bit in device_common.h
     uint32_t h = 2166136261u;
     for (size_t i = 0; i < n; ++i) h = (h ^ s[i]) * 16777619u;
     return (h ^ (h >> 15)) & (TLD_BLOOM_BITS - 1);

@@ -125,7 +125,7 @@ __device__ __forceinline__ void drain_v4(uint32_t* ring, uint32_t& head, uint32_
 }
 
 // Prefilter up to 64 domain anchors (first byte of the last label), one per lane; survivors go to the domain list.
-// Mirrors the first steps of val_domain (scan_kernels.hip): a '.' inside the label means a later dot owns the run, the
+// Mirrors the first steps of val_domain (validate_kernels.hip): a '.' inside the label means a later dot owns the run, the
 // run must end at a boundary, and the label must be the last label of some public suffix. Undecidable cases (label
 // longer than 8 bytes, bytes not resident) are kept.
 __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32_t& tail, uint32_t n, bool final, const WaveCtx& cx,

@@ -1,0 +1,618 @@
+// HIP kernels of stage B of the `matchy match` hot path on gfx950 (MI355X, wave64): the database lookups.
+//
+//   k_lookup    one lane per candidate: MMDB trie walk / XXH64 literal probe / Aho-Corasick DFA + glob verification;
+//               every hit leaves at once as its final matchy_scan_hit_t record (pack_record: device copy + pinned host
+//               mirror, pattern ids resolved to data offsets).
+//
+// Semantics follow the reference CPU path; every rule cites the reference function it reproduces
+// (matchy-format/src/mmdb/tree.rs = "tree", matchy-literal-hash/src/lib.rs = "lh",
+// matchy-paraglob/src/paraglob_offset.rs = "pg").
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "hashes.h"
+#include "scan_types.h"
+
+#include "device_shared.h"
+
+namespace mxy {
+
+// ------------------------------------------------------------------------------------------------ stage B: lookups
+// SearchTree::lookup_v4 / lookup_v6 (tree:46-125). Returns record (> node_count) or 0 for "not found".
+__device__ bool trie_v4(const DevDb& db, uint32_t addr, uint32_t& data_off, uint32_t& prefix) {
+    // levels 0..15 come from the first-level table (DeviceDb::upload), the rest is the reference's walk
+    const uint2 e = db.ip_l1[addr >> 16];
+    const uint32_t kind = e.x & 0xFF;
+    if (kind == 1) return false;
+    if (kind == 2) { data_off = e.y; prefix = e.x >> 8; return true; }
+    uint32_t node = e.y;
+    for (int bi = 16; bi < 32; ++bi) {
+        uint2 nd = db.ip_nodes[node];
+        uint32_t rec = ((addr >> (31 - bi)) & 1) ? nd.y : nd.x;
+        if (rec == db.node_count) return false;
+        if (rec < db.node_count) node = rec;
+        else {
+            uint32_t off = rec - db.node_count;
+            if (off < 16) return false;  // reference: MmdbError -> lookup error; treated as not found (never produced by builders)
+            data_off = off - 16;
+            prefix = (uint32_t)bi + 1;  // tree:76-80: depth counts from 96 in v6 trees and 96 is subtracted again
+            return true;
+        }
+    }
+    return false;
+}
+__device__ bool trie_v6(const DevDb& db, const uint16_t seg[8], uint32_t& data_off, uint32_t& prefix) {
+    uint32_t node = 0;
+    for (int bi = 0; bi < 128; ++bi) {
+        uint2 nd = db.ip_nodes[node];
+        uint32_t bit = (seg[bi >> 4] >> (15 - (bi & 15))) & 1;
+        uint32_t rec = bit ? nd.y : nd.x;
+        if (rec == db.node_count) return false;
+        if (rec < db.node_count) node = rec;
+        else {
+            uint32_t off = rec - db.node_count;
+            if (off < 16) return false;
+            data_off = off - 16;
+            prefix = (uint32_t)bi + 1;
+            return true;
+        }
+    }
+    return false;
+}
+
+// ---- case-insensitive databases: Rust str::to_lowercase on the device (texts with non-ASCII characters only; pure ASCII is
+// folded inline). The character data comes from matchy_amd/data/lowercase.bin (DevDb::lc_*).
+constexpr uint32_t CI_LOWER_MAX = 256;   // bytes of a lower-cased non-ASCII text that can still be compared with a key (error bit 3 beyond)
+__device__ __forceinline__ uint32_t d_utf8_decode(const uint8_t* s, uint32_t& cp) {   // valid UTF-8 only
+    const uint32_t c = s[0];
+    if (c < 0x80) { cp = c; return 1; }
+    if (c < 0xE0) { cp = ((c & 0x1Fu) << 6) | (s[1] & 0x3Fu); return 2; }
+    if (c < 0xF0) { cp = ((c & 0x0Fu) << 12) | ((s[1] & 0x3Fu) << 6) | (s[2] & 0x3Fu); return 3; }
+    cp = ((c & 0x07u) << 18) | ((s[1] & 0x3Fu) << 12) | ((s[2] & 0x3Fu) << 6) | (s[3] & 0x3Fu);
+    return 4;
+}
+__device__ bool d_cp_in_ranges(const uint2* r, uint32_t n, uint32_t cp) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (r[mid].y < cp) lo = mid + 1; else hi = mid; }
+    return lo < n && r[lo].x <= cp;
+}
+// case_ignorable_then_cased (alloc/src/str.rs) over text[0, i) right to left / text[i, n) left to right
+__device__ bool d_cased_behind(const DevDb& db, const uint8_t* s, uint32_t i) {
+    while (i > 0) {
+        uint32_t j = i - 1;
+        while (j > 0 && (s[j] & 0xC0) == 0x80) --j;
+        uint32_t cp;
+        d_utf8_decode(s + j, cp);
+        if (!d_cp_in_ranges(db.lc_ign, db.lc_n_ign, cp)) return d_cp_in_ranges(db.lc_cased, db.lc_n_cased, cp);
+        i = j;
+    }
+    return false;
+}
+__device__ bool d_cased_ahead(const DevDb& db, const uint8_t* s, uint32_t i, uint32_t n) {
+    while (i < n) {
+        uint32_t cp;
+        const uint32_t a = d_utf8_decode(s + i, cp);
+        if (!d_cp_in_ranges(db.lc_ign, db.lc_n_ign, cp)) return d_cp_in_ranges(db.lc_cased, db.lc_n_cased, cp);
+        i += a;
+    }
+    return false;
+}
+// Lower-cases s[0, n) into out[0, CI_LOWER_MAX) and returns the length of the lower-cased text; bytes past CI_LOWER_MAX are
+// counted but not stored.
+__device__ uint32_t d_to_lowercase(const DevDb& db, const uint8_t* s, uint32_t n, uint8_t* out) {
+    uint32_t o = 0;
+    for (uint32_t i = 0; i < n;) {
+        uint32_t cp;
+        const uint32_t a = d_utf8_decode(s + i, cp);
+        uint32_t len = a, w0 = 0, w1 = 0;
+        bool mapped = false;
+        if (cp < 0x80) {
+            if (o < CI_LOWER_MAX) out[o] = (uint8_t)ascii_lower1(cp);
+            ++o;
+            i += a;
+            continue;
+        }
+        if (cp == 0x3A3) {   // capital sigma: final form iff preceded by a cased letter and not followed by one
+            const bool fin = d_cased_behind(db, s, i) && !d_cased_ahead(db, s, i + a, n);
+            len = 2; w0 = 0xCFu | ((fin ? 0x82u : 0x83u) << 8); mapped = true;
+        } else {
+            uint32_t lo = 0, hi = db.lc_n;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (db.lc_map[mid * 3] < cp) lo = mid + 1; else hi = mid; }
+            if (lo < db.lc_n && db.lc_map[lo * 3] == cp) {
+                const uint32_t e1 = db.lc_map[lo * 3 + 1];
+                len = e1 & 0xFF; w0 = e1 >> 8; w1 = db.lc_map[lo * 3 + 2]; mapped = true;
+            }
+        }
+        const uint64_t bytes = (uint64_t)w0 | ((uint64_t)w1 << 24);
+        for (uint32_t k = 0; k < len; ++k)
+            if (o + k < CI_LOWER_MAX) out[o + k] = mapped ? (uint8_t)(bytes >> (8 * k)) : s[i + k];
+        o += len;
+        i += a;
+    }
+    return o;
+}
+
+// LiteralHash::lookup (lh:467-525) over the re-hashed device table. Case-insensitive databases (lh:469-472): the query is
+// lower-cased first — pure-ASCII text inline while it is hashed and compared, anything else through d_to_lowercase.
+__device__ bool lit_lookup(const DevDb& db, const uint8_t* s0, uint32_t n0, uint32_t& pattern_id, uint32_t* err) {
+    const uint8_t* s = s0;
+    uint32_t n = n0;
+    bool fold = false;
+    uint8_t lowbuf[CI_LOWER_MAX];
+    if (db.ci) {
+        uint64_t hi = 0;
+        uint32_t k = 0;
+        for (; k + 8 <= n0; k += 8) { uint64_t x; __builtin_memcpy(&x, s0 + k, 8); hi |= x; }
+        for (; k < n0; ++k) hi |= s0[k];
+        if ((hi & 0x8080808080808080ull) == 0) fold = true;
+        else {
+            n = d_to_lowercase(db, s0, n0, lowbuf);
+            if (n > db.lit_max_len) return false;                      // longer than every key
+            if (n > CI_LOWER_MAX) { atomicOr(err, 8u); return false; }  // a database with keys this long and such a query
+            s = lowbuf;
+        }
+    }
+    const uint64_t h = fold ? xxh64<true>(s, n, 0) : xxh64<false>(s, n, 0);
+    uint32_t slot = (uint32_t)(h ^ (h >> 32)) & db.lit_mask;
+    for (;;) {
+        LitSlot e = db.lit_slots[slot];
+        if (e.str_off == 0xFFFFFFFFu) return false;
+        if (e.hash == h) {
+            const uint8_t* q = db.lit_pool + e.str_off;
+            uint32_t sl = (uint32_t)q[0] | ((uint32_t)q[1] << 8);
+            if (sl == n) {
+                // 8 bytes per step, no early exit: the loads are independent of each other
+                uint64_t diff = 0;
+                uint32_t k = 0;
+                for (; k + 8 <= n; k += 8) {
+                    uint64_t x, y;
+                    __builtin_memcpy(&x, q + 2 + k, 8);
+                    __builtin_memcpy(&y, s + k, 8);
+                    diff |= x ^ (fold ? ascii_lower8(y) : y);
+                }
+                for (; k < n; ++k) diff |= (uint64_t)(q[2 + k] ^ (fold ? ascii_lower1(s[k]) : (uint32_t)s[k]));
+                if (diff == 0) { pattern_id = e.pattern_id; return true; }
+            }
+        }
+        slot = (slot + 1) & db.lit_mask;
+    }
+}
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+
+// find_ac_transition (pg:1271-1353): returns target node offset or 0xFFFFFFFF
+__device__ uint32_t ac_transition(const uint8_t* ac, uint32_t ac_len, uint32_t node_off, uint32_t ch) {
+    if (node_off + 20 > ac_len) return 0xFFFFFFFFu;
+    uint32_t w0 = ld32(ac + node_off);
+    uint32_t kind = w0 & 0xFF;
+    if (kind == 1) return ((w0 >> 8) & 0xFF) == ch ? ld32(ac + node_off + 12) : 0xFFFFFFFFu;
+    if (kind == 2) {
+        uint32_t eo = ld32(ac + node_off + 12), cnt = (w0 >> 16) & 0xFF;
+        if (eo + cnt * 8 > ac_len) return 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            uint32_t ec = ac[eo + i * 8];
+            if (ec == ch) return ld32(ac + eo + i * 8 + 4);
+            if (ec > ch) return 0xFFFFFFFFu;
+        }
+        return 0xFFFFFFFFu;
+    }
+    if (kind == 3) {
+        uint32_t t = ld32(ac + node_off + 12) + ch * 4;
+        if (t + 4 > ac_len) return 0xFFFFFFFFu;
+        uint32_t target = ld32(ac + t);
+        return target != 0 ? target : 0xFFFFFFFFu;
+    }
+    return 0xFFFFFFFFu;
+}
+
+__device__ __forceinline__ uint32_t utf8_adv(uint32_t c) { return c < 0x80 ? 1 : c < 0xE0 ? 2 : c < 0xF0 ? 3 : 4; }
+__device__ __forceinline__ bool is_rust_char(uint32_t c) { return c < 0xD800 || (c > 0xDFFF && c <= 0x10FFFF); }
+
+// Candidate text as the glob pass reads it: the first GLOB_WIN bytes sit in a per-lane LDS window (the star loop of a
+// `*literal` pattern probes the text once per position; from the log each probe would be a dependent global load), the
+// rest comes from the log.
+constexpr uint32_t GLOB_WIN = 64, GLOB_WIN_WORDS = GLOB_WIN / 8 + 1;
+constexpr uint32_t GLOB_OUTQ = 8;   // output states queued per text before they are handled (LDS, per lane)
+struct TextView {
+    const uint8_t* g;     // the text in the log
+    uint32_t n;           // its length
+    const uint64_t* w;    // LDS window, GLOB_WIN_WORDS words; bytes past the staged ones are zero
+    uint32_t wn;          // bytes staged
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return i < wn ? (uint32_t)(w[i >> 3] >> ((i & 7) * 8)) & 0xFF : g[i]; }
+    // bytes i..i+7 little-endian; bytes at or past n are unspecified
+    __device__ __forceinline__ uint64_t load8(uint32_t i) const {
+        if (i < wn && (i + 8 <= wn || wn >= n)) {   // all 8 bytes staged, or nothing exists past the staged ones
+            const uint64_t a = w[i >> 3], b = w[(i >> 3) + 1];
+            const uint32_t sh = (i & 7) * 8;
+            return sh ? (a >> sh) | (b << (64 - sh)) : a;
+        }
+        uint64_t v = 0;
+        if (i + 8 <= n) __builtin_memcpy(&v, g + i, 8);
+        else for (uint32_t b = 0; i + b < n; ++b) v |= (uint64_t)g[i + b] << (8 * b);
+        return v;
+    }
+};
+// stage the first bytes of text[0, n) (inside log[0, log_len)) into the lane's window
+__device__ __forceinline__ TextView text_stage(const uint8_t* log, uint32_t log_len, uint32_t start, uint32_t n, uint64_t* win) {
+    TextView tv{log + start, n, win, min(n, GLOB_WIN)};
+#pragma unroll
+    for (uint32_t k = 0; k < GLOB_WIN_WORDS; ++k) {
+        uint64_t v = 0;
+        const uint32_t o = k * 8;
+        if (o < tv.wn) {
+            if (start + o + 8 <= log_len) __builtin_memcpy(&v, log + start + o, 8);
+            else for (uint32_t b = 0; start + o + b < log_len; ++b) v |= (uint64_t)log[start + o + b] << (8 * b);
+            if (tv.wn - o < 8) v &= (1ull << ((tv.wn - o) * 8)) - 1;
+        }
+        win[k] = v;
+    }
+    return tv;
+}
+
+// match_glob_from_buffer / match_segments_impl (pg:1364-1639), case-sensitive. The recursion is replayed with an
+// explicit stack of Star frames; every call of the reference consumes one unit of the 100 000-step budget here too.
+// The header of the segment last looked at and the first 8 bytes of its literal stay in registers: a star re-enters the
+// same segment once per text position.
+__device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView& text, uint32_t* err) {
+    const uint8_t* pg = db.pg;
+    const bool ci = db.ci != 0;
+    const uint32_t tn = text.n;
+    uint32_t io = db.glob_seg_off + pattern_id * 8;
+    if (io + 8 > db.pg_len) return false;
+    uint32_t first = ld32(pg + io);
+    uint32_t count = ld32(pg + io + 4) & 0xFFFF;
+    uint32_t steps = 100000;
+    uint32_t st_seg[MAX_GLOB_STARS], st_pos[MAX_GLOB_STARS], t_seg = 0, t_pos = 0;
+    int sp = 0;
+    uint32_t pos = 0, seg = 0;
+    bool result = false;
+    uint32_t c_seg = 0xFFFFFFFFu, c_h0 = 0, c_dlen = 0, c_doff = 0;
+    uint64_t c_lit8 = 0;
+    for (;;) {
+        // ---- CALL(pos, seg)
+        bool ret = false;
+        if (steps == 0) return false;  // once exhausted every remaining call returns false (pg:1415-1417)
+        --steps;
+        if (seg >= count) { result = pos >= tn; ret = true; }
+        else {
+            uint32_t so = first + seg * 12;
+            if (so + 12 > db.pg_len) { result = false; ret = true; }
+            else {
+                if (seg != c_seg) {
+                    c_seg = seg;
+                    c_h0 = ld32(pg + so); c_dlen = ld32(pg + so + 4); c_doff = ld32(pg + so + 8);
+                    c_lit8 = 0;
+                    if ((c_h0 & 0xFF) == 0 && c_doff + c_dlen <= db.pg_len) {
+                        if (c_dlen >= 8) __builtin_memcpy(&c_lit8, pg + c_doff, 8);
+                        else for (uint32_t k = 0; k < c_dlen; ++k) c_lit8 |= (uint64_t)pg[c_doff + k] << (8 * k);
+                        // case-insensitive (pg:1456-1478): characters compare with eq_ignore_ascii_case, which on UTF-8 bytes
+                        // is ASCII folding of both sides (the bytes of other characters are >= 0x80 and must be equal)
+                        if (ci) c_lit8 = ascii_lower8(c_lit8);
+                    }
+                }
+                const uint32_t st = c_h0 & 0xFF, fl = (c_h0 >> 8) & 0xFF, dlen = c_dlen, doff = c_doff;
+                if (st == 0) {
+                    bool ok = doff + dlen <= db.pg_len && tn - pos >= dlen;
+                    if (ok && dlen) {
+                        const uint64_t m0 = dlen >= 8 ? ~0ull : (1ull << (dlen * 8)) - 1;
+                        const uint64_t t0 = text.load8(pos);
+                        uint64_t diff = ((ci ? ascii_lower8(t0) : t0) ^ c_lit8) & m0;
+                        if (diff == 0) {
+                            for (uint32_t k = 8; k < dlen; k += 8) {   // no early exit: the loads are independent
+                                const uint32_t r = dlen - k;
+                                uint64_t x = 0;
+                                if (r >= 8) __builtin_memcpy(&x, pg + doff + k, 8);
+                                else for (uint32_t b = 0; b < r; ++b) x |= (uint64_t)pg[doff + k + b] << (8 * b);
+                                const uint64_t tk = text.load8(pos + k);
+                                diff |= ((ci ? ascii_lower8(tk) : tk) ^ (ci ? ascii_lower8(x) : x)) & (r >= 8 ? ~0ull : (1ull << (r * 8)) - 1);
+                            }
+                        }
+                        ok = diff == 0;
+                    }
+                    if (ok) { pos += dlen; ++seg; } else { result = false; ret = true; }
+                } else if (st == 1) {
+                    if (seg + 1 >= count) { result = true; ret = true; }
+                    else if (sp >= (int)MAX_GLOB_STARS) { atomicOr(err, 2u); return false; }
+                    else {
+                        if (sp > 0) { st_seg[sp - 1] = t_seg; st_pos[sp - 1] = t_pos; }   // the innermost frame lives in registers
+                        t_seg = seg; t_pos = pos; ++sp; ++seg;
+                    }
+                } else if (st == 2) {
+                    if (pos < tn) { pos += utf8_adv(text.at(pos)); ++seg; } else { result = false; ret = true; }
+                } else if (st == 3) {
+                    if (pos >= tn || doff + dlen > db.pg_len) { result = false; ret = true; }
+                    else {
+                        uint32_t c = text.at(pos), adv = utf8_adv(c);
+                        uint32_t cp = adv == 1 ? c : adv == 2 ? (c & 0x1F) : adv == 3 ? (c & 0x0F) : (c & 0x07);
+                        for (uint32_t k = 1; k < adv && pos + k < tn; ++k) cp = (cp << 6) | (text.at(pos + k) & 0x3F);
+                        if (ci) cp = ascii_lower1(cp);   // pg:1552-1555
+                        bool in_class = false;
+                        for (uint32_t k = 0; k < dlen / 12 && !in_class; ++k) {
+                            const uint8_t* it = pg + doff + k * 12;
+                            uint32_t ty = it[0], c1 = ld32(it + 4), c2 = ld32(it + 8);
+                            if (ci) { c1 = ascii_lower1(c1); c2 = ascii_lower1(c2); }   // pg:1584-1607 (values that are no chars fail is_rust_char either way)
+                            if (ty == 0) in_class = is_rust_char(c1) && cp == c1;
+                            else if (ty == 1) in_class = is_rust_char(c1) && is_rust_char(c2) && cp >= c1 && cp <= c2;
+                        }
+                        if ((fl & 1) ? !in_class : in_class) { pos += adv; ++seg; } else { result = false; ret = true; }
+                    }
+                } else { result = false; ret = true; }
+            }
+        }
+        if (!ret) continue;
+        // ---- RETURN(result) to the innermost Star frame
+        for (;;) {
+            if (sp == 0) return result;
+            uint32_t fp = t_pos;
+            if (result || fp >= tn) {  // star returns true, or is exhausted and returns false: propagate
+                --sp;
+                if (sp > 0) { t_seg = st_seg[sp - 1]; t_pos = st_pos[sp - 1]; }
+                continue;
+            }
+            fp += utf8_adv(text.at(fp));
+            t_pos = fp;
+            pos = fp;
+            seg = t_seg + 1;
+            break;
+        }
+    }
+}
+
+// Paraglob::find_all (pg:1028-1182): returns the sorted unique pattern ids in out[0..n)
+__device__ uint32_t glob_find_all(const DevDb& db, const DfaView& dv, const TextView& text, uint32_t* oq, uint32_t* out, uint32_t* err) {
+    const uint32_t tn = text.n;
+    uint32_t n = 0;
+    auto insert = [&](uint32_t id) {
+        uint32_t k = 0;
+        while (k < n && out[k] < id) ++k;
+        if (k < n && out[k] == id) return;
+        if (n >= MAX_GLOB_RESULTS) { atomicOr(err, 1u); return; }
+        for (uint32_t m = n; m > k; --m) out[m] = out[m - 1];
+        out[k] = id;
+        ++n;
+    };
+    auto contains = [&](uint32_t id) { for (uint32_t k = 0; k < n; ++k) if (out[k] == id) return true; return false; };
+    auto consider = [&](uint32_t pid) {
+        uint32_t eo = db.patterns_off + pid * 16;
+        if (eo + 16 > db.pg_len) return;
+        uint32_t entry_id = ld32(db.pg + eo);
+        uint32_t ptype = db.pg[eo + 4];
+        if (contains(entry_id)) return;
+        if (ptype == 0 || glob_match(db, entry_id, text, err)) insert(entry_id);
+    };
+    for (uint32_t i = 0; i < db.wild_count; ++i) {
+        uint32_t wo = db.wild_off + i * 8;
+        if (wo + 8 > db.pg_len) continue;
+        uint32_t pid = ld32(db.pg + wo);
+        if (db.patterns_off + pid * 16 + 16 > db.pg_len) continue;
+        if (!contains(pid) && glob_match(db, pid, text, err)) insert(pid);
+    }
+    if (db.ac_size > 0 && tn > 0) {
+        const uint8_t* ac = db.pg + db.ac_start;
+        // literals that end at node `cur` -> their patterns (run_ac_matching_into_static collects them per visited node)
+        auto outputs = [&](uint32_t cur) {
+            const uint32_t pc = ac[cur + 3];
+            if (!pc) return;
+            const uint32_t po = ld32(ac + cur + 16);
+            if (po + pc * 4 > db.ac_size) return;
+            for (uint32_t k = 0; k < pc; ++k) {
+                const uint32_t lit = ld32(ac + po + k * 4);
+                if (lit >= db.n_ac_lits) continue;
+                for (uint32_t q = db.lit2pat_off[lit]; q < db.lit2pat_off[lit + 1]; ++q) consider(db.lit2pat[q]);
+            }
+        };
+        if (db.dfa) {
+            // flattened automaton: one table load per byte, the text fetched 8 bytes at a time
+            uint32_t st = 0, qn = 0;
+            for (uint32_t i = 0; i < tn; i += 8) {
+                uint64_t w = text.load8(i);
+                const uint32_t m = min(8u, tn - i);
+                for (uint32_t b = 0; b < m; ++b) {
+                    const uint32_t e = dfa_step(db, dv, st, (uint32_t)w & 0xFF);
+                    w >>= 8;
+                    st = e & 0x7FFFFFFFu;
+                    if (e >> 31) {
+                        // Output states are queued and handled after the walk: lanes meet them at different text
+                        // positions, and handling them on the spot would run each lane's chain of dependent loads
+                        // (node -> literal -> patterns -> segments) one after the other instead of side by side.
+                        if (qn < GLOB_OUTQ) oq[qn++] = st;
+                        else outputs(db.dfa_node[st]);
+                    }
+                }
+            }
+            for (uint32_t k = 0; k < qn; ++k) outputs(db.dfa_node[oq[k]]);
+        } else {
+            uint32_t cur = 0;
+            for (uint32_t i = 0; i < tn; ++i) {
+                uint32_t ch = text.at(i);
+                if (db.ci) ch = ascii_lower1(ch);   // pg:1198-1206
+                for (;;) {
+                    uint32_t nx = ac_transition(ac, db.ac_size, cur, ch);
+                    if (nx != 0xFFFFFFFFu) { cur = nx; break; }
+                    if (cur == 0) break;
+                    if (cur + 20 > db.ac_size) break;
+                    cur = ld32(ac + cur + 8);
+                }
+                if (cur + 20 > db.ac_size) continue;
+                outputs(cur);
+            }
+        }
+    }
+    return n;
+}
+
+// true when the text reaches a state of the flattened AC automaton that has output literals (necessary for any glob
+// with a literal part to match)
+__device__ __forceinline__ bool ac_touches_output(const DevDb& db, const DfaView& dv, const uint8_t* text, uint32_t tn) {
+    uint32_t st = 0, any = 0;
+    for (uint32_t i = 0; i < tn; i += 8) {
+        uint64_t w = 0;
+        const uint32_t m = min(8u, tn - i);
+        if (m == 8) __builtin_memcpy(&w, text + i, 8);
+        else for (uint32_t b = 0; b < m; ++b) w |= (uint64_t)text[i + b] << (8 * b);
+        for (uint32_t b = 0; b < m; ++b) {
+            const uint32_t e = dfa_step(db, dv, st, (uint32_t)w & 0xFF);
+            w >>= 8;
+            st = e & 0x7FFFFFFFu;
+            any |= e;
+        }
+    }
+    return (any >> 31) != 0;
+}
+
+// One lane's hit -> dense FinalHit record (+ its pattern ids and data offsets), device copy and pinned host mirror: the body of
+// k_pack, also called straight from k_lookup for bulk scans (LookupParams::direct), where it overlaps the PCIe writes of
+// the records with the lookups instead of running as a kernel of its own afterwards. Wave-uniform call; `valid` marks the
+// lanes that hold a hit. Glob ids come from `globs` (k_lookup's own result list) or, when that is null, from pp.ids.
+// Pattern results follow Database::lookup_string_uncached (database.rs:911-981): the literal id counts only if it has a data
+// mapping, then the glob ids in ascending order; a literal without mapping and no glob is NotFound.
+__device__ __forceinline__ void pack_record(const PackParams& pp, bool valid, const Hit& h, const uint32_t* globs) {
+    const uint32_t lane = lane_id();
+    uint32_t nid = 0, lit_off = 0xFFFFFFFFu;
+    if (valid && h.kind == 3) {
+        if (h.a != 0xFFFFFFFFu && h.a < pp.n_lit) lit_off = pp.lit_offsets[h.a];
+        nid = (lit_off != 0xFFFFFFFFu ? 1u : 0u) + h.n_globs;
+        if (nid == 0) valid = false;
+    }
+    // dense slot for the record: one atomic per wave
+    const uint64_t vm = __ballot(valid);
+    if (vm == 0) return;
+    uint32_t slot0 = 0;
+    if (lane == 0) slot0 = atomicAdd(&pp.counters->n_final, (uint32_t)__popcll(vm));
+    slot0 = __builtin_amdgcn_readfirstlane(slot0);
+    const uint32_t slot = slot0 + (uint32_t)__popcll(vm & lanemask_lt());
+    // side-array space for pattern ids: wave exclusive scan of nid, one atomic per wave
+    uint32_t scan = valid ? nid : 0u;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)scan, off);
+        if ((int)lane >= off) scan += t;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)scan, 63);
+    uint32_t ids0 = 0;
+    if (total) {
+        if (lane == 0) ids0 = atomicAdd(&pp.counters->n_final_ids, total);
+        ids0 = __builtin_amdgcn_readfirstlane(ids0);
+    }
+    if (valid) {
+        const uint32_t my_ids = ids0 + scan - nid;
+        FinalHit f{};
+        f.start = h.start;
+        f.len_type = h.len_type;
+        f.kind = h.kind;
+        f.prefix_len = h.prefix_len;
+        if (h.kind == 2) f.value = h.a;
+        else {
+            f.n_ids = (uint16_t)nid;
+            f.value = my_ids;
+            uint32_t w = my_ids;
+            if (lit_off != 0xFFFFFFFFu) {
+                if (w < pp.out_ids_cap) { pp.out_ids[w] = h.a; pp.out_offs[w] = (long long)lit_off; }
+                if (w < pp.host_ids_cap) { pp.host_ids[w] = h.a; pp.host_offs[w] = (long long)lit_off; }
+                ++w;
+            }
+            for (uint32_t k = 0; k < h.n_globs; ++k, ++w) {
+                const uint32_t pid = globs ? globs[k] : ((h.ids_off + k < pp.ids_cap) ? pp.ids[h.ids_off + k] : 0u);
+                const long long go = pid < pp.n_glob ? (long long)pp.glob_offsets[pid] : -1ll;
+                if (w < pp.out_ids_cap) { pp.out_ids[w] = pid; pp.out_offs[w] = go; }
+                if (w < pp.host_ids_cap) { pp.host_ids[w] = pid; pp.host_offs[w] = go; }
+            }
+        }
+        if (slot < pp.out_cap) pp.out[slot] = f;
+        if (slot < pp.host_cap) pp.host_out[slot] = f;
+    }
+}
+
+// GLOB=false carries no glob state and stays register-lean: databases without a PARAGLOB section, and the first pass of
+// the two-pass lookup (p.ac_filter): IP and literal lookups plus one DFA walk per string candidate; candidates that
+// touch an AC output state are deferred to the GLOB=true pass through p.glob_work. GLOB=true does the full
+// Paraglob::find_all, over all candidates or (p.from_work) over the work list.
+template <bool GLOB>
+__global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
+    __shared__ uint8_t cls[256];  // byte -> DFA class
+    // the glob pass sees texts that go deep into the automaton anyway: a small shallow part, more resident waves
+    constexpr uint32_t ROWS = GLOB ? DFA_LDS_ENTRIES_GLOB : DFA_LDS_ENTRIES;
+    __shared__ uint32_t rows[ROWS];
+    __shared__ uint64_t twin[GLOB ? 256 * GLOB_WIN_WORDS : 1];   // per-lane text window of the glob pass
+    __shared__ uint32_t outq[GLOB ? 256 * GLOB_OUTQ : 1];
+    const DfaView dv = dfa_stage<ROWS>(db, cls, rows);
+    __syncthreads();
+    const uint32_t n = p.from_work ? min(p.counters->n_glob_work, p.glob_work_cap) : min(p.counters->n_cand, p.cand_cap);
+    uint32_t stride = gridDim.x * blockDim.x;
+    ChunkWriter<Hit, HIT_CHUNK> cw;
+    ChunkWriter<uint32_t, 64> ww;
+    Hit SH{};
+    SH.kind = 0xFF;
+    // loop bound is wave-uniform so that the chunk writers see converged waves
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        uint32_t i = base + threadIdx.x;
+        Hit h{};
+        bool emit = false, defer = false;
+        uint32_t globs[GLOB ? MAX_GLOB_RESULTS : 1];
+        uint32_t ng = 0;
+        Candidate c{0, 0xFFFFFFFFu, 0, 0};
+        if (p.from_work) {
+            const uint32_t idx = i < n ? p.glob_work[i] : 0xFFFFFFFFu;
+            if (idx != 0xFFFFFFFFu && idx < p.cand_cap) { c = p.cands[idx]; i = idx; }
+        } else if (i < n) {
+            c = p.cands[i];
+        }
+        if (c.len_type != 0xFFFFFFFFu) {
+            uint32_t type = c.len_type >> 24, tl = c.len_type & 0xFFFFFF;
+            const uint8_t* text = p.log + c.start;
+            h.cand = i; h.start = c.start; h.len_type = c.len_type;
+            if (type == IT_IPV4) {
+                uint32_t off, pfx;
+                if (db.has_ip && trie_v4(db, c.v4, off, pfx)) { h.kind = 2; h.a = off; h.prefix_len = (uint8_t)pfx; emit = true; }
+            } else if (type == IT_IPV6) {
+                uint16_t seg[8];
+                uint32_t off, pfx;
+                if (db.has_ip && d_parse_ipv6(text, tl, seg) && trie_v6(db, seg, off, pfx)) { h.kind = 2; h.a = off; h.prefix_len = (uint8_t)pfx; emit = true; }
+            } else {
+                if (!GLOB && p.ac_filter && ac_touches_output(db, dv, text, tl)) defer = true;
+                else {
+                    uint32_t pid = 0xFFFFFFFFu;
+                    if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q, &p.counters->error)) pid = q; }
+                    if constexpr (GLOB) ng = glob_find_all(db, dv, text_stage(p.log, p.len, c.start, tl, twin + threadIdx.x * GLOB_WIN_WORDS), outq + threadIdx.x * GLOB_OUTQ, globs, &p.counters->error);
+                    if (pid != 0xFFFFFFFFu || ng) { h.kind = 3; h.a = pid; h.n_globs = (uint16_t)ng; emit = true; }
+                }
+            }
+        }
+        if (p.direct) {
+            // bulk scans: the record goes out right here (device copy + pinned host mirror), no hit list, no k_pack
+            pack_record(p.pk, emit, h, GLOB ? globs : nullptr);
+        } else {
+            if (GLOB && emit && ng) {
+                uint32_t io = atomicAdd(&p.counters->n_ids, ng);
+                h.ids_off = io;
+                for (uint32_t k = 0; k < ng; ++k) if (io + k < p.ids_cap) p.ids[io + k] = globs[k];
+            }
+            cw.append(emit, h, p.hits, p.hit_cap, &p.counters->n_hits, SH);
+        }
+        if (!GLOB && p.ac_filter) ww.append(defer, i, p.glob_work, p.glob_work_cap, &p.counters->n_glob_work, 0xFFFFFFFFu);
+    }
+    cw.pad_rest(p.hits, p.hit_cap, SH);
+    if (!GLOB && p.ac_filter) ww.pad_rest(p.glob_work, p.glob_work_cap, 0xFFFFFFFFu);
+    if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->hits_true, cw.total);
+}
+
+// ------------------------------------------------------------------------------------------------ launch wrapper
+void launch_lookup(const LookupParams& p_in, const DevDb& db, int grid, hipStream_t stream) {
+    LookupParams p = p_in;
+    p.ac_filter = 0; p.from_work = 0;
+    if (!db.has_glob) {
+        hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(256), 0, stream, p, db);
+    } else if (db.dfa && db.wild_count == 0 && p.glob_work && grid > 1) {
+        // two passes: lean lookup + AC prefilter for everything, the register-heavy glob matcher only for the few
+        // candidates that reach an AC output state (without literal hits no glob can match: pure wildcards aside)
+        p.ac_filter = 1;
+        hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(256), 0, stream, p, db);
+        p.ac_filter = 0; p.from_work = 1;
+        hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(256), 0, stream, p, db);
+    } else {
+        hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(256), 0, stream, p, db);
+    }
+}
+
+}  // namespace mxy
