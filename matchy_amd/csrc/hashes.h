@@ -97,40 +97,23 @@ MXY_HD uint64_t xxh64(const uint8_t* p, size_t len, uint64_t seed) {
     return h;
 }
 
-// XXH64 (seed 0) of a string of n <= 31 bytes given as four little-endian 8-byte lanes (bytes beyond n are ignored).
-// Same arithmetic as xxh64() for len < 32, written without data-dependent branches for the device.
-MXY_HD uint64_t xxh64_lanes31(uint64_t l0, uint64_t l1, uint64_t l2, uint64_t l3, uint32_t n) {
-    const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL,
-                   P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
-    uint64_t h = P5 + (uint64_t)n;
-    const uint32_t nl = n >> 3;
-    const uint64_t lane[3] = {l0, l1, l2};
-    for (int k = 0; k < 3; ++k) {
-        uint64_t v = lane[k] * P2;
-        v = rotl64(v, 31) * P1;
-        const uint64_t hn = rotl64(h ^ v, 27) * P1 + P4;
-        h = (uint32_t)k < nl ? hn : h;
+// Hash of a name of n <= 31 bytes given as four little-endian 8-byte lanes (bytes at and past n are ignored) for the
+// device-side "can any literal key be this name" bitmap (DevDb::lit_bm). Host (bitmap construction from the stored keys)
+// and device (k_validate_dom) only have to agree with each other, so this is a cheap 32-bit multiply-xorshift mix instead
+// of the XXH64 that the literal table itself is keyed by: 9 32-bit multiplies instead of ~16 64-bit ones per name.
+MXY_HD uint32_t name_hash31(uint64_t l0, uint64_t l1, uint64_t l2, uint64_t l3, uint32_t n) {
+    const uint64_t lane[4] = {l0, l1, l2, l3};
+    uint32_t h = n * 0x9E3779B1u + 0x7F4A7C15u;
+    for (int k = 0; k < 4; ++k) {
+        const int rem = (int)n - 8 * k;   // bytes of this lane that belong to the name
+        const uint64_t m = rem >= 8 ? ~0ull : rem <= 0 ? 0ull : ((1ull << (8 * rem)) - 1ull);
+        const uint64_t v = lane[k] & m;
+        h = (h ^ (uint32_t)v) * 0x85EBCA6Bu; h ^= h >> 15;
+        h = (h ^ (uint32_t)(v >> 32)) * 0xC2B2AE35u; h ^= h >> 13;
     }
-    uint64_t t = nl == 0 ? l0 : nl == 1 ? l1 : nl == 2 ? l2 : l3;   // the lane that holds the remaining n & 7 bytes
-    uint32_t rest = n & 7;
-    {
-        const uint64_t hn = rotl64(h ^ ((t & 0xFFFFFFFFull) * P1), 23) * P2 + P3;
-        const bool take = rest >= 4;
-        h = take ? hn : h;
-        t = take ? (t >> 32) : t;
-        rest = take ? rest - 4 : rest;
-    }
-    for (int b = 0; b < 3; ++b) {
-        const uint64_t hn = rotl64(h ^ ((t & 0xFFull) * P5), 11) * P1;
-        h = (uint32_t)b < rest ? hn : h;
-        t >>= 8;
-    }
-    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    h *= 0x27D4EB2Fu; h ^= h >> 16;
     return h;
 }
-
-// bit index (before masking) of a literal's XXH64 in the device-side "is any literal hashed like this" bitmap
-MXY_HD uint32_t lit_bm_bit(uint64_t h) { return (uint32_t)(h >> 13); }
 
 // rustc-hash 2.x (64-bit): hash = (hash + x) * K, finish = rotl(hash, 26). See DESIGN.md (unverified vs crate source).
 MXY_HD uint64_t fx_u32(uint32_t v) { return rotl64((uint64_t)v * 0xf1357aea2e62a9c5ULL, 26); }

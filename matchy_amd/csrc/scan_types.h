@@ -62,7 +62,7 @@ struct DevDb {
     const LitSlot* lit_slots;
     uint32_t lit_mask;
     uint32_t has_literal;
-    // bitmap over the literals' XXH64 values (bit lit_bm_bit(h) & lit_bm_mask): clear => no literal has this hash.
+    // bitmap over name_hash31() of the literal keys of <= 31 bytes (bit h & lit_bm_mask): clear => no key is this name.
     // k_validate drops (but counts) domain candidates that cannot hit when the database has no glob section.
     const uint32_t* lit_bm;
     uint32_t lit_bm_mask;

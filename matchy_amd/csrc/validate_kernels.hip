@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
                 pend_word = 0xFFFFFFFFu; pend_bit = 0;
                 n_valid += 1;
                 if (p.filter_lit) {
-                    // XXH64 of the name straight from the context record (no second read of the log): the 32 context
+                    // hash of the name straight from the context record (no second read of the log): the 32 context
                     // bytes go through a per-lane LDS buffer to get the name aligned to 8-byte lanes
                     *reinterpret_cast<uint4*>(sb) = make_uint4(cur.c[0], cur.c[1], cur.c[2], cur.c[3]);
                     *reinterpret_cast<uint4*>(sb + 4) = make_uint4(cur.c[4], cur.c[5], cur.c[6], cur.c[7]);
@@ -717,8 +717,7 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) ln[k] = ascii_lower8(ln[k]);
                     }
-                    const uint64_t h = xxh64_lanes31(ln[0], ln[1], ln[2], ln[3], n);
-                    const uint32_t b = lit_bm_bit(h) & db.lit_bm_mask;
+                    const uint32_t b = name_hash31(ln[0], ln[1], ln[2], ln[3], n) & db.lit_bm_mask;
                     pend_word = db.lit_bm ? db.lit_bm[b >> 5] : 0u;
                     pend_bit = b & 31;
                     if constexpr (AC) {
