@@ -88,6 +88,36 @@ struct ChunkWriter {
     }
 };
 
+// Writer for the sparse lists (rare anchors, long tokens, heavy tokens): entries collect in a 64-slot LDS buffer of the wave
+// and leave together — one atomic per flush for exactly the entries there are, so these lists carry no per-wave padding
+// (with ~10 000 producer waves a 64-slot chunk per wave was mostly padding, which the consumers dragged through their
+// loops) and appends that carry one or two entries do not pay an atomic round trip each.
+template <class T>
+struct BufferedWriter {
+    T* buf;              // 64 entries of LDS owned by this wave
+    uint32_t cnt = 0;    // wave-uniform
+    __device__ __forceinline__ explicit BufferedWriter(T* lds) : buf(lds) {}
+    __device__ __forceinline__ void flush(T* out, uint32_t cap, uint32_t* counter) {
+        if (cnt == 0) return;
+        uint32_t b = 0;
+        if (lane_id() == 0) b = atomicAdd(counter, cnt);
+        b = __builtin_amdgcn_readfirstlane(b);
+        __builtin_amdgcn_wave_barrier();
+        if (lane_id() < cnt && b + lane_id() < cap) out[b + lane_id()] = buf[lane_id()];
+        __builtin_amdgcn_wave_barrier();
+        cnt = 0;
+    }
+    // all lanes of the (converged) wave call this
+    __device__ __forceinline__ void append(bool emit, const T& v, T* out, uint32_t cap, uint32_t* counter) {
+        const uint64_t m = __ballot(emit);
+        if (m == 0) return;
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (cnt + n > 64) flush(out, cap, counter);
+        if (emit) buf[cnt + (uint32_t)__popcll(m & lanemask_lt())] = v;
+        cnt += n;
+    }
+};
+
 // Chunked writer for the plane-organised domain anchor list (TokParams::dom_list): slots are reserved like in
 // ChunkWriter (one atomic per ANCHOR_CHUNK slots), the caller stores the planes of its slot.
 struct DomWriter {

@@ -208,6 +208,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     __shared__ __attribute__((aligned(16))) uint32_t rawst[AW][RAW_DW];
     __shared__ uint32_t q_v4[AW][QCAP];
     __shared__ uint32_t q_dom[AW][QCAP];
+    __shared__ uint2 wb_misc[AW][64], wb_tok[AW][64];   // BufferedWriter staging
 
     ctab[threadIdx.x] = (uint8_t)(class_of(threadIdx.x) | (((db.tld_first[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1) ? C_TLD1 : 0));
     for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += AW * 64) bloom[i] = db.tld_bloom[i];
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     uint32_t v4_old = 0, dom_old = 0;            // block start of the oldest ring entry (valid while the ring is non-empty)
     ChunkWriter<Candidate, V4_CHUNK> cw_cand;
     DomWriter cw_dom;
-    ChunkWriter<uint2, RARE_CHUNK> cw_misc, cw_tok;  // rare anchors are sparse: small chunks keep the lists dense
+    BufferedWriter<uint2> cw_misc(wb_misc[wave]), cw_tok(wb_tok[wave]);   // rare anchors and long tokens are sparse: dense lists
     const uint2 S64 = make_uint2(0xFFFFFFFFu, 0xFFu);
     uint2* rare_out = reinterpret_cast<uint2*>(p.rare);
     uint2* tok_out = reinterpret_cast<uint2*>(p.tok);
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                         v = make_uint2(pos0 + ((bit & 3) << 2) + (bit >> 3), (bit & 4) ? (uint32_t)RARE_AT : (uint32_t)RARE_V6);
                         Fm &= Fm - 1;
                     }
-                    cw_misc.append(has, v, rare_out, p.rare_cap, &p.counters->n_rare, S64);
+                    cw_misc.append(has, v, rare_out, p.rare_cap, &p.counters->n_rare);
                 }
             }
             if (en_tok) {
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                     const uint32_t j = pos0 + (ck & 3) * 4 + (low ? ((uint32_t)(__ffs((int)low) - 1) >> 3) : 0u);
                     const uint32_t tl = (uint32_t)((int32_t)j - 1 - lb);
                     const bool tok = ck < 4 && ((tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128);
-                    cw_tok.append(tok, make_uint2(j - tl, (uint32_t)RARE_TOK | (tl << 8)), tok_out, p.tok_cap, &p.counters->n_tok, S64);
+                    cw_tok.append(tok, make_uint2(j - tl, (uint32_t)RARE_TOK | (tl << 8)), tok_out, p.tok_cap, &p.counters->n_tok);
                 }
                 // carry: last boundary byte of this block (scalar: the highest lane with a boundary), and the Z bits
                 if (anyB) {
@@ -460,11 +461,11 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         if (v4t != v4h) drain_v4(rv4, v4h, v4t, v4t - v4h, true, cx, pend, cw_cand);
     }
     commit_v4(pend, cx, cw_cand);
+    cw_misc.flush(rare_out, p.rare_cap, &p.counters->n_rare);
+    cw_tok.flush(tok_out, p.tok_cap, &p.counters->n_tok);
     // mark the unused tail of every open chunk
     cw_dom.pad_rest(p.dom_list, p.dom_cap);
     cw_cand.pad_rest(p.cands, p.cand_cap, Candidate{0, 0xFFFFFFFFu, 0, 0});
-    cw_misc.pad_rest(rare_out, p.rare_cap, S64);
-    cw_tok.pad_rest(tok_out, p.tok_cap, S64);
     {
         uint32_t nv = pend.n_valid;  // validated IPv4 candidates, listed or not
 #pragma unroll

@@ -646,9 +646,9 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
     // the list free of padding for k_lookup)
     ChunkWriter<Candidate, CAND_CHUNK> cw_dense;
     ChunkWriter<Candidate, 64> cw;
-    ChunkWriter<RareAnchor, RARE_CHUNK> sw;   // undecided anchors -> rare list
+    __shared__ RareAnchor wb_slow[4][64];
+    BufferedWriter<RareAnchor> sw(wb_slow[threadIdx.x >> 6]);   // undecided anchors -> rare list (sparse: dense, no padding)
     const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
-    const RareAnchor SR{0xFFFFFFFFu, 0xFFu};
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t nd = min(p.counters->n_dom, p.dom_cap);
     struct Rec { uint32_t j; uint32_t c[8]; };
@@ -738,14 +738,14 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
                 }
             }
         }
-        sw.append(slow, RareAnchor{cur.j & 0x7FFFFFFFu, (uint32_t)RARE_DOM}, p.rare, p.rare_cap, &p.counters->n_rare, SR);
+        sw.append(slow, RareAnchor{cur.j & 0x7FFFFFFFu, (uint32_t)RARE_DOM}, p.rare, p.rare_cap, &p.counters->n_rare);
         cur = nxt;
     }
     if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
-    sw.pad_rest(p.rare, p.rare_cap, SR);
     cw.pad_rest(p.cands, p.cand_cap, SC);
     cw_dense.pad_rest(p.cands, p.cand_cap, SC);
+    sw.flush(p.rare, p.rare_cap, &p.counters->n_rare);
     // validated domain candidates, listed or not
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
@@ -769,8 +769,8 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     // SHA-256 / Keccak and hundreds of registers, so tokens that pass their cheap prefix tests go to the `heavy` list
     // for k_rare. A token made of non-boundary bytes may contain high bytes; every accepted form is pure ASCII, so the
     // reference's from_utf8 precondition is implied by the per-symbol checks.
-    ChunkWriter<RareAnchor, RARE_CHUNK> hw;
-    const RareAnchor SH{0xFFFFFFFFu, 0xFFu};
+    __shared__ RareAnchor wb_heavy[4][64];
+    BufferedWriter<RareAnchor> hw(wb_heavy[threadIdx.x >> 6]);
     const uint32_t nt = min(p.counters->n_tok, p.tok_cap);
     for (uint32_t base = blockIdx.x * blockDim.x; base < nt; base += stride) {
         const uint32_t i = base + threadIdx.x;
@@ -796,13 +796,14 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
                 if (s[0] == 'b' && s[1] == 'c' && s[2] == '1') hk = HEAVY_BECH32;
                 else if (s[0] == '1' || s[0] == '3') hk = HEAVY_B58;
             }
-            hw.append(hk != 0, RareAnchor{ra.pos, (tl << 8) | hk}, p.heavy, p.heavy_cap, &p.counters->n_heavy, SH);
+            hw.append(hk != 0, RareAnchor{ra.pos, (tl << 8) | hk}, p.heavy, p.heavy_cap, &p.counters->n_heavy);
             hk = 0;
             if (live && (p.flags & EX_ETHEREUM) && tl == 42 && s[0] == '0' && s[1] == 'x') hk = HEAVY_ETH;
             if (live && (p.flags & EX_MONERO) && tl >= 90 && tl <= 110 && (s[0] == '4' || s[0] == '8')) hk = HEAVY_XMR;
-            hw.append(hk != 0, RareAnchor{ra.pos, (tl << 8) | hk}, p.heavy, p.heavy_cap, &p.counters->n_heavy, SH);
+            hw.append(hk != 0, RareAnchor{ra.pos, (tl << 8) | hk}, p.heavy, p.heavy_cap, &p.counters->n_heavy);
         }
     }
+    hw.flush(p.heavy, p.heavy_cap, &p.counters->n_heavy);
     // IPv6 ("::") and e-mail ('@') anchors from the rare list. The IPv6 parser reads its bytes many times: each lane
     // copies log[p2-40, p2+40) into its LDS window with five wide loads first.
     uint8_t* win = winbuf + threadIdx.x * 80;
@@ -844,7 +845,6 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         }
         cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     }
-    hw.pad_rest(p.heavy, p.heavy_cap, SH);
     cw.pad_rest(p.cands, p.cand_cap, SC);
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
 }
