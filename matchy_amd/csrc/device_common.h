@@ -88,7 +88,7 @@ struct ChunkWriter {
     }
 };
 
-// Writer for the sparse lists (rare anchors, long tokens, heavy tokens): entries collect in a 64-slot LDS buffer of the wave
+// Writer for the sparse lists (rare anchors, long tokens, heavy tokens, prefiltered candidates): entries collect in a 64-slot LDS buffer of the wave
 // and leave together — one atomic per flush for exactly the entries there are, so these lists carry no per-wave padding
 // (with ~10 000 producer waves a 64-slot chunk per wave was mostly padding, which the consumers dragged through their
 // loops) and appends that carry one or two entries do not pay an atomic round trip each.
@@ -96,6 +96,7 @@ template <class T>
 struct BufferedWriter {
     T* buf;              // 64 entries of LDS owned by this wave
     uint32_t cnt = 0;    // wave-uniform
+    uint32_t total = 0;  // entries appended by this wave
     __device__ __forceinline__ explicit BufferedWriter(T* lds) : buf(lds) {}
     __device__ __forceinline__ void flush(T* out, uint32_t cap, uint32_t* counter) {
         if (cnt == 0) return;
@@ -115,6 +116,7 @@ struct BufferedWriter {
         if (cnt + n > 64) flush(out, cap, counter);
         if (emit) buf[cnt + (uint32_t)__popcll(m & lanemask_lt())] = v;
         cnt += n;
+        total += n;
     }
 };
 

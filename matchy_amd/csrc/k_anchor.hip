@@ -35,7 +35,6 @@ constexpr uint32_t BLK_BYTES = 1024;    // bytes per wave iteration
 constexpr uint32_t QCAP = 128;          // ring entries per wave and type
 constexpr uint32_t RAW_BYTES = 4096;    // raw-byte window per wave (circular, block granular)
 constexpr uint32_t RAW_DW = RAW_BYTES / 4;
-constexpr uint32_t V4_CHUNK = 64;       // IPv4 candidates that pass the /24 bitmap are sparse: small chunks
 static_assert(SEG_BYTES % RAW_BYTES == 0 && RAW_BYTES % BLK_BYTES == 0, "window wraps on block edges inside a segment");
 
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
@@ -75,15 +74,15 @@ struct PendingV4 {
     uint32_t n_valid = 0;  // per-lane count of validated candidates (reduced into ScanCounters::cand_true at the end)
 };
 
-__device__ __forceinline__ void commit_v4(PendingV4& pd, const WaveCtx& cx, ChunkWriter<Candidate, V4_CHUNK>& cw) {
+__device__ __forceinline__ void commit_v4(PendingV4& pd, const WaveCtx& cx, BufferedWriter<Candidate>& cw) {
     const TokParams& p = *cx.p;
     const bool emit = pd.ok && ((pd.word >> ((pd.c.v4 >> 8) & 31)) & 1);
-    cw.append(emit, pd.c, p.cands, p.cand_cap, &p.counters->n_cand, Candidate{0, 0xFFFFFFFFu, 0, 0});
+    cw.append(emit, pd.c, p.cands, p.cand_cap, &p.counters->n_cand);
     pd.ok = false;
 }
 
 __device__ __forceinline__ void drain_v4(uint32_t* ring, uint32_t& head, uint32_t& tail, uint32_t n, bool final, const WaveCtx& cx,
-                                         PendingV4& pd, ChunkWriter<Candidate, V4_CHUNK>& cw) {
+                                         PendingV4& pd, BufferedWriter<Candidate>& cw) {
     const uint32_t lane = lane_id();
     const TokParams& p = *cx.p;
     commit_v4(pd, cx, cw);
@@ -209,6 +208,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     __shared__ uint32_t q_v4[AW][QCAP];
     __shared__ uint32_t q_dom[AW][QCAP];
     __shared__ uint2 wb_misc[AW][64], wb_tok[AW][64];   // BufferedWriter staging
+    __shared__ Candidate wb_cand[AW][64];
 
     ctab[threadIdx.x] = (uint8_t)(class_of(threadIdx.x) | (((db.tld_first[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1) ? C_TLD1 : 0));
     for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += AW * 64) bloom[i] = db.tld_bloom[i];
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     uint32_t nl_count = 0;                       // per-lane '\n' count, reduced once at the end
     uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0;   // ring heads / tails (wave-uniform)
     uint32_t v4_old = 0, dom_old = 0;            // block start of the oldest ring entry (valid while the ring is non-empty)
-    ChunkWriter<Candidate, V4_CHUNK> cw_cand;
+    BufferedWriter<Candidate> cw_cand(wb_cand[wave]);   // IPv4 candidates that pass the /24 bitmap are sparse
     DomWriter cw_dom;
     BufferedWriter<uint2> cw_misc(wb_misc[wave]), cw_tok(wb_tok[wave]);   // rare anchors and long tokens are sparse: dense lists
     const uint2 S64 = make_uint2(0xFFFFFFFFu, 0xFFu);
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     cw_tok.flush(tok_out, p.tok_cap, &p.counters->n_tok);
     // mark the unused tail of every open chunk
     cw_dom.pad_rest(p.dom_list, p.dom_cap);
-    cw_cand.pad_rest(p.cands, p.cand_cap, Candidate{0, 0xFFFFFFFFu, 0, 0});
+    cw_cand.flush(p.cands, p.cand_cap, &p.counters->n_cand);
     {
         uint32_t nv = pend.n_valid;  // validated IPv4 candidates, listed or not
 #pragma unroll

@@ -642,10 +642,10 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
     DfaView dv{dcls, drows, 0};
     if constexpr (AC) dv = dfa_stage<DFA_LDS_ENTRIES_VAL>(db, dcls, drows);
     __syncthreads();
-    // candidates: dense when every valid domain is listed (chunks of CAND_CHUNK), sparse otherwise (chunks of 64 keep
-    // the list free of padding for k_lookup)
+    // candidates: chunked when every valid domain is listed (high rate), buffered otherwise (no padding for k_lookup)
     ChunkWriter<Candidate, CAND_CHUNK> cw_dense;
-    ChunkWriter<Candidate, 64> cw;
+    __shared__ Candidate wb_cand[4][64];
+    BufferedWriter<Candidate> cw(wb_cand[threadIdx.x >> 6]);   // prefiltered (sparse) candidates
     __shared__ RareAnchor wb_slow[4][64];
     BufferedWriter<RareAnchor> sw(wb_slow[threadIdx.x >> 6]);   // undecided anchors -> rare list (sparse: dense, no padding)
     const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
     uint32_t* sb = strbuf[threadIdx.x];
     for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
         const uint32_t i = base + threadIdx.x;
-        if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+        if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand);
         else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
         pend = false;
         load_rec(i + stride, nxt);
@@ -741,9 +741,9 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
         sw.append(slow, RareAnchor{cur.j & 0x7FFFFFFFu, (uint32_t)RARE_DOM}, p.rare, p.rare_cap, &p.counters->n_rare);
         cur = nxt;
     }
-    if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+    if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand);
     else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
-    cw.pad_rest(p.cands, p.cand_cap, SC);
+    cw.flush(p.cands, p.cand_cap, &p.counters->n_cand);
     cw_dense.pad_rest(p.cands, p.cand_cap, SC);
     sw.flush(p.rare, p.rare_cap, &p.counters->n_rare);
     // validated domain candidates, listed or not
@@ -762,8 +762,8 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     for (uint32_t i = threadIdx.x; i < (1u << TLD_TAB_BITS); i += blockDim.x) tldtab[i] = db.tld_tab[i];
     __syncthreads();
     LogView lg{p.log, p.len};
-    ChunkWriter<Candidate, 64> cw;
-    const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
+    __shared__ Candidate wb_cand[4][64];
+    BufferedWriter<Candidate> cw(wb_cand[threadIdx.x >> 6]);
     const uint32_t stride = gridDim.x * blockDim.x;
     // Long tokens: hex hashes are decided here; the checksum validators (Base58Check, Bech32, EIP-55, Monero) need
     // SHA-256 / Keccak and hundreds of registers, so tokens that pass their cheap prefix tests go to the `heavy` list
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
                 const int ht = tl == 32 ? IT_MD5 : tl == 40 ? IT_SHA1 : tl == 64 ? IT_SHA256 : tl == 96 ? IT_SHA384 : tl == 128 ? IT_SHA512 : -1;
                 if (ht >= 0 && all_hex_wide(s, tl)) { c.start = ra.pos; c.len_type = tl | ((uint32_t)ht << 24); emit = true; }
             }
-            cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+            cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand);
         }
         // a token can yield several items: hash, Bitcoin, Ethereum and Monero are independent extractors
         {
@@ -843,9 +843,9 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
                 c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true;
             }
         }
-        cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+        cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand);
     }
-    cw.pad_rest(p.cands, p.cand_cap, SC);
+    cw.flush(p.cands, p.cand_cap, &p.counters->n_cand);
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
 }
 
@@ -856,8 +856,8 @@ __global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
     __shared__ __attribute__((aligned(16))) uint8_t tokbuf[64][112];
     __shared__ __attribute__((aligned(16))) uint8_t decbuf[64][96];
     LogView lg{p.log, p.len};
-    ChunkWriter<Candidate, CAND_CHUNK> cw;
-    const Candidate SC{0, 0xFFFFFFFFu, 0, 0};
+    __shared__ Candidate wb_cand[64];
+    BufferedWriter<Candidate> cw(wb_cand);
     const uint32_t n = min(p.counters->n_heavy, p.heavy_cap);
     uint8_t* tb = tokbuf[threadIdx.x];
     uint8_t* dec = decbuf[threadIdx.x];
@@ -886,9 +886,9 @@ __global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
             else if (kind == HEAVY_XMR) { if (val_monero(tb, tl, dec)) ty = IT_MONERO; }
             if (ty >= 0) { ct.start = ra.pos; ct.len_type = tl | ((uint32_t)ty << 24); em = true; }
         }
-        cw.append(em, ct, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+        cw.append(em, ct, p.cands, p.cand_cap, &p.counters->n_cand);
     }
-    cw.pad_rest(p.cands, p.cand_cap, SC);
+    cw.flush(p.cands, p.cand_cap, &p.counters->n_cand);
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
 }
 
