@@ -541,7 +541,8 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
     const uint32_t n = p.from_work ? min(p.counters->n_glob_work, p.glob_work_cap) : min(p.counters->n_cand, p.cand_cap);
     uint32_t stride = gridDim.x * blockDim.x;
     ChunkWriter<Hit, HIT_CHUNK> cw;
-    ChunkWriter<uint32_t, 64> ww;
+    __shared__ uint32_t wb_work[4][64];
+    BufferedWriter<uint32_t> ww(wb_work[threadIdx.x >> 6]);   // glob work list: sparse, dense output
     Hit SH{};
     SH.kind = 0xFF;
     // loop bound is wave-uniform so that the chunk writers see converged waves
@@ -590,10 +591,10 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
             }
             cw.append(emit, h, p.hits, p.hit_cap, &p.counters->n_hits, SH);
         }
-        if (!GLOB && p.ac_filter) ww.append(defer, i, p.glob_work, p.glob_work_cap, &p.counters->n_glob_work, 0xFFFFFFFFu);
+        if (!GLOB && p.ac_filter) ww.append(defer, i, p.glob_work, p.glob_work_cap, &p.counters->n_glob_work);
     }
     cw.pad_rest(p.hits, p.hit_cap, SH);
-    if (!GLOB && p.ac_filter) ww.pad_rest(p.glob_work, p.glob_work_cap, 0xFFFFFFFFu);
+    if (!GLOB && p.ac_filter) ww.flush(p.glob_work, p.glob_work_cap, &p.counters->n_glob_work);
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->hits_true, cw.total);
 }
 
