@@ -405,7 +405,6 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.filter_ac = (lookup && ac_ok) ? 1u : 0u;
     tp.filter_lit = (lookup && (!ddb_->view.has_glob || ac_ok)) ? 1u : 0u;
     if (const char* dbg = getenv("MATCHY_AMD_DEBUG")) tp.debug = (uint32_t)atoi(dbg);
-    tp.n_segs = (uint32_t)(((uint64_t)len + 1 + SEG_BYTES - 1) / SEG_BYTES);
     tp.cands = cands_.p; tp.cand_cap = (uint32_t)cands_.n;
     tp.rare = rare_.p; tp.rare_cap = (uint32_t)rare_.n;
     tp.tok = tok_.p; tp.tok_cap = (uint32_t)tok_.n;
@@ -424,6 +423,14 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         for (int k = 0; k < 4; ++k) if (o[k] > 0) gm[k] = o[k];
     }
     for (int& m : gm) m = std::max(1, std::min(m, 64));
+    {
+        // segment size: about three segments per wave of the full grid, within [SEG_MIN, SEG_MAX] (see scan_types.h)
+        const uint64_t waves = (uint64_t)n_cu_ * gm[0] * 4;
+        uint64_t sb = ((uint64_t)len / (waves * 3)) / SEG_ALIGN * SEG_ALIGN;
+        if (const char* e = getenv("MATCHY_AMD_SEG_KB")) sb = (uint64_t)atoi(e) * 1024 / SEG_ALIGN * SEG_ALIGN;
+        tp.seg_bytes = (uint32_t)std::min<uint64_t>(SEG_MAX, std::max<uint64_t>(SEG_MIN, sb));
+        tp.n_segs = (uint32_t)(((uint64_t)len + 1 + tp.seg_bytes - 1) / tp.seg_bytes);
+    }
     int grid_tok = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * gm[0]);
     if (grid_tok < 1) grid_tok = 1;
     if (profile_) MXY_HIP(hipEventRecord(ev_[0], stream));

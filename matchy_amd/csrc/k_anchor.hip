@@ -33,9 +33,9 @@ namespace mxy {
 constexpr int AW = 4;                   // waves per workgroup
 constexpr uint32_t BLK_BYTES = 1024;    // bytes per wave iteration
 constexpr uint32_t QCAP = 128;          // ring entries per wave and type
-constexpr uint32_t RAW_BYTES = 4096;    // raw-byte window per wave (circular, block granular)
+constexpr uint32_t RAW_BYTES = 8192;    // raw-byte window per wave (circular, block granular)
 constexpr uint32_t RAW_DW = RAW_BYTES / 4;
-static_assert(SEG_BYTES % RAW_BYTES == 0 && RAW_BYTES % BLK_BYTES == 0, "window wraps on block edges inside a segment");
+static_assert(SEG_ALIGN % RAW_BYTES == 0 && RAW_BYTES % BLK_BYTES == 0, "window wraps on block edges inside a segment");
 
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -264,9 +264,9 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     };
 
     for (uint32_t seg = gw; seg < p.n_segs; seg += nw) {
-        const uint32_t seg_start = seg * SEG_BYTES;
+        const uint32_t seg_start = seg * p.seg_bytes;
         // positions 0..len are scanned: position `len` (padding, class "boundary") closes a trailing token
-        const uint32_t seg_end = min(seg_start + SEG_BYTES, len + 1);
+        const uint32_t seg_end = min(seg_start + p.seg_bytes, len + 1);
         // classes of the 4 bytes in front of the segment (before the buffer: boundary), wave-uniform
         uint32_t carryP = C_B * LSB;
         if (seg_start) {
