@@ -213,6 +213,11 @@ void DeviceDb::upload(const DbImage& img, int dev) {
         }
         ip_bm24.upload(bm);
         view.ip_bm24 = ip_bm24.p;
+        {
+            uint64_t set = 0;
+            for (uint32_t wv : bm) set += (uint64_t)__builtin_popcount(wv);
+            view.ip_bm24_permille = (uint32_t)(set * 1000 / ((uint64_t)bm.size() * 32));
+        }
         bytes_uploaded += bm.size() * 4;
     }
     if (img.has_literal) {
@@ -415,7 +420,11 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     // larger grid only adds a partially filled second round). MATCHY_AMD_GRID=a,v,l overrides for experiments.
     // k_anchor: two full rounds of resident workgroups; k_validate: one; k_lookup: 2 per CU measured best (every wave
     // pads its last hit chunk, and more waves in flight only add contention on the random table accesses).
-    static const int occ_a = anchor_blocks_per_cu(), occ_v = validate_blocks_per_cu(false), occ_v_ac = validate_blocks_per_cu(true);
+    static const int occ_a8 = anchor_blocks_per_cu(false), occ_a4 = anchor_blocks_per_cu(true), occ_v = validate_blocks_per_cu(false), occ_v_ac = validate_blocks_per_cu(true);
+    // most IPv4 candidates survive the /24 filter (CIDR-heavy databases): k_anchor writes a candidate per line, more waves help
+    tp.small_window = (!lookup || ddb_->view.ip_bm24_permille > 250) ? 1u : 0u;   // (or every candidate is listed: extraction)
+    if (const char* w = getenv("MATCHY_AMD_WINDOW_KB")) tp.small_window = atoi(w) <= 4 ? 1u : 0u;
+    const int occ_a = tp.small_window ? occ_a4 : occ_a8;
     int gm[4] = {2 * occ_a, tp.filter_ac ? occ_v_ac : occ_v, 2, 2};
     if (const char* g = getenv("MATCHY_AMD_GRID")) {   // 0 keeps the default of that kernel
         int o[4] = {0, 0, 0, 0};

@@ -33,9 +33,12 @@ namespace mxy {
 constexpr int AW = 4;                   // waves per workgroup
 constexpr uint32_t BLK_BYTES = 1024;    // bytes per wave iteration
 constexpr uint32_t QCAP = 128;          // ring entries per wave and type
-constexpr uint32_t RAW_BYTES = 8192;    // raw-byte window per wave (circular, block granular)
-constexpr uint32_t RAW_DW = RAW_BYTES / 4;
-static_assert(SEG_ALIGN % RAW_BYTES == 0 && RAW_BYTES % BLK_BYTES == 0, "window wraps on block edges inside a segment");
+// Raw-byte window per wave (circular, block granular): the kernel is built for two sizes. 8 KiB lets the anchor rings fill
+// up before their oldest entry leaves the window (fuller drains: fewer instructions) but leaves room for 12 waves per CU;
+// 4 KiB keeps 16 — better when most IPv4 candidates survive the /24 filter and the kernel writes a candidate per line
+// (latency-sensitive). The host picks (TokParams::small_window).
+constexpr uint32_t RAW_BYTES_MAX = 8192;
+static_assert(SEG_ALIGN % RAW_BYTES_MAX == 0 && 4096 % BLK_BYTES == 0, "window wraps on block edges inside a segment");
 
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -46,11 +49,11 @@ __device__ __forceinline__ uint64_t shl_carry(uint64_t cur, uint64_t prev, int k
 
 // n_dw + 1 dwords of the circular window starting at absolute byte position `a`, shifted so that byte `a` is byte 0
 template <int N>
-__device__ __forceinline__ void raw_read(const uint32_t* raw32, uint32_t a, uint32_t (&out)[N]) {
+__device__ __forceinline__ void raw_read(const uint32_t* raw32, uint32_t raw_mask_dw, uint32_t a, uint32_t (&out)[N]) {
     const uint32_t i0 = a >> 2, sh = a & 3;
     uint32_t w[N + 1];
 #pragma unroll
-    for (int i = 0; i <= N; ++i) w[i] = raw32[(i0 + i) & (RAW_DW - 1)];
+    for (int i = 0; i <= N; ++i) w[i] = raw32[(i0 + i) & raw_mask_dw];
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
 }
@@ -58,6 +61,7 @@ __device__ __forceinline__ void raw_read(const uint32_t* raw32, uint32_t a, uint
 struct WaveCtx {
     const TokParams* p;
     const uint32_t* raw32;
+    uint32_t raw_mask_dw;      // window size in dwords - 1
     const uint32_t* bloom;
     const uint32_t* bm24;
     uint32_t res_lo, res_hi;   // absolute byte range currently held by the raw window
@@ -106,7 +110,7 @@ __device__ __forceinline__ void drain_v4(uint32_t* ring, uint32_t& head, uint32_
         bool ok;
         if (dot >= cx.res_lo + 4 && dot + 16 <= cx.res_hi) {
             uint32_t w[5];
-            raw_read<5>(cx.raw32, dot - 4, w);
+            raw_read<5>(cx.raw32, cx.raw_mask_dw, dot - 4, w);
             ok = d_ipv4_from_window(make_uint4(w[0], w[1], w[2], w[3]), w[4], dot, s, e, a);
         } else if (dot >= 4 && dot + 16 <= p.len) {
             ok = val_ipv4_fast(p.log, dot, s, e, a);          // window not resident (segment edges): HBM
@@ -151,7 +155,7 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
     if (have && !later) {
         keep = true;
         if (j >= cx.res_lo + 24 && j + 8 <= cx.res_hi) {
-            raw_read<8>(cx.raw32, j - 24, ctx);   // log[j-24, j+8): the last label starts at byte 24
+            raw_read<8>(cx.raw32, cx.raw_mask_dw, j - 24, ctx);   // log[j-24, j+8): the last label starts at byte 24
             have_ctx = true;
             // the label's 8-byte window as SWAR masks (no per-byte loop, no divergent control flow)
             constexpr uint64_t H = 0x8080808080808080ull;
@@ -172,7 +176,7 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
                 // a label of 8+ bytes: usually not the last one ("www.examplesite.com" at 'e'). Look 16 bytes further: a
                 // dot before the first non-domain byte settles it; otherwise it stays undecided (long last label)
                 uint32_t more[4];
-                raw_read<4>(cx.raw32, j + 8, more);
+                raw_read<4>(cx.raw32, cx.raw_mask_dw, j + 8, more);
                 const ByteMasks ma = domain_masks((uint64_t)more[0] | ((uint64_t)more[1] << 32));
                 const ByteMasks mb = domain_masks((uint64_t)more[2] | ((uint64_t)more[3] << 32));
                 const uint64_t na = ~ma.dc & H, nb = ~mb.dc & H;
@@ -201,7 +205,9 @@ __device__ __forceinline__ uint32_t from_next_lane(uint32_t v, uint32_t edge) {
 // index (0..3) of the highest non-zero byte of a word whose bytes are 0 or 1
 __device__ __forceinline__ uint32_t top_byte(uint32_t x) { return (31u - (uint32_t)__clz((int)x)) >> 3; }
 
+template <uint32_t RAW_BYTES>
 __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
+    constexpr uint32_t RAW_DW = RAW_BYTES / 4;
     __shared__ uint8_t ctab[256];
     __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
     __shared__ __attribute__((aligned(16))) uint32_t rawst[AW][RAW_DW];
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     const uint2 S64 = make_uint2(0xFFFFFFFFu, 0xFFu);
     uint2* rare_out = reinterpret_cast<uint2*>(p.rare);
     uint2* tok_out = reinterpret_cast<uint2*>(p.tok);
-    WaveCtx cx{&p, raw32, bloom, db.ip_bm24, 0u, 0u};
+    WaveCtx cx{&p, raw32, RAW_DW - 1, bloom, db.ip_bm24, 0u, 0u};
     PendingV4 pend;
 
     // 16 bytes of block `b` for this lane; positions >= len read as ' ' (a boundary, like the end of the buffer)
@@ -480,14 +486,17 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
 }
 
 // workgroups of k_anchor that are resident on one CU at the same time (register / LDS limited)
-int anchor_blocks_per_cu() {
+int anchor_blocks_per_cu(bool small_window) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_anchor, AW * 64, 0) != hipSuccess || n < 1) n = 4;
+    const hipError_t e = small_window ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_anchor<4096>, AW * 64, 0)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_anchor<8192>, AW * 64, 0);
+    if (e != hipSuccess || n < 1) n = small_window ? 4 : 3;
     return n;
 }
 
 void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_anchor, dim3(grid), dim3(AW * 64), 0, stream, p, db);
+    if (p.small_window) hipLaunchKernelGGL(k_anchor<4096>, dim3(grid), dim3(AW * 64), 0, stream, p, db);
+    else hipLaunchKernelGGL(k_anchor<8192>, dim3(grid), dim3(AW * 64), 0, stream, p, db);
 }
 
 }  // namespace mxy

@@ -52,6 +52,7 @@ struct PslSlot { uint64_t hash; uint32_t off; uint32_t len; };              // l
 struct DevDb {
     // IP tree, re-laid out as one uint2 {left,right} per node (records widened to 32 bit, host byte order)
     const uint2* ip_nodes;
+    uint32_t ip_bm24_permille; // share of set bits in ip_bm24 (how much of the IPv4 space the /24 filter lets through)
     const uint32_t* ip_bm24; // 2^24 bits: bit v set iff the first 24 IPv4 levels for prefix v do not end in "not found"
     const uint2* ip_l1;      // 65536 entries: outcome of the first 16 IPv4 levels (x = kind | prefix << 8, y = node / data offset)
     uint32_t node_count;
@@ -143,6 +144,7 @@ struct TokParams {
     uint32_t filter_lit;      // 1: domain candidates whose XXH64 is not in DevDb::lit_bm are counted but not listed ...
     uint32_t filter_ac;       // 1: ... unless their text reaches an output state of the glob automaton (databases with globs)
     uint32_t n_segs;
+    uint32_t small_window;    // k_anchor variant: 1 = 4 KiB raw window (16 waves per CU), 0 = 8 KiB (12 waves, fuller ring drains)
     uint32_t seg_bytes;       // bytes of log per wavefront work item: a multiple of SEG_ALIGN chosen from the batch length
     Candidate* cands;
     uint32_t cand_cap;
