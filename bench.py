@@ -194,6 +194,7 @@ def main():
         tj = json.load(open(ROOT / "profiles" / "r01_traffic.json"))
         if tj.get("bytes_per_gpu") == nbytes:
             key = {"k_anchor": "mxy::k_anchor", "k_validate_dom+k_validate": "mxy::k_validate_dom<false>", "k_rare": "mxy::k_rare", "k_lookup": "mxy::k_lookup<false>"}[dom_name]
+            key = next((k for k in tj["kernels"] if k.startswith(key)), key)   # template instantiations: mxy::k_anchor<8192u>
             traffic = tj["kernels"][key]["hbm_bytes"]
             tr_note = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
     except Exception:
