@@ -1,9 +1,9 @@
 // k_anchor — stage A1 of the `matchy match` hot path on gfx950: the streaming pass over the log.
 //
-// One wavefront owns one 16 KiB segment at a time (grid-stride). Per 1 KiB block:
+// One wavefront owns one segment of the log at a time (grid-stride; 8-64 KiB, TokParams::seg_bytes). Per 1 KiB block:
 //   * every lane loads 16 contiguous log bytes (one coalesced global_load_dwordx4 per lane = 1 KiB per wave; the next
 //     block's load is issued before the current block is processed),
-//   * the raw bytes go to a per-wave circular LDS window (RAW_BYTES) so that anchors can be processed later without
+//   * the raw bytes go to a per-wave circular LDS window (8 or 4 KiB) so that anchors can be processed later without
 //     touching HBM again; bytes become class bytes through a 256-entry LDS table,
 //   * each lane keeps the class bytes of its 16 positions in 4 registers, gets the neighbouring dwords with two DPP wave
 //     shifts and evaluates every anchor pattern for all 16 positions at once (SWAR: v_alignbyte + shifts + ands, result
