@@ -1,51 +1,53 @@
 // k_anchor — stage A1 of the `matchy match` hot path on gfx950: the streaming pass over the log.
 //
-// One wavefront owns one segment of the log at a time (grid-stride; 8-64 KiB, TokParams::seg_bytes). Per 1 KiB block:
-//   * every lane loads 16 contiguous log bytes (one coalesced global_load_dwordx4 per lane = 1 KiB per wave; the next
-//     block's load is issued before the current block is processed),
-//   * the raw bytes go to a per-wave circular LDS window (8 or 4 KiB) so that anchors can be processed later without
-//     touching HBM again; bytes become class bytes through a 256-entry LDS table,
-//   * each lane keeps the class bytes of its 16 positions in 4 registers, gets the neighbouring dwords with two DPP wave
-//     shifts and evaluates every anchor pattern for all 16 positions at once (SWAR: v_alignbyte + shifts + ands, result
-//     in bit 0 of each byte); lanes with a hit are compacted with ballot + v_mbcnt (wavefront ballot / prefix-sum)
-//     into per-type LDS rings, one compaction loop per block and type,
+// One wavefront owns one segment of the log at a time (grid-stride; 8-64 KiB, TokParams::seg_bytes) and walks it in blocks of
+// 2 KiB = 8 rows of 256 bytes. Per block:
+//   * every lane loads dword L of each row (8 coalesced global_load_dword, 256 contiguous bytes per wave instruction; the
+//     next block's loads are issued before the current block is processed) and copies them to a per-wave circular LDS
+//     window (8 KiB) in natural byte order, so that anchors can be processed later without touching HBM again;
+//   * BIT-SLICED front end (anchor_planes.h): an 8 x 8 bit-matrix transpose turns the lane's 8 dwords into the 8 bit
+//     planes of its 32 bytes (bit 8 b + q of plane c = bit c of byte b of row q), the byte classes (boundary, digit, '.',
+//     ':', '@', '\n', label byte, possible first byte of a public-suffix label) are boolean functions of those planes
+//     — one 32-bit operation classifies 32 log positions per lane, no table look-ups — and every anchor pattern is
+//     AND / OR of class planes shifted by 1..4 positions. "k positions earlier" is v_alignbyte(P, P of the previous
+//     dword, 4 - k): consecutive dwords of a row sit in consecutive lanes (one DPP wave shift per plane; lane 0 / lane 63
+//     wrap to the neighbouring row of lane 63 / lane 0, fixed up with a readlane and two scalar operations);
+//   * lanes with a hit are compacted with ballot + v_mbcnt (wavefront ballot / prefix-sum) into per-type LDS rings;
 //   * when a ring holds 64 anchors the whole wave processes them, one anchor per lane, from the LDS window:
 //     IPv4 anchors are fully validated (dotted-quad rules), checked against the database's /24 bitmap and leave as
 //     candidates; domain anchors pass a SWAR prefilter (a later dot owns the run; the run ends at a boundary; the last
 //     label is some public suffix's last label — Bloom filter) and the survivors leave with 32 bytes of context for
 //     k_validate_dom. Anchors whose look-ahead lies in the block that is not staged yet go back into the ring.
 //     Lists are written through wave-private chunks (one atomic per chunk, coalesced stores).
-// Tokens long enough to be hashes / crypto addresses (>= 26 bytes) are found without per-byte work: four ballots of
-// "my dword has no boundary byte" give one bit per dword, five set bits in a row below a token end are necessary
-// for such a token (scalar shift / and on the masks), and only then is the exact length computed.
+// Tokens long enough to be hashes / crypto addresses (>= 26 bytes) are found without per-byte work: one bit per dword
+// ("no boundary byte in it") travels five lanes down the wave (DPP rotate); a dword with a boundary byte whose five
+// predecessors are boundary-free closes a token of >= 20 bytes, and only then is the exact length computed from ballots.
 //
-// Anchor rules (exact-coverage arguments in DESIGN.md §Anchors; differential-tested against oracle/):
+// Anchor rules (exact-coverage arguments in DESIGN.md §Anchors; differential-tested against oracle/). The streaming
+// pass may list MORE positions than these rules (the look-ahead of the last bytes of a block is taken as "anything", the
+// first byte of a public-suffix label is a superset class): the drains and the validation kernels decide exactly.
 //   IPv4    '.' at j preceded by 1-3 digits preceded by a boundary / buffer start, followed by 1-3 digits and '.'
 //                                                                                    (ext:1120-1179, 813-869)
 //   domain  byte that can start a PSL last label at j, '.' at j-1, label byte at j-2 (ext:537-628)
 //   IPv6    "::" ending at j, no third ':' before it                                (ext:1044-1116)
 //   e-mail  '@' at j                                                                 (ext:1182-1196)
 //   token   boundary at j closing a token of length 26..62, 64, 90..110 or 128       (ext:1212-1409)
+#include "anchor_planes.h"
 #include "device_common.h"
 
 namespace mxy {
 
-constexpr int AW = 4;                   // waves per workgroup
-constexpr uint32_t BLK_BYTES = 1024;    // bytes per wave iteration
-constexpr uint32_t QCAP = 128;          // ring entries per wave and type
-// Raw-byte window per wave (circular, block granular): the kernel is built for two sizes. 8 KiB lets the anchor rings fill
-// up before their oldest entry leaves the window (fuller drains: fewer instructions) but leaves room for 12 waves per CU;
-// 4 KiB keeps 16 — better when most IPv4 candidates survive the /24 filter and the kernel writes a candidate per line
-// (latency-sensitive). The host picks (TokParams::small_window).
-constexpr uint32_t RAW_BYTES_MAX = 8192;
-static_assert(SEG_ALIGN % RAW_BYTES_MAX == 0 && 4096 % BLK_BYTES == 0, "window wraps on block edges inside a segment");
+constexpr int AW = 4;                       // waves per workgroup
+constexpr uint32_t BLK_BYTES = AB_BLOCK;    // bytes per wave iteration (8 rows of 256)
+constexpr uint32_t QCAP = 128;              // ring entries per wave and type
+// Raw-byte window per wave (circular, block granular): four blocks, so that the anchor rings fill up before their oldest
+// entry leaves the window (drains run with full lanes).
+constexpr uint32_t RAW_BYTES = 8192;
+static_assert(SEG_ALIGN % RAW_BYTES == 0 && RAW_BYTES % BLK_BYTES == 0 && RAW_BYTES >= 3 * BLK_BYTES, "window wraps on block edges inside a segment");
 
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
-
-// (cur << k) with the top k bits of prev shifted in at the bottom: bit i = "dword i-k", across the block edge
-__device__ __forceinline__ uint64_t shl_carry(uint64_t cur, uint64_t prev, int k) { return (cur << k) | (prev >> (64 - k)); }
 
 // n_dw + 1 dwords of the circular window starting at absolute byte position `a`, shifted so that byte `a` is byte 0
 template <int N>
@@ -195,20 +197,31 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
     __builtin_amdgcn_wave_barrier();
 }
 
-// value of lane-1 / lane+1 (DPP wave shift: no LDS traffic); lane 0 / lane 63 get `edge`
-__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v, uint32_t edge) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+// ---- cross-lane plumbing of the bit planes
+constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138, DPP_WAVE_ROR1 = 0x13C;
+// Plane word of the PREVIOUS dword of the byte stream for every lane: lane L-1's word; lane 0 gets lane 63's word moved
+// one row up (bit 8 b + q <- bit 8 b + q - 1) with the last row of the previous block (`carry`: that block's lane-63 word,
+// whose bits 8 b + 7 are row 7) coming in as row -1. Updates `carry` for the next block.
+__device__ __forceinline__ uint32_t plane_prev_dword(uint32_t P, uint32_t& carry) {
+    const uint32_t s63 = (uint32_t)__builtin_amdgcn_readlane((int)P, 63);
+    const uint32_t fix0 = ((s63 << 1) & 0xFEFEFEFEu) | ((carry >> 7) & 0x01010101u);
+    carry = s63;
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fix0, (int)P, DPP_WAVE_SHR1, 0xF, 0xF, false);
 }
-__device__ __forceinline__ uint32_t from_next_lane(uint32_t v, uint32_t edge) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+// Plane word of the NEXT dword: lane L+1's word; lane 63 gets lane 0's word moved one row down, and `ahead` for the
+// first dword of the next block (not loaded yet: all ones keeps look-ahead tests conservative)
+__device__ __forceinline__ uint32_t plane_next_dword(uint32_t P, uint32_t ahead) {
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)P, 0);
+    const uint32_t fix63 = ((s0 >> 1) & 0x7F7F7F7Fu) | ahead;
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fix63, (int)P, DPP_WAVE_SHL1, 0xF, 0xF, false);
 }
-// index (0..3) of the highest non-zero byte of a word whose bytes are 0 or 1
-__device__ __forceinline__ uint32_t top_byte(uint32_t x) { return (31u - (uint32_t)__clz((int)x)) >> 3; }
+// class of the byte k positions earlier / later (k = 1..4), aligned to this position
+template <int K> __device__ __forceinline__ uint32_t back(uint32_t P, uint32_t PV) { return K == 4 ? PV : __builtin_amdgcn_alignbyte(P, PV, 4 - K); }
+template <int K> __device__ __forceinline__ uint32_t ahead(uint32_t P, uint32_t NV) { return K == 4 ? NV : __builtin_amdgcn_alignbyte(NV, P, K); }
 
-template <uint32_t RAW_BYTES>
 __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     constexpr uint32_t RAW_DW = RAW_BYTES / 4;
-    __shared__ uint8_t ctab[256];
+    __shared__ uint8_t ctab[256];    // byte classes for the few bytes in front of a segment (the blocks themselves are bit-sliced)
     __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
     __shared__ __attribute__((aligned(16))) uint32_t rawst[AW][RAW_DW];
     __shared__ uint32_t q_v4[AW][QCAP];
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     __shared__ uint2 wb_misc[AW][64], wb_tok[AW][64];   // BufferedWriter staging
     __shared__ Candidate wb_cand[AW][64];
 
-    ctab[threadIdx.x] = (uint8_t)(class_of(threadIdx.x) | (((db.tld_first[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1) ? C_TLD1 : 0));
+    ctab[threadIdx.x] = (uint8_t)class_of(threadIdx.x);
     for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += AW * 64) bloom[i] = db.tld_bloom[i];
     __syncthreads();
 
@@ -229,42 +242,53 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     const bool en_v4 = (p.flags & EX_IPV4) != 0, en_dom = (p.flags & EX_DOMAINS) != 0;
     const bool en_v6 = (p.flags & EX_IPV6) != 0, en_at = (p.flags & EX_EMAILS) != 0;
     const bool en_tok = (p.flags & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
-    const bool en_rare_row = en_v6 || en_at;
-    static_assert(C_B == 1 && C_DIG == 2 && C_DOT == 4 && C_COLON == 8 && C_AT == 16 && C_LD == 32 && C_TLD1 == 128, "SWAR shifts below");
-    constexpr uint32_t LSB = 0x01010101u;
+    // the shipped public-suffix list only has last labels that start with 'a'..'z' or a byte >= 0x80; any other list
+    // switches the first-byte class to "any label byte or '-'"
+    bool tl_wide = false;
+    {
+        uint32_t outside = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t allowed = k >= 4 ? 0xFFFFFFFFu : (k == 3 ? 0x07FFFFFEu : 0u);   // 0x61..0x7A, 0x80..0xFF
+            outside |= db.tld_first[k] & ~allowed;
+        }
+        tl_wide = outside != 0;
+    }
 
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t nl_count = 0;                       // per-lane '\n' count, reduced once at the end
     uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0;   // ring heads / tails (wave-uniform)
     uint32_t v4_old = 0, dom_old = 0;            // block start of the oldest ring entry (valid while the ring is non-empty)
     BufferedWriter<Candidate> cw_cand(wb_cand[wave]);   // IPv4 candidates that pass the /24 bitmap are sparse
     DomWriter cw_dom;
     BufferedWriter<uint2> cw_misc(wb_misc[wave]), cw_tok(wb_tok[wave]);   // rare anchors and long tokens are sparse: dense lists
-    const uint2 S64 = make_uint2(0xFFFFFFFFu, 0xFFu);
     uint2* rare_out = reinterpret_cast<uint2*>(p.rare);
     uint2* tok_out = reinterpret_cast<uint2*>(p.tok);
     WaveCtx cx{&p, raw32, RAW_DW - 1, bloom, db.ip_bm24, 0u, 0u};
     PendingV4 pend;
+    const uint32_t lane_off = lane << 2;
+    const uint32_t lane0_ones = lane == 0 ? 0xFFFFFFFFu : 0u;
 
-    // 16 bytes of block `b` for this lane; positions >= len read as ' ' (a boundary, like the end of the buffer)
-    auto load_block = [&](uint32_t b, uint32_t (&w)[4]) {
-        const uint32_t pos0 = b + lane * 16;
-        if (pos0 + 16 <= len) {
-            // streamed once: a non-temporal load keeps the log from pushing the database's /24 bitmap (the one table
-            // this kernel reads at random) out of L2
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.log + pos0));
-            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    // dword `lane` of the 8 rows of block `b`; positions >= len read as ' ' (a boundary, like the end of the buffer)
+    auto load_block = [&](uint32_t b, uint32_t (&w)[8]) {
+        if (b + BLK_BYTES <= len) {
+            // streamed once: non-temporal loads keep the log from pushing the database's /24 bitmap (the one table this
+            // kernel reads at random) out of L2
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(p.log + b) + lane;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = __builtin_nontemporal_load(src + 64 * q);
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t x = 0;
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t pos0 = b + AB_ROW_BYTES * q + lane_off;
+                uint32_t x = 0x20202020u;
+                if (pos0 + 4 <= len) {
+                    x = *reinterpret_cast<const uint32_t*>(p.log + pos0);
+                } else if (pos0 < len) {
+                    x = 0;
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                    const uint32_t q = pos0 + k * 4 + bb;
-                    x |= (q < len ? (uint32_t)p.log[q] : (uint32_t)' ') << (8 * bb);
+                    for (int bb = 0; bb < 4; ++bb) x |= (pos0 + bb < len ? (uint32_t)p.log[pos0 + bb] : (uint32_t)' ') << (8 * bb);
                 }
-                w[k] = x;
+                w[q] = x;
             }
         }
     };
@@ -273,29 +297,29 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         const uint32_t seg_start = seg * p.seg_bytes;
         // positions 0..len are scanned: position `len` (padding, class "boundary") closes a trailing token
         const uint32_t seg_end = min(seg_start + p.seg_bytes, len + 1);
-        // classes of the 4 bytes in front of the segment (before the buffer: boundary), wave-uniform
-        uint32_t carryP = C_B * LSB;
+        // Plane carries = the word a lane 63 of a block in front of the segment would hold; only its row-7 bits (8 b + 7 =
+        // class of byte seg_start - 4 + b) are ever used. In front of the buffer: boundary.
+        uint32_t cB = 0x80808080u, cD = 0, cT = 0, cLD = 0, cC = 0;
         if (seg_start) {
-            carryP = 0;
-            for (uint32_t k = 0; k < 4; ++k) carryP |= (uint32_t)ctab[p.log[seg_start - 4 + k]] << (8 * k);
-            carryP = __builtin_amdgcn_readfirstlane(carryP);
+            uint32_t c4 = 0;
+            for (uint32_t k = 0; k < 4; ++k) c4 |= (uint32_t)ctab[p.log[seg_start - 4 + k]] << (8 * k);
+            c4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c4);
+            static_assert(C_B == 1 && C_DIG == 2 && C_DOT == 4 && C_COLON == 8 && C_LD == 32, "carry shifts");
+            cB = (c4 << 7) & 0x80808080u; cD = (c4 << 6) & 0x80808080u; cT = (c4 << 5) & 0x80808080u;
+            cC = (c4 << 4) & 0x80808080u; cLD = (c4 << 2) & 0x80808080u;
         }
-        // token state carried along the segment: position of the last boundary byte seen, and the boundary-free bits
-        // of the previous block's dwords (Zp[k] bit L = dword k of lane L). At a segment start nothing is known about
-        // the dwords before it, so they are taken as boundary-free (more exact checks, never fewer) and lastB comes
-        // from a 256-byte look-back.
-        int32_t lastB = -1;
-        uint64_t Zp[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        // Token state: the boundary plane of the previous block (row 7 = the 256 bytes in front of this block) and its
+        // "dword holds no boundary byte" bits. In front of the buffer: a boundary at position -1.
+        uint32_t Bprev = lane == 63 ? 0x80000000u : 0u, Gprev = 0;
         if (en_tok && seg_start) {
-            lastB = (int32_t)seg_start - 257;  // "far": a token reaching back this far is longer than 128 bytes
-            for (uint32_t base = seg_start - 256; base < seg_start; base += 64) {
-                const uint32_t c = ctab[p.log[base + lane]];
-                const uint64_t bm = __ballot(c & C_B);
-                if (bm) lastB = (int32_t)(base + 63 - __clzll((unsigned long long)bm));
-            }
+            const uint32_t x = *reinterpret_cast<const uint32_t*>(p.log + seg_start - AB_ROW_BYTES + lane_off);
+            const uint32_t c = (uint32_t)ctab[x & 0xFF] | ((uint32_t)ctab[(x >> 8) & 0xFF] << 8) | ((uint32_t)ctab[(x >> 16) & 0xFF] << 16) |
+                               ((uint32_t)ctab[x >> 24] << 24);
+            Bprev = (c << 7) & 0x80808080u;
+            Gprev = Bprev ? 0u : 0x80u;
         }
 
-        uint32_t nx[4];
+        uint32_t nx[8];
         load_block(seg_start, nx);
         for (uint32_t blk = seg_start; blk < seg_end; blk += BLK_BYTES) {
             // ---- anchors whose look-back bytes are about to be overwritten in the raw window leave first
@@ -304,72 +328,59 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                 if (v4t != v4h && v4_old <= lim) { drain_v4(rv4, v4h, v4t, v4t - v4h, false, cx, pend, cw_cand); v4_old = blk - BLK_BYTES; }
                 if (dt != dh && dom_old <= lim) { drain_dom(rdom, dh, dt, dt - dh, false, cx, cw_dom); dom_old = blk - BLK_BYTES; }
             }
-            // ---- this lane's 16 bytes: raw bytes into the window, bytes -> class bytes; prefetch the next block
-            uint32_t wv[4] = {nx[0], nx[1], nx[2], nx[3]};
-            if (blk + BLK_BYTES < seg_end) load_block(blk + BLK_BYTES, nx);
-            // X[0] = classes of the 4 bytes before this lane's bytes, X[1..4] = its own 16, X[5] = the 4 after
-            uint32_t X[6];
+            // ---- this lane's 8 dwords: raw bytes into the window (natural byte order); prefetch the next block
+            uint32_t w[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t x = wv[k];
-                X[k + 1] = (uint32_t)ctab[x & 0xFF] | ((uint32_t)ctab[(x >> 8) & 0xFF] << 8) | ((uint32_t)ctab[(x >> 16) & 0xFF] << 16) |
-                           ((uint32_t)ctab[x >> 24] << 24);
-                nl_count += __popc(X[k + 1] & (C_NL * LSB));
-            }
+            for (int q = 0; q < 8; ++q) w[q] = nx[q];
+            if (blk + BLK_BYTES < seg_end) load_block(blk + BLK_BYTES, nx);
             __builtin_amdgcn_wave_barrier();
-            *reinterpret_cast<uint4*>(&raw32[((blk & (RAW_BYTES - 1)) >> 2) + lane * 4]) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            {
+                uint32_t* dst = &raw32[((blk & (RAW_BYTES - 1)) >> 2) + lane];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dst[64 * q] = w[q];
+            }
             __builtin_amdgcn_wave_barrier();
             cx.res_hi = blk + BLK_BYTES;
             cx.res_lo = cx.res_hi - seg_start > RAW_BYTES ? cx.res_hi - RAW_BYTES : seg_start;
-            X[0] = from_prev_lane(X[4], carryP);
-            // the bytes after lane 63's are in the next block: "anything" (all class bits) keeps the look-ahead test of
-            // the IPv4 anchor conservative there
-            X[5] = from_next_lane(X[1], 0xFFFFFFFFu);
-            carryP = (uint32_t)__builtin_amdgcn_readlane((int)X[4], 63);
-            const uint32_t pos0 = blk + lane * 16;
 
-            // ---- every anchor pattern for the lane's 16 positions (SWAR on bit 0 of each byte, 4 dwords); the flags of
-            // dword k go to bit k of each byte: bit (8 b + k) <-> position 4 k + b
-            uint32_t Fd = 0, F4 = 0, Fm = 0, bl[4], A1s[4];
-            // byte-shifted views shared by neighbouring dwords: S1[k] = classes of positions (4k-3 .. 4k) seen from dword
-            // k-1/k, i.e. v_alignbyte(X[k+1], X[k], 1); the look-ahead views of dword k are the look-back views of k+1
-            uint32_t S1[5], S2[5], S3[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                S1[k] = __builtin_amdgcn_alignbyte(X[k + 1], X[k], 1);
-                S2[k] = __builtin_amdgcn_alignbyte(X[k + 1], X[k], 2);
-                S3[k] = __builtin_amdgcn_alignbyte(X[k + 1], X[k], 3);
+            // ---- bit planes and byte classes of the lane's 32 positions: bit t <-> position blk + 256 (t & 7) + 4 lane + (t >> 3)
+            bit_transpose8(w);
+            const ClassPlanes cl = classify_planes(w, tl_wide);
+            nl_count += __popc(cl.NL);
+            const uint32_t pos_base = blk + lane_off;
+
+            uint32_t Fd = 0, F4 = 0, F6 = 0;
+            uint32_t PV_T = 0;
+            if (en_v4 || en_dom) PV_T = plane_prev_dword(cl.T, cT);
+            if (en_v4) {
+                // '.' at j, digit at j-1, then boundary | digit,boundary | digit,digit,boundary ...
+                const uint32_t PV_D = plane_prev_dword(cl.D, cD), PV_B = plane_prev_dword(cl.B, cB);
+                const uint32_t lookback = back<1>(cl.D, PV_D) &
+                                          (back<2>(cl.B, PV_B) | (back<2>(cl.D, PV_D) & (back<3>(cl.B, PV_B) | (back<3>(cl.D, PV_D) & back<4>(cl.B, PV_B)))));
+                // ... and followed by a second octet and a second dot: digit, then '.' | digit,'.' | digit,digit,'.'
+                // (necessary for a dotted quad; drops "HTTP/1.1", "Mozilla/5.0", "Safari/537.36" style anchors)
+                const uint32_t NV_D = plane_next_dword(cl.D, 0x80808080u), NV_T = plane_next_dword(cl.T, 0x80808080u);
+                const uint32_t lookahead = ahead<1>(cl.D, NV_D) &
+                                           (ahead<2>(cl.T, NV_T) | (ahead<2>(cl.D, NV_D) & (ahead<3>(cl.T, NV_T) | (ahead<3>(cl.D, NV_D) & ahead<4>(cl.T, NV_T)))));
+                F4 = cl.T & lookback & lookahead;
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t A = X[k + 1], P = X[k], N = X[k + 2];
-                const uint32_t A1 = S3[k];  // classes of positions pos-1 .. pos+2
-                const uint32_t A2 = S2[k];  // pos-2 .. pos+1
-                const uint32_t A3 = S1[k];  // pos-3 .. pos
-                bl[k] = A & LSB;
-                A1s[k] = A1;
-                // domain: TLD1 at j (bit 7), '.' at j-1 (bit 2), label byte at j-2 (bit 5)
-                if (en_dom) Fd |= ((A >> 7) & (A1 >> 2) & (A2 >> 5) & LSB) << k;
-                if (en_v4) {
-                    // '.' at j (bit 2), digit at j-1 (bit 1), then boundary | digit,boundary | digit,digit,boundary
-                    uint32_t f = (A >> 2) & (A1 >> 1) & (A2 | ((A2 >> 1) & (A3 | ((A3 >> 1) & P)))) & LSB;
-                    // ... and followed by a second octet and a second dot: digit, then '.' | digit,'.' | digit,digit,'.'
-                    // (necessary for a dotted quad; drops "HTTP/1.1", "Mozilla/5.0", "Safari/537.36" style anchors)
-                    const uint32_t F1 = S1[k + 1], F2 = S2[k + 1], F3 = S3[k + 1];  // pos+1 .., pos+2 .., pos+3 ..
-                    f &= (F1 >> 1) & ((F2 >> 2) | ((F2 >> 1) & ((F3 >> 2) | ((F3 >> 1) & (N >> 2)))));
-                    F4 |= f << k;
-                }
-                // "::" ending at j without a third ':' (bit 3) -> flag bits 0..3; '@' at j (bit 4) -> flag bits 4..7
-                if (en_v6) Fm |= ((A >> 3) & (A1 >> 3) & ~(A2 >> 3) & LSB) << k;
-                if (en_at) Fm |= ((A >> 4) & LSB) << (4 + k);
+            if (en_dom) {
+                // byte that can start a public suffix's last label at j, '.' at j-1, label byte at j-2
+                const uint32_t PV_LD = plane_prev_dword(cl.LD, cLD);
+                Fd = cl.TL & back<1>(cl.T, PV_T) & back<2>(cl.LD, PV_LD);
+            }
+            if (en_v6) {
+                // "::" ending at j without a third ':'
+                const uint32_t PV_C = plane_prev_dword(cl.C, cC);
+                F6 = cl.C & back<1>(cl.C, PV_C) & ~back<2>(cl.C, PV_C);
             }
             if (en_dom) {
                 for (;;) {
                     const uint64_t m = __ballot(Fd != 0);
                     if (!m) break;
                     if (Fd) {
-                        const uint32_t bit = (uint32_t)(__ffs((int)Fd) - 1);
-                        rdom[(dt + mbcnt64(m)) & (QCAP - 1)] = pos0 + ((bit & 7) << 2) + (bit >> 3);
+                        const uint32_t t = (uint32_t)(__ffs((int)Fd) - 1);
+                        rdom[(dt + mbcnt64(m)) & (QCAP - 1)] = pos_base + ((t & 7) << 8) + (t >> 3);
                         Fd &= Fd - 1;
                     }
                     if (dt == dh) dom_old = blk;
@@ -382,8 +393,8 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                     const uint64_t m = __ballot(F4 != 0);
                     if (!m) break;
                     if (F4) {
-                        const uint32_t bit = (uint32_t)(__ffs((int)F4) - 1);
-                        rv4[(v4t + mbcnt64(m)) & (QCAP - 1)] = pos0 + ((bit & 7) << 2) + (bit >> 3);
+                        const uint32_t t = (uint32_t)(__ffs((int)F4) - 1);
+                        rv4[(v4t + mbcnt64(m)) & (QCAP - 1)] = pos_base + ((t & 7) << 8) + (t >> 3);
                         F4 &= F4 - 1;
                     }
                     if (v4t == v4h) v4_old = blk;
@@ -391,75 +402,78 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                     if (v4t - v4h >= 64) { drain_v4(rv4, v4h, v4t, 64u, false, cx, pend, cw_cand); v4_old = blk; }
                 }
             }
-            if (en_rare_row) {
-                for (;;) {
-                    const uint64_t m = __ballot(Fm != 0);
-                    if (!m) break;
-                    uint2 v = S64;
-                    const bool has = Fm != 0;
+            if (en_v6 || en_at) {
+                uint32_t FA = en_at ? cl.AT : 0u;
+                while (__ballot((F6 | FA) != 0)) {
+                    // one anchor per lane and round: "::" anchors first
+                    const bool has = (F6 | FA) != 0;
+                    uint2 v = make_uint2(0xFFFFFFFFu, 0xFFu);
                     if (has) {
-                        const uint32_t bit = (uint32_t)(__ffs((int)Fm) - 1);
-                        v = make_uint2(pos0 + ((bit & 3) << 2) + (bit >> 3), (bit & 4) ? (uint32_t)RARE_AT : (uint32_t)RARE_V6);
-                        Fm &= Fm - 1;
+                        const bool six = F6 != 0;
+                        const uint32_t f = six ? F6 : FA;
+                        const uint32_t t = (uint32_t)(__ffs((int)f) - 1);
+                        v = make_uint2(pos_base + ((t & 7) << 8) + (t >> 3), six ? (uint32_t)RARE_V6 : (uint32_t)RARE_AT);
+                        if (six) F6 &= F6 - 1; else FA &= FA - 1;
                     }
                     cw_misc.append(has, v, rare_out, p.rare_cap, &p.counters->n_rare);
                 }
             }
             if (en_tok) {
-                // Z[k]: bit L set when dword k of lane L holds no boundary byte (dword index in the block = 4 L + k)
-                uint64_t Z[4];
+                // nb: bit q set when this lane's dword of row q holds a boundary byte; G = the complement ("free" dwords)
+                const uint32_t nb = (cl.B | (cl.B >> 8) | (cl.B >> 16) | (cl.B >> 24)) & 0xFFu;
+                const uint32_t G = nb ^ 0xFFu;
+                // x: bit q + 1 = row q of this lane is free, bit 0 = row 7 of the previous block. The value travels down the
+                // wave (rotate by one lane per step); when it wraps from lane 63 to lane 0 it moves one row up, which is
+                // one bit to the left. After k steps x is the state of the dword k places earlier in the byte stream.
+                uint32_t x = (G << 1) | (Gprev >> 7), r5 = 0xFFFFFFFFu;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) Z[k] = __ballot(bl[k] == 0);
+                for (int k = 0; k < 5; ++k) {
+                    x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_WAVE_ROR1, 0xF, 0xF, false);
+                    x += x & lane0_ones;
+                    r5 &= x;
+                }
                 // A token of >= 26 bytes that ends in dword i leaves dwords i-1..i-5 boundary-free (necessary); only the
-                // lowest boundary byte of a dword can close a long token and it must follow a non-boundary byte.
-                uint32_t ck = 4;  // dword of this lane that may close a long token (at most one can)
-                uint64_t c5[4];   // scalar masks: bit L = dwords i-1..i-5 of dword (L, k) are boundary-free
+                // lowest boundary byte of a dword can close a long token.
+                const uint32_t cand = (r5 >> 1) & nb;
+                if (__ballot(cand != 0)) {
+                    const uint64_t Zp = __ballot((Gprev & 0x80u) != 0);   // free dwords of the previous block's last row
+                    uint64_t Zprev_row = Zp;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint64_t c = ~0ull;
-#pragma unroll
-                    for (int t = 1; t <= 5; ++t) {
-                        int idx = k - t, sh = 0;
-                        while (idx < 0) { idx += 4; ++sh; }
-                        c &= sh ? shl_carry(Z[idx], Zp[idx], sh) : Z[idx];
+                    for (int q = 0; q < 8; ++q) {
+                        const uint64_t Zq = __ballot(((G >> q) & 1u) != 0);
+                        const bool mine = ((cand >> q) & 1u) != 0;
+                        if (__ballot(mine)) {
+                            // free dwords directly below this one: in this row, then at the end of the previous row
+                            const uint64_t below = lane ? (Zq << (64 - lane)) : 0ull;          // bit 63 = dword lane-1
+                            uint32_t run = lane ? (uint32_t)__clzll((long long)~below) : 0u;   // ~below != 0 for lane < 64... see min
+                            run = min(run, lane);
+                            bool too_long = false;
+                            if (run == lane) {
+                                const uint32_t r2 = ~Zprev_row ? (uint32_t)__clzll((long long)~Zprev_row) : 64u;
+                                too_long = r2 == 64u;   // 64 + free dwords = more than 256 bytes: longer than any token
+                                run += r2;
+                            }
+                            // the dword below the run holds the last boundary byte before the token
+                            const int32_t it = (int32_t)(64 * q + lane) - (int32_t)run - 1;    // dword index in the block (negative: previous block)
+                            const uint32_t src_lane = (uint32_t)it & 63u;
+                            const uint32_t wb_cur = (uint32_t)__shfl((int)cl.B, (int)src_lane);
+                            const uint32_t wb_prev = (uint32_t)__shfl((int)Bprev, (int)src_lane);
+                            const uint32_t rowbits = it >= 0 ? ((wb_cur >> (it >> 6)) & 0x01010101u) : ((wb_prev >> 7) & 0x01010101u);
+                            const uint32_t hb = rowbits ? (31u - (uint32_t)__clz((int)rowbits)) >> 3 : 0u;
+                            const int32_t s = (int32_t)blk + 4 * it + (int32_t)hb + 1;         // token start
+                            const uint32_t mybits = (cl.B >> q) & 0x01010101u;
+                            const uint32_t b0 = mybits ? ((uint32_t)__ffs((int)mybits) - 1u) >> 3 : 0u;
+                            const uint32_t e = blk + AB_ROW_BYTES * q + lane_off + b0;          // closing boundary
+                            const uint32_t tl = e - (uint32_t)s;
+                            const bool tok = mine && !too_long && rowbits != 0 &&
+                                             ((tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128);
+                            cw_tok.append(tok, make_uint2((uint32_t)s, (uint32_t)RARE_TOK | (tl << 8)), tok_out, p.tok_cap, &p.counters->n_tok);
+                        }
+                        Zprev_row = Zq;
                     }
-                    c5[k] = c;
                 }
-                // logs rarely hold 20+ boundary-free bytes: the per-lane tests run only when some dword qualifies
-                if (c5[0] | c5[1] | c5[2] | c5[3]) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t low = bl[k] & (0u - bl[k]);
-                        if ((low & ~A1s[k]) != 0 && ((c5[k] >> lane) & 1)) ck = k;
-                    }
-                }
-                const uint64_t anyB = ~(Z[0] & Z[1] & Z[2] & Z[3]);  // lanes with at least one boundary byte
-                const uint64_t cm = __ballot(ck < 4);
-                if (cm) {
-                    // exact length: the last boundary before the closing dword is the highest boundary byte of the
-                    // nearest lower lane that has one (the 5 dwords in between are free), else the carried lastB
-                    const uint32_t hb = bl[3] ? 12 + top_byte(bl[3]) : bl[2] ? 8 + top_byte(bl[2]) : bl[1] ? 4 + top_byte(bl[1]) : top_byte(bl[0] | 1u);
-                    const uint64_t mlt = anyB & lt_mask;
-                    const uint32_t e = mlt ? (uint32_t)(63 - __clzll((unsigned long long)mlt)) : 0u;
-                    const uint32_t hbe = (uint32_t)__shfl((int)hb, (int)e);
-                    const int32_t lb = mlt ? (int32_t)(blk + e * 16 + hbe) : lastB;
-                    const uint32_t blk_k = ck == 0 ? bl[0] : ck == 1 ? bl[1] : ck == 2 ? bl[2] : bl[3];
-                    const uint32_t low = blk_k & (0u - blk_k);
-                    const uint32_t j = pos0 + (ck & 3) * 4 + (low ? ((uint32_t)(__ffs((int)low) - 1) >> 3) : 0u);
-                    const uint32_t tl = (uint32_t)((int32_t)j - 1 - lb);
-                    const bool tok = ck < 4 && ((tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128);
-                    cw_tok.append(tok, make_uint2(j - tl, (uint32_t)RARE_TOK | (tl << 8)), tok_out, p.tok_cap, &p.counters->n_tok);
-                }
-                // carry: last boundary byte of this block (scalar: the highest lane with a boundary), and the Z bits
-                if (anyB) {
-                    const uint32_t e = (uint32_t)(63 - __clzll((unsigned long long)anyB));
-                    const uint32_t s3 = (uint32_t)__builtin_amdgcn_readlane((int)bl[3], (int)e), s2 = (uint32_t)__builtin_amdgcn_readlane((int)bl[2], (int)e);
-                    const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)bl[1], (int)e), s0 = (uint32_t)__builtin_amdgcn_readlane((int)bl[0], (int)e);
-                    const uint32_t hbs = s3 ? 12 + top_byte(s3) : s2 ? 8 + top_byte(s2) : s1 ? 4 + top_byte(s1) : top_byte(s0 | 1u);
-                    lastB = (int32_t)(blk + e * 16 + hbs);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) Zp[k] = Z[k];
+                Gprev = G;
+                Bprev = cl.B;
             }
         }
         // the next segment of this wave is not contiguous: finish the rings while their bytes are still in the window
@@ -486,17 +500,15 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
 }
 
 // workgroups of k_anchor that are resident on one CU at the same time (register / LDS limited)
-int anchor_blocks_per_cu(bool small_window) {
+int anchor_blocks_per_cu(bool) {
     int n = 0;
-    const hipError_t e = small_window ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_anchor<4096>, AW * 64, 0)
-                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_anchor<8192>, AW * 64, 0);
-    if (e != hipSuccess || n < 1) n = small_window ? 4 : 3;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_anchor, AW * 64, 0);
+    if (e != hipSuccess || n < 1) n = 3;
     return n;
 }
 
 void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
-    if (p.small_window) hipLaunchKernelGGL(k_anchor<4096>, dim3(grid), dim3(AW * 64), 0, stream, p, db);
-    else hipLaunchKernelGGL(k_anchor<8192>, dim3(grid), dim3(AW * 64), 0, stream, p, db);
+    hipLaunchKernelGGL(k_anchor, dim3(grid), dim3(AW * 64), 0, stream, p, db);
 }
 
 }  // namespace mxy
