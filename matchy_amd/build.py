@@ -32,6 +32,8 @@ def build(force=False, verbose=False):
     objs = []
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
              "-Wno-unused-result", "-DNDEBUG"]
+    # throw-away instrumented builds (kernel experiments): MATCHY_AMD_CFLAGS="-DMXY_ANCHOR_DEBUG" python -m matchy_amd.build --force
+    flags += os.environ.get("MATCHY_AMD_CFLAGS", "").split()
     procs = []
     for src in SOURCES:
         obj = LIBDIR / (src.rsplit(".", 1)[0] + ".o")

@@ -45,25 +45,41 @@ constexpr uint32_t QCAP = 128;              // ring entries per wave and type
 constexpr uint32_t RAW_BYTES = 8192;
 static_assert(SEG_ALIGN % RAW_BYTES == 0 && RAW_BYTES % BLK_BYTES == 0 && RAW_BYTES >= 3 * BLK_BYTES, "window wraps on block edges inside a segment");
 
+// base + number of set bits of m below this lane
+__device__ __forceinline__ uint32_t mbcnt64_add(uint64_t m, uint32_t base) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
+}
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// n_dw + 1 dwords of the circular window starting at absolute byte position `a`, shifted so that byte `a` is byte 0
+// N dwords of the circular window starting at absolute byte position `a`, shifted so that byte `a` is byte 0. The first
+// RAW_MIRROR bytes of the window are kept a second time behind its end, so a read that starts near the end runs straight on
+// (constant offsets: ds_read2_b32 pairs, no wrap arithmetic per dword).
+constexpr uint32_t RAW_MIRROR = 64;
 template <int N>
-__device__ __forceinline__ void raw_read(const uint32_t* raw32, uint32_t raw_mask_dw, uint32_t a, uint32_t (&out)[N]) {
-    const uint32_t i0 = a >> 2, sh = a & 3;
+__device__ __forceinline__ void raw_read(const uint32_t* raw32, uint32_t a, uint32_t (&out)[N]) {
+    static_assert(4 * (N + 1) <= RAW_MIRROR + 4, "read runs past the mirrored bytes");
+    const uint32_t* q = raw32 + ((a & (RAW_BYTES - 1)) >> 2);
+    const uint32_t sh = a & 3;
     uint32_t w[N + 1];
 #pragma unroll
-    for (int i = 0; i <= N; ++i) w[i] = raw32[(i0 + i) & raw_mask_dw];
+    for (int i = 0; i <= N; ++i) w[i] = q[i];
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
+}
+
+// Ring entry of an anchor found at bit t of lane L of the block that starts at blk (a multiple of 2048): blk | L << 5 | t.
+// The compaction loops run once per anchor of the busiest lane, the drains once per 64 anchors, so the position is
+// decoded in the drain.
+__device__ __forceinline__ uint32_t anchor_pos(uint32_t e) {
+    return (e & ~(BLK_BYTES - 1)) + ((e & 7u) << 8) + ((e >> 3) & 0xFCu) + ((e >> 3) & 3u);
 }
 
 struct WaveCtx {
     const TokParams* p;
     const uint32_t* raw32;
-    uint32_t raw_mask_dw;      // window size in dwords - 1
+    const uint8_t* ctab;       // byte classes (LDS)
     const uint32_t* bloom;
     const uint32_t* bm24;
     uint32_t res_lo, res_hi;   // absolute byte range currently held by the raw window
@@ -87,6 +103,50 @@ __device__ __forceinline__ void commit_v4(PendingV4& pd, const WaveCtx& cx, Buff
     pd.ok = false;
 }
 
+// IPv4 dotted-quad rules (ext:813-869, 1120-1179) on the 20 bytes w[0] = [dot-4, dot), w[1..4] = [dot, dot+16) of a '.':
+// accepts iff the maximal [0-9.] run around the dot is a valid dotted quad whose FIRST dot this is, delimited by
+// boundaries (N1). Octet values come from v_dot4_u32_u8 (digit bytes x decimal weights), the digit tests are byte-lane
+// SWAR, and the rejections are collected in one integer (`bad`) instead of per-test branch masks.
+__device__ __forceinline__ bool d_ipv4_lean(const uint32_t (&w)[5], const uint8_t* ctab, uint32_t dot, uint32_t& start, uint32_t& end, uint32_t& addr) {
+    constexpr uint32_t WEIGHTS = 0x00010A64u;   // bytes 0..2 = 100, 10, 1
+    // bit 7 of every byte of (bytes ^ '0') that is not a digit value 0..9
+    auto nondigit = [](uint32_t x) { return (((x & 0x7F7F7F7Fu) + 0x76767676u) | x) & 0x80808080u; };
+    // first octet, right to left from dot-1 (byte 3 of w[0]): n1 = digits in front of the dot (a 4th digit shows up as a
+    // non-boundary byte in front of the octet)
+    const uint32_t x0 = w[0] ^ 0x30303030u;
+    const uint32_t lz = (uint32_t)__clz((int)(nondigit(x0) | 0x80u));   // 0, 8, 16 or 24
+    const uint32_t before = (w[0] >> ((24u - lz) & 31u)) & 0xFFu;
+    uint32_t bad = (lz == 0) | !(ctab[before] & C_B);
+    const uint32_t d0 = x0 >> ((32u - lz) & 31u);                        // the octet's digits, most significant in byte 0
+    uint32_t a = __builtin_amdgcn_udot4(d0, WEIGHTS >> ((24u - lz) & 31u), 0u, false);
+    bad |= (a >> 8) | ((lz > 8) & ((d0 & 0xFFu) == 0));                  // > 255, leading zero
+    // r0..r2 = the 12 bytes after the dot
+    uint32_t r0 = __builtin_amdgcn_alignbyte(w[2], w[1], 1), r1 = __builtin_amdgcn_alignbyte(w[3], w[2], 1), r2 = __builtin_amdgcn_alignbyte(w[4], w[3], 1);
+    uint32_t pos = dot + 1;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const uint32_t x = r0 ^ 0x30303030u;
+        const uint32_t f = (uint32_t)__builtin_ctz(nondigit(x) | 0x80000000u);   // 7, 15, 23, 31 <-> 0..3 digits (a 4th digit = bad separator)
+        const uint32_t n = f >> 3;
+        const uint32_t sep = (r0 >> (f - 7u)) & 0xFFu;
+        const uint32_t v = __builtin_amdgcn_udot4(x, WEIGHTS >> (31u - f), 0u, false);
+        bad |= (f == 7) | (v >> 8) | ((f > 15) & ((x & 0xFFu) == 0));
+        a = (a << 8) | v;
+        pos += n;
+        if (o < 2) {
+            bad |= sep ^ (uint32_t)'.';
+            pos += 1;
+            // drop n + 1 bytes: first n (0..3), then one more
+            r0 = __builtin_amdgcn_alignbyte(r1, r0, n); r1 = __builtin_amdgcn_alignbyte(r2, r1, n); if (o == 0) r2 = __builtin_amdgcn_alignbyte(0u, r2, n);
+            r0 = __builtin_amdgcn_alignbyte(r1, r0, 1); if (o == 0) { r1 = __builtin_amdgcn_alignbyte(r2, r1, 1); }
+        } else {
+            bad |= !(ctab[sep] & C_B);
+        }
+    }
+    start = dot - (lz >> 3); end = pos; addr = a;
+    return bad == 0;
+}
+
 __device__ __forceinline__ void drain_v4(uint32_t* ring, uint32_t& head, uint32_t& tail, uint32_t n, bool final, const WaveCtx& cx,
                                          PendingV4& pd, BufferedWriter<Candidate>& cw) {
     const uint32_t lane = lane_id();
@@ -94,37 +154,41 @@ __device__ __forceinline__ void drain_v4(uint32_t* ring, uint32_t& head, uint32_
     commit_v4(pd, cx, cw);
     __builtin_amdgcn_wave_barrier();
     const bool have = lane < n;
-    uint32_t dot = 0;
-    if (have) dot = ring[(head + lane) & (QCAP - 1)];
+    uint32_t ent = 0;
+    if (have) ent = ring[(head + lane) & (QCAP - 1)];
+    const uint32_t dot = anchor_pos(ent);
     head += n;
     // an anchor in the last bytes of the newest block has its look-ahead in the block that is not staged yet: it goes
-    // back into the ring and is validated by a later drain (without this nearly every drain would drag one lane
-    // through the global-memory fallback below)
+    // back into the ring and is validated by a later drain
     const bool later = have && !final && dot + 16 > cx.res_hi;
     const uint64_t rm = __ballot(later);
     if (rm) {
         __builtin_amdgcn_wave_barrier();
-        if (later) ring[(tail + mbcnt64(rm)) & (QCAP - 1)] = dot;
+        if (later) ring[(tail + mbcnt64(rm)) & (QCAP - 1)] = ent;
         tail += (uint32_t)__popcll(rm);
     }
-    if (have && !later) {
-        uint32_t s = 0, e = 0, a = 0;
-        bool ok;
-        if (dot >= cx.res_lo + 4 && dot + 16 <= cx.res_hi) {
-            uint32_t w[5];
-            raw_read<5>(cx.raw32, cx.raw_mask_dw, dot - 4, w);
-            ok = d_ipv4_from_window(make_uint4(w[0], w[1], w[2], w[3]), w[4], dot, s, e, a);
-        } else if (dot >= 4 && dot + 16 <= p.len) {
-            ok = val_ipv4_fast(p.log, dot, s, e, a);          // window not resident (segment edges): HBM
-        } else {
-            ok = val_ipv4(LogView{p.log, p.len}, dot, s, e, a);  // buffer edge
-        }
-        if (ok) {
-            pd.c.start = s; pd.c.len_type = (e - s) | ((uint32_t)IT_IPV4 << 24); pd.c.v4 = a;
-            pd.ok = true;
-            pd.n_valid += 1;
-            pd.word = p.filter_v4 ? cx.bm24[a >> 13] : 0xFFFFFFFFu;
-        }
+#ifdef MXY_ANCHOR_DEBUG
+    if (p.debug & 1) return;
+#endif
+    const bool go = have && !later;
+    // the 20 bytes around the dot come from the LDS window (positions >= len are staged as ' ', a boundary like the end of the
+    // buffer); only anchors in the first bytes of a segment or at its very end (final drain) read the log itself
+    const bool in_window = dot >= cx.res_lo + 4 && dot + 16 <= cx.res_hi;
+    uint32_t s = 0, e = 0, a = 0;
+    bool ok = false;
+    if (go && in_window) {
+        uint32_t w[5];
+        raw_read<5>(cx.raw32, dot - 4, w);
+        ok = d_ipv4_lean(w, cx.ctab, dot, s, e, a);
+    }
+    if (__ballot(go && !in_window)) {
+        if (go && !in_window) ok = val_ipv4(LogView{p.log, p.len}, dot, s, e, a);
+    }
+    if (ok) {
+        pd.c.start = s; pd.c.len_type = (e - s) | ((uint32_t)IT_IPV4 << 24); pd.c.v4 = a;
+        pd.ok = true;
+        pd.n_valid += 1;
+        pd.word = p.filter_v4 ? cx.bm24[a >> 13] : 0xFFFFFFFFu;
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -138,26 +202,30 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
     const uint32_t lane = lane_id();
     const TokParams& p = *cx.p;
     __builtin_amdgcn_wave_barrier();
-    uint32_t j = 0xFFFFFFFFu;
+    uint32_t ent = 0;
     bool keep = false, have_ctx = false;
     uint32_t ctx[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) ctx[k] = 0;
     const bool have = lane < n;
-    if (have) j = ring[(head + lane) & (QCAP - 1)];
+    if (have) ent = ring[(head + lane) & (QCAP - 1)];
+    const uint32_t j = have ? anchor_pos(ent) : 0xFFFFFFFFu;
     head += n;
     // label window not staged yet (anchor in the last bytes of the newest block): back into the ring for a later drain
     const bool later = have && !final && j + 8 > cx.res_hi;
     const uint64_t rm = __ballot(later);
     if (rm) {
         __builtin_amdgcn_wave_barrier();
-        if (later) ring[(tail + mbcnt64(rm)) & (QCAP - 1)] = j;
+        if (later) ring[(tail + mbcnt64(rm)) & (QCAP - 1)] = ent;
         tail += (uint32_t)__popcll(rm);
     }
+#ifdef MXY_ANCHOR_DEBUG
+    if (p.debug & 2) return;
+#endif
     if (have && !later) {
         keep = true;
         if (j >= cx.res_lo + 24 && j + 8 <= cx.res_hi) {
-            raw_read<8>(cx.raw32, cx.raw_mask_dw, j - 24, ctx);   // log[j-24, j+8): the last label starts at byte 24
+            raw_read<8>(cx.raw32, j - 24, ctx);   // log[j-24, j+8): the last label starts at byte 24
             have_ctx = true;
             // the label's 8-byte window as SWAR masks (no per-byte loop, no divergent control flow)
             constexpr uint64_t H = 0x8080808080808080ull;
@@ -178,7 +246,7 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
                 // a label of 8+ bytes: usually not the last one ("www.examplesite.com" at 'e'). Look 16 bytes further: a
                 // dot before the first non-domain byte settles it; otherwise it stays undecided (long last label)
                 uint32_t more[4];
-                raw_read<4>(cx.raw32, cx.raw_mask_dw, j + 8, more);
+                raw_read<4>(cx.raw32, j + 8, more);
                 const ByteMasks ma = domain_masks((uint64_t)more[0] | ((uint64_t)more[1] << 32));
                 const ByteMasks mb = domain_masks((uint64_t)more[2] | ((uint64_t)more[3] << 32));
                 const uint64_t na = ~ma.dc & H, nb = ~mb.dc & H;
@@ -190,11 +258,23 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
     }
     const uint32_t slot = dw.reserve(keep, p.dom_list, p.dom_cap, &p.counters->n_dom);
     if (slot != 0xFFFFFFFFu) {
-        p.dom_list[dom_plane_index(slot, 0)] = have_ctx ? j : (j | 0x80000000u);
+        uint32_t* rec = p.dom_list + dom_plane_index(slot, 0);   // the planes of a 64-slot tile are 256 bytes apart
+        rec[0] = have_ctx ? j : (j | 0x80000000u);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) p.dom_list[dom_plane_index(slot, 1 + k)] = ctx[k];
+        for (int k = 0; k < 8; ++k) rec[(1 + k) * DOM_TILE] = ctx[k];
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+// The shipped public-suffix list only has last labels that start with 'a'..'z' or a byte >= 0x80 (ClassPlanes::TL); any other
+// list switches the first-byte class to "any label byte or '-'".
+__host__ __device__ inline bool anchor_tl_wide(const DevDb& db) {
+    uint32_t outside = 0;
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t allowed = k >= 4 ? 0xFFFFFFFFu : (k == 3 ? 0x07FFFFFEu : 0u);   // 0x61..0x7A, 0x80..0xFF
+        outside |= db.tld_first[k] & ~allowed;
+    }
+    return outside != 0;
 }
 
 // ---- cross-lane plumbing of the bit planes
@@ -219,11 +299,14 @@ __device__ __forceinline__ uint32_t plane_next_dword(uint32_t P, uint32_t ahead)
 template <int K> __device__ __forceinline__ uint32_t back(uint32_t P, uint32_t PV) { return K == 4 ? PV : __builtin_amdgcn_alignbyte(P, PV, 4 - K); }
 template <int K> __device__ __forceinline__ uint32_t ahead(uint32_t P, uint32_t NV) { return K == 4 ? NV : __builtin_amdgcn_alignbyte(NV, P, K); }
 
+// ALL: every extractor is enabled and the public-suffix first-byte class is the narrow one (the command line's and the
+// bulk scan's configuration): no run-time flag tests in the block loop.
+template <bool ALL>
 __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     constexpr uint32_t RAW_DW = RAW_BYTES / 4;
     __shared__ uint8_t ctab[256];    // byte classes for the few bytes in front of a segment (the blocks themselves are bit-sliced)
     __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
-    __shared__ __attribute__((aligned(16))) uint32_t rawst[AW][RAW_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t rawst[AW][RAW_DW + RAW_MIRROR / 4];
     __shared__ uint32_t q_v4[AW][QCAP];
     __shared__ uint32_t q_dom[AW][QCAP];
     __shared__ uint2 wb_misc[AW][64], wb_tok[AW][64];   // BufferedWriter staging
@@ -233,27 +316,18 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += AW * 64) bloom[i] = db.tld_bloom[i];
     __syncthreads();
 
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // readfirstlane: tells the compiler that the wave index — and with it the segment loop, the block position and the ring
+    // heads / tails — is wave-uniform (scalar registers and scalar branches instead of vector ones)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t gw = blockIdx.x * AW + wave, nw = gridDim.x * AW;
     uint32_t* raw32 = rawst[wave];
     uint32_t* rv4 = q_v4[wave];
     uint32_t* rdom = q_dom[wave];
     const uint32_t len = p.len;
-    const bool en_v4 = (p.flags & EX_IPV4) != 0, en_dom = (p.flags & EX_DOMAINS) != 0;
-    const bool en_v6 = (p.flags & EX_IPV6) != 0, en_at = (p.flags & EX_EMAILS) != 0;
-    const bool en_tok = (p.flags & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
-    // the shipped public-suffix list only has last labels that start with 'a'..'z' or a byte >= 0x80; any other list
-    // switches the first-byte class to "any label byte or '-'"
-    bool tl_wide = false;
-    {
-        uint32_t outside = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t allowed = k >= 4 ? 0xFFFFFFFFu : (k == 3 ? 0x07FFFFFEu : 0u);   // 0x61..0x7A, 0x80..0xFF
-            outside |= db.tld_first[k] & ~allowed;
-        }
-        tl_wide = outside != 0;
-    }
+    const bool en_v4 = ALL || (p.flags & EX_IPV4) != 0, en_dom = ALL || (p.flags & EX_DOMAINS) != 0;
+    const bool en_v6 = ALL || (p.flags & EX_IPV6) != 0, en_at = ALL || (p.flags & EX_EMAILS) != 0;
+    const bool en_tok = ALL || (p.flags & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
+    const bool tl_wide = !ALL && anchor_tl_wide(db);
 
     uint32_t nl_count = 0;                       // per-lane '\n' count, reduced once at the end
     uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0;   // ring heads / tails (wave-uniform)
@@ -263,7 +337,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     BufferedWriter<uint2> cw_misc(wb_misc[wave]), cw_tok(wb_tok[wave]);   // rare anchors and long tokens are sparse: dense lists
     uint2* rare_out = reinterpret_cast<uint2*>(p.rare);
     uint2* tok_out = reinterpret_cast<uint2*>(p.tok);
-    WaveCtx cx{&p, raw32, RAW_DW - 1, bloom, db.ip_bm24, 0u, 0u};
+    WaveCtx cx{&p, raw32, ctab, bloom, db.ip_bm24, 0u, 0u};
     PendingV4 pend;
     const uint32_t lane_off = lane << 2;
     const uint32_t lane0_ones = lane == 0 ? 0xFFFFFFFFu : 0u;
@@ -310,13 +384,13 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         }
         // Token state: the boundary plane of the previous block (row 7 = the 256 bytes in front of this block) and its
         // "dword holds no boundary byte" bits. In front of the buffer: a boundary at position -1.
-        uint32_t Bprev = lane == 63 ? 0x80000000u : 0u, Gprev = 0;
+        uint32_t Bprev = lane == 63 ? 0x80000000u : 0u, Sprev = 0;
         if (en_tok && seg_start) {
             const uint32_t x = *reinterpret_cast<const uint32_t*>(p.log + seg_start - AB_ROW_BYTES + lane_off);
             const uint32_t c = (uint32_t)ctab[x & 0xFF] | ((uint32_t)ctab[(x >> 8) & 0xFF] << 8) | ((uint32_t)ctab[(x >> 16) & 0xFF] << 16) |
                                ((uint32_t)ctab[x >> 24] << 24);
             Bprev = (c << 7) & 0x80808080u;
-            Gprev = Bprev ? 0u : 0x80u;
+            Sprev = (Bprev ? 0u : 0x80u) | ((Bprev & 0x80808000u) ? 0u : 0x800000u);   // row 7: free / bytes 1..3 free
         }
 
         uint32_t nx[8];
@@ -338,6 +412,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                 uint32_t* dst = &raw32[((blk & (RAW_BYTES - 1)) >> 2) + lane];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) dst[64 * q] = w[q];
+                if ((blk & (RAW_BYTES - 1)) == 0 && lane < RAW_MIRROR / 4) raw32[RAW_DW + lane] = w[0];   // mirror of the window's first bytes
             }
             __builtin_amdgcn_wave_barrier();
             cx.res_hi = blk + BLK_BYTES;
@@ -348,6 +423,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             const ClassPlanes cl = classify_planes(w, tl_wide);
             nl_count += __popc(cl.NL);
             const uint32_t pos_base = blk + lane_off;
+            const uint32_t ent_base = blk | (lane << 5);   // ring entries: anchor_pos()
 
             uint32_t Fd = 0, F4 = 0, F6 = 0;
             uint32_t PV_T = 0;
@@ -374,13 +450,17 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                 const uint32_t PV_C = plane_prev_dword(cl.C, cC);
                 F6 = cl.C & back<1>(cl.C, PV_C) & ~back<2>(cl.C, PV_C);
             }
+#ifdef MXY_ANCHOR_DEBUG
+            if (p.debug & 4) F4 = 0;
+            if (p.debug & 8) Fd = 0;
+            if (p.debug & 64) { nl_count += (F4 | Fd | F6) & 1; F4 = 0; Fd = 0; F6 = 0; }
+#endif
             if (en_dom) {
                 for (;;) {
                     const uint64_t m = __ballot(Fd != 0);
                     if (!m) break;
                     if (Fd) {
-                        const uint32_t t = (uint32_t)(__ffs((int)Fd) - 1);
-                        rdom[(dt + mbcnt64(m)) & (QCAP - 1)] = pos_base + ((t & 7) << 8) + (t >> 3);
+                        rdom[mbcnt64_add(m, dt) & (QCAP - 1)] = ent_base | (uint32_t)__builtin_ctz(Fd);
                         Fd &= Fd - 1;
                     }
                     if (dt == dh) dom_old = blk;
@@ -393,8 +473,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                     const uint64_t m = __ballot(F4 != 0);
                     if (!m) break;
                     if (F4) {
-                        const uint32_t t = (uint32_t)(__ffs((int)F4) - 1);
-                        rv4[(v4t + mbcnt64(m)) & (QCAP - 1)] = pos_base + ((t & 7) << 8) + (t >> 3);
+                        rv4[mbcnt64_add(m, v4t) & (QCAP - 1)] = ent_base | (uint32_t)__builtin_ctz(F4);
                         F4 &= F4 - 1;
                     }
                     if (v4t == v4h) v4_old = blk;
@@ -418,23 +497,34 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                     cw_misc.append(has, v, rare_out, p.rare_cap, &p.counters->n_rare);
                 }
             }
+#ifdef MXY_ANCHOR_DEBUG
+            if (!(p.debug & 16))
+#endif
             if (en_tok) {
-                // nb: bit q set when this lane's dword of row q holds a boundary byte; G = the complement ("free" dwords)
-                const uint32_t nb = (cl.B | (cl.B >> 8) | (cl.B >> 16) | (cl.B >> 24)) & 0xFFu;
+                // Per row q of this lane's dwords (bit q): nb = the dword holds a boundary byte, G = it holds none ("free"),
+                // t3 = its bytes 1..3 are free, only3 = its only boundary byte is byte 3.
+                const uint32_t u1 = cl.B >> 8, u2 = cl.B >> 16, u3 = cl.B >> 24;
+                const uint32_t o123 = u1 | u2 | u3;
+                const uint32_t nb = (cl.B | o123) & 0xFFu;
                 const uint32_t G = nb ^ 0xFFu;
-                // x: bit q + 1 = row q of this lane is free, bit 0 = row 7 of the previous block. The value travels down the
-                // wave (rotate by one lane per step); when it wraps from lane 63 to lane 0 it moves one row up, which is
+                const uint32_t S = G | ((~o123 & 0xFFu) << 16);           // free bits, and the bytes-1..3-free bits in the upper half
+                const uint32_t only3 = u3 & ~(cl.B | u1 | u2) & 0xFFu;
+                // x: bit q + 1 = row q of this lane, bit 0 = row 7 of the previous block (both halves). The value travels down
+                // the wave (rotate by one lane per step); when it wraps from lane 63 to lane 0 it moves one row up, which is
                 // one bit to the left. After k steps x is the state of the dword k places earlier in the byte stream.
-                uint32_t x = (G << 1) | (Gprev >> 7), r5 = 0xFFFFFFFFu;
+                uint32_t x = (S << 1) | ((Sprev >> 7) & 0x00010001u), r5 = 0xFFFFFFFFu;
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
+                for (int k = 0; k < 6; ++k) {
                     x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_WAVE_ROR1, 0xF, 0xF, false);
                     x += x & lane0_ones;
-                    r5 &= x;
+                    if (k < 5) r5 &= x;
                 }
-                // A token of >= 26 bytes that ends in dword i leaves dwords i-1..i-5 boundary-free (necessary); only the
-                // lowest boundary byte of a dword can close a long token.
-                const uint32_t cand = (r5 >> 1) & nb;
+                // A token of >= 26 bytes that ends at byte b0 of dword i leaves dwords i-1..i-5 boundary-free and needs 6 - b0
+                // more free bytes in front of them: dword i-6 free as well, or b0 = 3 and the last three bytes of dword i-6
+                // free (necessary conditions; the exact length is computed below). Only the lowest boundary byte of a dword
+                // can close a long token.
+                const uint32_t cand = nb & (r5 >> 1) & ((x >> 1) | (only3 & (x >> 17)));
+                const uint32_t Gprev = Sprev & 0xFFu;
                 if (__ballot(cand != 0)) {
                     const uint64_t Zp = __ballot((Gprev & 0x80u) != 0);   // free dwords of the previous block's last row
                     uint64_t Zprev_row = Zp;
@@ -472,7 +562,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                         Zprev_row = Zq;
                     }
                 }
-                Gprev = G;
+                Sprev = S;
                 Bprev = cl.B;
             }
         }
@@ -502,13 +592,14 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
 // workgroups of k_anchor that are resident on one CU at the same time (register / LDS limited)
 int anchor_blocks_per_cu(bool) {
     int n = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_anchor, AW * 64, 0);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_anchor<true>, AW * 64, 0);
     if (e != hipSuccess || n < 1) n = 3;
     return n;
 }
 
 void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_anchor, dim3(grid), dim3(AW * 64), 0, stream, p, db);
+    if ((p.flags & EX_ALL) == EX_ALL && !anchor_tl_wide(db)) hipLaunchKernelGGL(k_anchor<true>, dim3(grid), dim3(AW * 64), 0, stream, p, db);
+    else hipLaunchKernelGGL(k_anchor<false>, dim3(grid), dim3(AW * 64), 0, stream, p, db);
 }
 
 }  // namespace mxy

@@ -155,7 +155,7 @@ struct TokParams {
     RareAnchor* heavy;        // tokens that passed the cheap prefilters of k_validate and need k_rare
     uint32_t heavy_cap;
     // Domain anchors that survive k_anchor's prefilter, with 32 bytes of context copied from its LDS window so that
-    // k_validate reads them coalesced instead of gathering log lines: per 1024-slot chunk 9 planes of 1024 dwords
+    // k_validate reads them coalesced instead of gathering log lines: per 64-slot tile 9 planes of 64 dwords
     // (dom_plane_index): plane 0 = anchor position j (bit 31 set: no context, 0xFFFFFFFF: unused slot),
     // planes 1..8 = log[j-24, j+8). dom_cap counts slots.
     uint32_t* dom_list;
@@ -223,8 +223,12 @@ struct LookupParams {
 // chunk hold a sentinel (anchor 0xFFFFFFFF, Candidate.len_type 0xFFFFFFFF, RareAnchor kind 0xFF, Hit.kind 0xFF).
 constexpr uint32_t ANCHOR_CHUNK = 1024, RARE_CHUNK = 64, CAND_CHUNK = 512, HIT_CHUNK = 256;
 constexpr uint32_t DOM_PLANES = 9;
+// The domain anchor list is organised in tiles of 64 slots (one wave store per plane): tile t holds plane 0 of its 64 slots,
+// then plane 1, ... — the planes of one slot are 256 bytes apart, which fits the immediate offset of a store instruction.
+constexpr uint32_t DOM_TILE = 64;
+static_assert(ANCHOR_CHUNK % DOM_TILE == 0, "chunks are whole tiles");
 __host__ __device__ inline size_t dom_plane_index(uint32_t slot, uint32_t plane) {
-    return (size_t)(slot / ANCHOR_CHUNK) * (DOM_PLANES * ANCHOR_CHUNK) + (size_t)plane * ANCHOR_CHUNK + (slot % ANCHOR_CHUNK);
+    return (size_t)(slot / DOM_TILE) * (DOM_PLANES * DOM_TILE) + (size_t)plane * DOM_TILE + (slot % DOM_TILE);
 }
 // A wavefront of k_anchor works through the log in segments (grid-stride). Every segment end flushes the wave's anchor
 // rings, however few anchors they hold, so long segments are cheaper per byte (64 KiB: 7 % less time in k_anchor than
