@@ -92,9 +92,9 @@ struct ChunkWriter {
 // and leave together — one atomic per flush for exactly the entries there are, so these lists carry no per-wave padding
 // (with ~10 000 producer waves a 64-slot chunk per wave was mostly padding, which the consumers dragged through their
 // loops) and appends that carry one or two entries do not pay an atomic round trip each.
-template <class T>
+template <class T, uint32_t CAP = 64>
 struct BufferedWriter {
-    T* buf;              // 64 entries of LDS owned by this wave
+    T* buf;              // CAP entries of LDS owned by this wave
     uint32_t cnt = 0;    // wave-uniform
     uint32_t total = 0;  // entries appended by this wave
     __device__ __forceinline__ explicit BufferedWriter(T* lds) : buf(lds) {}
@@ -113,8 +113,18 @@ struct BufferedWriter {
         const uint64_t m = __ballot(emit);
         if (m == 0) return;
         const uint32_t n = (uint32_t)__popcll(m);
-        if (cnt + n > 64) flush(out, cap, counter);
-        if (emit) buf[cnt + (uint32_t)__popcll(m & lanemask_lt())] = v;
+        const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
+        if (CAP < 64 && n > CAP) {
+            // more entries than the staging buffer holds (dense phases): they leave directly, one atomic for all of them
+            uint32_t b = 0;
+            if (lane_id() == 0) b = atomicAdd(counter, n);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (emit && b + rank < cap) out[b + rank] = v;
+            total += n;
+            return;
+        }
+        if (cnt + n > CAP) flush(out, cap, counter);
+        if (emit) buf[cnt + rank] = v;
         cnt += n;
         total += n;
     }

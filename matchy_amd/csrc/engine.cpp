@@ -418,14 +418,10 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.counters = counters_.p;
     // workgroups per CU for k_anchor / k_validate / k_lookup: what is resident at once (grid-stride kernels; a
     // larger grid only adds a partially filled second round). MATCHY_AMD_GRID=a,v,l overrides for experiments.
-    // k_anchor: two full rounds of resident workgroups; k_validate: one; k_lookup: 2 per CU measured best (every wave
+    // k_anchor: one full round of resident workgroups; k_validate: one; k_lookup: 2 per CU measured best (every wave
     // pads its last hit chunk, and more waves in flight only add contention on the random table accesses).
-    static const int occ_a8 = anchor_blocks_per_cu(false), occ_a4 = anchor_blocks_per_cu(true), occ_v = validate_blocks_per_cu(false), occ_v_ac = validate_blocks_per_cu(true);
-    // most IPv4 candidates survive the /24 filter (CIDR-heavy databases): k_anchor writes a candidate per line, more waves help
-    tp.small_window = (!lookup || ddb_->view.ip_bm24_permille > 250) ? 1u : 0u;   // (or every candidate is listed: extraction)
-    if (const char* w = getenv("MATCHY_AMD_WINDOW_KB")) tp.small_window = atoi(w) <= 4 ? 1u : 0u;
-    const int occ_a = tp.small_window ? occ_a4 : occ_a8;
-    int gm[4] = {2 * occ_a, tp.filter_ac ? occ_v_ac : occ_v, 2, 2};
+    static const int occ_a = anchor_blocks_per_cu(), occ_v = validate_blocks_per_cu(false), occ_v_ac = validate_blocks_per_cu(true);
+    int gm[4] = {occ_a, tp.filter_ac ? occ_v_ac : occ_v, 2, 2};
     if (const char* g = getenv("MATCHY_AMD_GRID")) {   // 0 keeps the default of that kernel
         int o[4] = {0, 0, 0, 0};
         (void)sscanf(g, "%d,%d,%d,%d", &o[0], &o[1], &o[2], &o[3]);
@@ -433,9 +429,12 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     }
     for (int& m : gm) m = std::max(1, std::min(m, 64));
     {
-        // segment size: about three segments per wave of the full grid, within [SEG_MIN, SEG_MAX] (see scan_types.h)
+        // k_anchor: one round of resident workgroups and ONE segment per wave, all of the same size — the segments are
+        // handed out statically, so anything else leaves some waves with one segment more than the others (with three or
+        // four segments per wave that was 19 % of the kernel), and every segment end flushes the wave's anchor rings.
+        // Short batches get SEG_MIN segments and fewer waves.
         const uint64_t waves = (uint64_t)n_cu_ * gm[0] * 4;
-        uint64_t sb = ((uint64_t)len / (waves * 3)) / SEG_ALIGN * SEG_ALIGN;
+        uint64_t sb = (((uint64_t)len + 1 + waves - 1) / waves + SEG_ALIGN - 1) / SEG_ALIGN * SEG_ALIGN;
         if (const char* e = getenv("MATCHY_AMD_SEG_KB")) sb = (uint64_t)atoi(e) * 1024 / SEG_ALIGN * SEG_ALIGN;
         tp.seg_bytes = (uint32_t)std::min<uint64_t>(SEG_MAX, std::max<uint64_t>(SEG_MIN, sb));
         tp.n_segs = (uint32_t)(((uint64_t)len + 1 + tp.seg_bytes - 1) / tp.seg_bytes);

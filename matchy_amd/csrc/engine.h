@@ -13,7 +13,7 @@
 namespace mxy {
 
 // kernel launch wrappers (k_anchor.hip, validate_kernels.hip, lookup_kernels.hip)
-int anchor_blocks_per_cu(bool small_window);
+int anchor_blocks_per_cu();
 int validate_blocks_per_cu(bool ac);
 void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_validate(const TokParams& p, const DevDb& db, int grid, int n_cu, hipStream_t stream);

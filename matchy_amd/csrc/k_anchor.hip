@@ -76,6 +76,13 @@ __device__ __forceinline__ uint32_t anchor_pos(uint32_t e) {
     return (e & ~(BLK_BYTES - 1)) + ((e & 7u) << 8) + ((e >> 3) & 0xFCu) + ((e >> 3) & 3u);
 }
 
+// LDS budget: 4 workgroups (16 waves) per CU = 40 KiB per workgroup. Per wave: raw window 8 KiB + mirror, two anchor rings,
+// and small staging buffers for the sparse output lists (a list that turns dense bypasses its buffer, BufferedWriter).
+constexpr uint32_t CAND_STAGE = 16, RARE_STAGE = 8;
+typedef BufferedWriter<Candidate, CAND_STAGE> CandWriter;
+typedef BufferedWriter<uint2, RARE_STAGE> RareWriter;
+constexpr uint32_t BLOOM_FOLD_WORDS = TLD_BLOOM_WORDS / 2;   // the last-label Bloom filter folded to half its size (bit b | bit b + 16384)
+
 struct WaveCtx {
     const TokParams* p;
     const uint32_t* raw32;
@@ -96,7 +103,7 @@ struct PendingV4 {
     uint32_t n_valid = 0;  // per-lane count of validated candidates (reduced into ScanCounters::cand_true at the end)
 };
 
-__device__ __forceinline__ void commit_v4(PendingV4& pd, const WaveCtx& cx, BufferedWriter<Candidate>& cw) {
+__device__ __forceinline__ void commit_v4(PendingV4& pd, const WaveCtx& cx, CandWriter& cw) {
     const TokParams& p = *cx.p;
     const bool emit = pd.ok && ((pd.word >> ((pd.c.v4 >> 8) & 31)) & 1);
     cw.append(emit, pd.c, p.cands, p.cand_cap, &p.counters->n_cand);
@@ -148,7 +155,7 @@ __device__ __forceinline__ bool d_ipv4_lean(const uint32_t (&w)[5], const uint8_
 }
 
 __device__ __forceinline__ void drain_v4(uint32_t* ring, uint32_t& head, uint32_t& tail, uint32_t n, bool final, const WaveCtx& cx,
-                                         PendingV4& pd, BufferedWriter<Candidate>& cw) {
+                                         PendingV4& pd, CandWriter& cw) {
     const uint32_t lane = lane_id();
     const TokParams& p = *cx.p;
     commit_v4(pd, cx, cw);
@@ -236,7 +243,7 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
                 const uint32_t ll = (uint32_t)(__ffsll((long long)ndc) - 1) >> 3;
                 const uint64_t below = (1ull << (8 * ll)) - 1ull;
                 const uint32_t stop = (uint32_t)(w64 >> (8 * ll)) & 0xFF;
-                const uint32_t bit = tld_hash8((uint32_t)(w64 & below), (uint32_t)((w64 & below) >> 32)) & (TLD_BLOOM_BITS - 1);
+                const uint32_t bit = tld_hash8((uint32_t)(w64 & below), (uint32_t)((w64 & below) >> 32)) & (TLD_BLOOM_BITS / 2 - 1);
                 // a '.' inside the label: a later dot owns the run; the run must end at a boundary; the label must be
                 // some public suffix's last label
                 keep = (mw.dot & below) == 0 && d_is_boundary(stop) && ((cx.bloom[bit >> 5] >> (bit & 31)) & 1);
@@ -305,15 +312,15 @@ template <bool ALL>
 __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     constexpr uint32_t RAW_DW = RAW_BYTES / 4;
     __shared__ uint8_t ctab[256];    // byte classes for the few bytes in front of a segment (the blocks themselves are bit-sliced)
-    __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
+    __shared__ uint32_t bloom[BLOOM_FOLD_WORDS];
     __shared__ __attribute__((aligned(16))) uint32_t rawst[AW][RAW_DW + RAW_MIRROR / 4];
     __shared__ uint32_t q_v4[AW][QCAP];
     __shared__ uint32_t q_dom[AW][QCAP];
-    __shared__ uint2 wb_misc[AW][64], wb_tok[AW][64];   // BufferedWriter staging
-    __shared__ Candidate wb_cand[AW][64];
+    __shared__ uint2 wb_misc[AW][RARE_STAGE], wb_tok[AW][RARE_STAGE];   // BufferedWriter staging
+    __shared__ Candidate wb_cand[AW][CAND_STAGE];
 
     ctab[threadIdx.x] = (uint8_t)class_of(threadIdx.x);
-    for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += AW * 64) bloom[i] = db.tld_bloom[i];
+    for (uint32_t i = threadIdx.x; i < BLOOM_FOLD_WORDS; i += AW * 64) bloom[i] = db.tld_bloom[i] | db.tld_bloom[i + BLOOM_FOLD_WORDS];
     __syncthreads();
 
     // readfirstlane: tells the compiler that the wave index — and with it the segment loop, the block position and the ring
@@ -332,9 +339,9 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     uint32_t nl_count = 0;                       // per-lane '\n' count, reduced once at the end
     uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0;   // ring heads / tails (wave-uniform)
     uint32_t v4_old = 0, dom_old = 0;            // block start of the oldest ring entry (valid while the ring is non-empty)
-    BufferedWriter<Candidate> cw_cand(wb_cand[wave]);   // IPv4 candidates that pass the /24 bitmap are sparse
+    CandWriter cw_cand(wb_cand[wave]);   // IPv4 candidates that pass the /24 bitmap are sparse
     DomWriter cw_dom;
-    BufferedWriter<uint2> cw_misc(wb_misc[wave]), cw_tok(wb_tok[wave]);   // rare anchors and long tokens are sparse: dense lists
+    RareWriter cw_misc(wb_misc[wave]), cw_tok(wb_tok[wave]);   // rare anchors and long tokens are sparse: dense lists
     uint2* rare_out = reinterpret_cast<uint2*>(p.rare);
     uint2* tok_out = reinterpret_cast<uint2*>(p.tok);
     WaveCtx cx{&p, raw32, ctab, bloom, db.ip_bm24, 0u, 0u};
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
 }
 
 // workgroups of k_anchor that are resident on one CU at the same time (register / LDS limited)
-int anchor_blocks_per_cu(bool) {
+int anchor_blocks_per_cu() {
     int n = 0;
     const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_anchor<true>, AW * 64, 0);
     if (e != hipSuccess || n < 1) n = 3;

@@ -144,7 +144,6 @@ struct TokParams {
     uint32_t filter_lit;      // 1: domain candidates whose XXH64 is not in DevDb::lit_bm are counted but not listed ...
     uint32_t filter_ac;       // 1: ... unless their text reaches an output state of the glob automaton (databases with globs)
     uint32_t n_segs;
-    uint32_t small_window;    // k_anchor variant: 1 = 4 KiB raw window (16 waves per CU), 0 = 8 KiB (12 waves, fuller ring drains)
     uint32_t seg_bytes;       // bytes of log per wavefront work item: a multiple of SEG_ALIGN chosen from the batch length
     Candidate* cands;
     uint32_t cand_cap;
@@ -230,10 +229,10 @@ static_assert(ANCHOR_CHUNK % DOM_TILE == 0, "chunks are whole tiles");
 __host__ __device__ inline size_t dom_plane_index(uint32_t slot, uint32_t plane) {
     return (size_t)(slot / DOM_TILE) * (DOM_PLANES * DOM_TILE) + (size_t)plane * DOM_TILE + (slot % DOM_TILE);
 }
-// A wavefront of k_anchor works through the log in segments (grid-stride). Every segment end flushes the wave's anchor
-// rings, however few anchors they hold, so long segments are cheaper per byte (64 KiB: 7 % less time in k_anchor than
-// 16 KiB); short batches take shorter ones so that all waves get work. Segment starts must fall on window boundaries.
-constexpr uint32_t SEG_ALIGN = 8192, SEG_MIN = 8192, SEG_MAX = 65536;
+// A wavefront of k_anchor works through the log in segments. Every segment end flushes the wave's anchor rings, however few
+// anchors they hold, so long segments are cheaper per byte: the host makes one segment per resident wave (engine.cpp).
+// Segment starts must fall on window boundaries.
+constexpr uint32_t SEG_ALIGN = 8192, SEG_MIN = 8192, SEG_MAX = 1u << 26;
 constexpr uint32_t MAX_GLOB_RESULTS = 32;
 constexpr uint32_t MAX_GLOB_STARS = 24;
 
