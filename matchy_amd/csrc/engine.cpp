@@ -509,6 +509,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         if (!over) break;
         if (trace) fprintf(stderr, "[matchy_amd] work buffers overflow (attempt %d): regrow and rescan\n", attempt);
         if (single_) throw HipError{"lookup_one: work buffers overflow"};
+        if (attempt == 5) throw HipError{"scan: work buffers still overflow after regrowing"};
         // grow and run again: the kernels count past the capacity without writing, so the counts are exact demands
         if (c.n_cand > cands_.n) cands_.alloc((size_t)c.n_cand + c.n_cand / 4 + 1024);
         if (c.n_rare > rare_.n) rare_.alloc((size_t)c.n_rare + c.n_rare / 4 + 1024);
@@ -527,7 +528,6 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
             final_ids_.alloc(want); final_offs_.alloc(want);
         }
         scan_device(last_ptr_, last_len_, last_lookup_, stream, last_mirror_);
-        if (attempt == 5) throw HipError{"scan: work buffers still overflow after regrowing"};
     }
     const ScanCounters& c = host_counters_;
     if (c.error & 1) throw HipError{"scan: a candidate matched more than MAX_GLOB_RESULTS glob patterns"};

@@ -116,22 +116,25 @@ constexpr uint32_t DFA_LDS_ENTRIES_VAL = 2048;  // 8 KiB per workgroup of k_vali
 constexpr uint32_t TLD_BLOOM_BITS = 32768;
 constexpr uint32_t TLD_BLOOM_WORDS = TLD_BLOOM_BITS / 32;
 
+// List counters and statistics of one scan. Every counter that many waves bump with a returning atomic has a 128-byte line
+// of its own: atomics on one line are served one after the other (~12 ns each), and with all counters in one line the
+// list reservations of k_anchor's 4096 waves queued behind each other.
 struct ScanCounters {
-    unsigned long long lines;        // '\n' bytes
-    uint32_t n_cand;                 // candidates appended (may exceed capacity → overflow)
-    uint32_t n_rare;                 // IPv6 / e-mail anchors
-    uint32_t n_tok;                  // long-token anchors (hash / crypto candidates)
-    uint32_t reserved0;
-    uint32_t n_dom;                  // domain anchors (first byte of a label that follows a dot)
-    uint32_t n_hits;
-    uint32_t n_ids;
-    uint32_t error;                  // bit0: glob result list overflow, bit1: glob star-stack overflow, bit2: candidate > 16 MiB, bit3: lower-cased non-ASCII candidate > 256 B (case-insensitive DB)
+    alignas(128) unsigned long long lines;        // '\n' bytes
     uint32_t cand_true;              // candidates really written (n_cand counts chunk-allocated slots incl. padding)
     uint32_t hits_true;
-    uint32_t n_final;                // dense final hit records written by pack_record
+    uint32_t error;                  // bit0: glob result list overflow, bit1: glob star-stack overflow, bit2: candidate > 16 MiB, bit3: lower-cased non-ASCII candidate > 256 B (case-insensitive DB)
+    uint32_t reserved0;
+    alignas(128) uint32_t n_cand;    // candidates appended (may exceed capacity → overflow)
+    alignas(128) uint32_t n_dom;     // domain anchors (first byte of a label that follows a dot)
+    alignas(128) uint32_t n_rare;    // IPv6 / e-mail anchors
+    alignas(128) uint32_t n_tok;     // long-token anchors (hash / crypto candidates)
+    alignas(128) uint32_t n_heavy;   // tokens that need a checksum validator (Base58Check, Bech32, EIP-55, Monero)
+    alignas(128) uint32_t n_hits;
+    uint32_t n_ids;
+    alignas(128) uint32_t n_final;   // dense final hit records written by pack_record
     uint32_t n_final_ids;            // entries of the pattern-id / data-offset side arrays
-    uint32_t n_heavy;                // tokens that need a checksum validator (Base58Check, Bech32, EIP-55, Monero)
-    uint32_t n_glob_work;            // candidates whose text reaches an output state of the AC automaton (glob work list)
+    alignas(128) uint32_t n_glob_work;   // candidates whose text reaches an output state of the AC automaton (glob work list)
 };
 
 struct TokParams {
