@@ -130,6 +130,65 @@ struct BufferedWriter {
     }
 };
 
+// Writer for a list that may be sparse or dense (k_anchor's IPv4 candidates: a few per block when the database's /24 bitmap
+// filters, one per log line when it does not): the wave reserves chunks of `chunk` slots of the global list (one returning
+// atomic per chunk — atomics on one counter are served one at a time, ~12 ns each, so 4096 waves cannot afford one per
+// append), small appends collect in a CAP-entry LDS buffer and leave together as one coalesced store, large ones go
+// straight into the chunk. Unused slots of a chunk hold `sentinel`.
+template <class T, uint32_t CAP>
+struct StagedChunkWriter {
+    T* buf;                        // CAP entries of LDS owned by this wave
+    uint32_t cnt = 0;              // staged entries (wave-uniform)
+    uint32_t base = 0xFFFFFFFFu;   // current chunk (0xFFFFFFFF: none yet), wave-uniform
+    uint32_t used = 0, chunk;
+    __device__ __forceinline__ StagedChunkWriter(T* lds, uint32_t chunk_slots) : buf(lds), chunk(chunk_slots < 64 ? 64u : chunk_slots) {}
+    __device__ __forceinline__ void pad_rest(T* out, uint32_t cap, const T& sentinel) {
+        if (base == 0xFFFFFFFFu) return;
+        for (uint32_t k = used + lane_id(); k < chunk; k += 64)
+            if (base + k < cap) out[base + k] = sentinel;
+        used = chunk;
+    }
+    // room for n more entries in the current chunk, else a new chunk
+    __device__ __forceinline__ void need(uint32_t n, T* out, uint32_t cap, uint32_t* counter, const T& sentinel) {
+        if (base != 0xFFFFFFFFu && used + n <= chunk) return;
+        pad_rest(out, cap, sentinel);
+        uint32_t b = 0;
+        if (lane_id() == 0) b = atomicAdd(counter, chunk);
+        base = __builtin_amdgcn_readfirstlane(b);
+        used = 0;
+    }
+    __device__ __forceinline__ void flush(T* out, uint32_t cap, uint32_t* counter, const T& sentinel) {
+        if (cnt == 0) return;
+        need(cnt, out, cap, counter, sentinel);
+        __builtin_amdgcn_wave_barrier();
+        if (lane_id() < cnt && base + used + lane_id() < cap) out[base + used + lane_id()] = buf[lane_id()];
+        __builtin_amdgcn_wave_barrier();
+        used += cnt;
+        cnt = 0;
+    }
+    // all lanes of the (converged) wave call this
+    __device__ __forceinline__ void append(bool emit, const T& v, T* out, uint32_t cap, uint32_t* counter, const T& sentinel) {
+        const uint64_t m = __ballot(emit);
+        if (m == 0) return;
+        const uint32_t n = (uint32_t)__popcll(m);
+        const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
+        if (n > CAP / 2) {
+            flush(out, cap, counter, sentinel);   // keeps the list in append order per wave
+            need(n, out, cap, counter, sentinel);
+            if (emit && base + used + rank < cap) out[base + used + rank] = v;
+            used += n;
+            return;
+        }
+        if (cnt + n > CAP) flush(out, cap, counter, sentinel);
+        if (emit) buf[cnt + rank] = v;
+        cnt += n;
+    }
+    __device__ __forceinline__ void finish(T* out, uint32_t cap, uint32_t* counter, const T& sentinel) {
+        flush(out, cap, counter, sentinel);
+        pad_rest(out, cap, sentinel);
+    }
+};
+
 // Chunked writer for the plane-organised domain anchor list (TokParams::dom_list): slots are reserved like in
 // ChunkWriter (one atomic per ANCHOR_CHUNK slots), the caller stores the planes of its slot.
 struct DomWriter {

@@ -411,6 +411,8 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.filter_lit = (lookup && (!ddb_->view.has_glob || ac_ok)) ? 1u : 0u;
     if (const char* dbg = getenv("MATCHY_AMD_DEBUG")) tp.debug = (uint32_t)atoi(dbg);
     tp.cands = cands_.p; tp.cand_cap = (uint32_t)cands_.n;
+    // IPv4 candidates are listed sparsely when the /24 bitmap of the database filters most of the address space
+    tp.cand_chunk = (lookup && ddb_->view.ip_bm24_permille <= 250) ? 64u : 1024u;
     tp.rare = rare_.p; tp.rare_cap = (uint32_t)rare_.n;
     tp.tok = tok_.p; tp.tok_cap = (uint32_t)tok_.n;
     tp.heavy = heavy_.p; tp.heavy_cap = (uint32_t)heavy_.n;

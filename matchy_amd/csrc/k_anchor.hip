@@ -79,7 +79,7 @@ __device__ __forceinline__ uint32_t anchor_pos(uint32_t e) {
 // LDS budget: 4 workgroups (16 waves) per CU = 40 KiB per workgroup. Per wave: raw window 8 KiB + mirror, two anchor rings,
 // and small staging buffers for the sparse output lists (a list that turns dense bypasses its buffer, BufferedWriter).
 constexpr uint32_t CAND_STAGE = 16, RARE_STAGE = 8;
-typedef BufferedWriter<Candidate, CAND_STAGE> CandWriter;
+typedef StagedChunkWriter<Candidate, CAND_STAGE> CandWriter;
 typedef BufferedWriter<uint2, RARE_STAGE> RareWriter;
 constexpr uint32_t BLOOM_FOLD_WORDS = TLD_BLOOM_WORDS / 2;   // the last-label Bloom filter folded to half its size (bit b | bit b + 16384)
 
@@ -106,7 +106,7 @@ struct PendingV4 {
 __device__ __forceinline__ void commit_v4(PendingV4& pd, const WaveCtx& cx, CandWriter& cw) {
     const TokParams& p = *cx.p;
     const bool emit = pd.ok && ((pd.word >> ((pd.c.v4 >> 8) & 31)) & 1);
-    cw.append(emit, pd.c, p.cands, p.cand_cap, &p.counters->n_cand);
+    cw.append(emit, pd.c, p.cands, p.cand_cap, &p.counters->n_cand, Candidate{0u, 0xFFFFFFFFu, 0u, 0u});
     pd.ok = false;
 }
 
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     uint32_t nl_count = 0;                       // per-lane '\n' count, reduced once at the end
     uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0;   // ring heads / tails (wave-uniform)
     uint32_t v4_old = 0, dom_old = 0;            // block start of the oldest ring entry (valid while the ring is non-empty)
-    CandWriter cw_cand(wb_cand[wave]);   // IPv4 candidates that pass the /24 bitmap are sparse
+    CandWriter cw_cand(wb_cand[wave], p.cand_chunk);   // IPv4 candidates: sparse when the /24 bitmap filters, else one per line
     DomWriter cw_dom;
     RareWriter cw_misc(wb_misc[wave]), cw_tok(wb_tok[wave]);   // rare anchors and long tokens are sparse: dense lists
     uint2* rare_out = reinterpret_cast<uint2*>(p.rare);
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     cw_tok.flush(tok_out, p.tok_cap, &p.counters->n_tok);
     // mark the unused tail of every open chunk
     cw_dom.pad_rest(p.dom_list, p.dom_cap);
-    cw_cand.flush(p.cands, p.cand_cap, &p.counters->n_cand);
+    cw_cand.finish(p.cands, p.cand_cap, &p.counters->n_cand, Candidate{0u, 0xFFFFFFFFu, 0u, 0u});
     {
         uint32_t nv = pend.n_valid;  // validated IPv4 candidates, listed or not
 #pragma unroll

@@ -150,6 +150,7 @@ struct TokParams {
     uint32_t seg_bytes;       // bytes of log per wavefront work item: a multiple of SEG_ALIGN chosen from the batch length
     Candidate* cands;
     uint32_t cand_cap;
+    uint32_t cand_chunk;      // slots k_anchor reserves per atomic for its IPv4 candidates (64: sparse list, 1024: one per line)
     RareAnchor* rare;         // IPv6 / e-mail anchors
     uint32_t rare_cap;
     RareAnchor* tok;          // long-token anchors
