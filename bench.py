@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--config", default="c2", help="indicator mix (tools/synth.py): c2 = 100K mixed IoCs")
     ap.add_argument("--cpu-lines", type=int, default=3_000_000, help="lines of the same log timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host-buffer measurement")
     ap.add_argument("--case-insensitive", action="store_true", help="build the database with match_mode 1 (matchy build -i)")
     ap.add_argument("--pipelined", type=int, default=0, help="N > 1: after the timed steps, time the same K steps again with N batches in flight per GPU "
                     "(scanners on their own streams) and report it as the extra object `pipelined`. Off by default so that a profile "
@@ -190,17 +191,61 @@ def main():
     traffic = None
     tr_note = None
     try:
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/prof.sh; FETCH_SIZE x2 on gfx950)
-        tj = json.load(open(ROOT / "profiles" / "r01_traffic.json"))
-        if tj.get("bytes_per_gpu") == nbytes:
-            key = {"k_anchor": "mxy::k_anchor", "k_validate_dom+k_validate": "mxy::k_validate_dom<false>", "k_rare": "mxy::k_rare", "k_lookup": "mxy::k_lookup<false>"}[dom_name]
-            key = next((k for k in tj["kernels"] if k.startswith(key)), key)   # template instantiations: mxy::k_anchor<8192u>
-            traffic = tj["kernels"][key]["hbm_bytes"]
-            tr_note = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
+        # HBM bytes per launch from the newest committed rocprofv3 --pmc passes of this command (tools/prof.sh: separate
+        # FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 on gfx950). The file carries a fingerprint of the kernel sources it was
+        # taken from; a file from other sources, or of another batch size, is refused (traffic = null) instead of quoted.
+        from tools.csrc_hash import csrc_sha
+        files = sorted((ROOT / "profiles").glob("r*_traffic.json"))
+        tj = json.load(open(files[-1])) if files else {}
+        if tj.get("bytes_per_gpu") == nbytes and tj.get("csrc_sha") == csrc_sha():
+            prefix = {"k_anchor": "mxy::k_anchor", "k_validate_dom+k_validate": "mxy::k_validate_dom", "k_rare": "mxy::k_rare", "k_lookup": "mxy::k_lookup"}[dom_name]
+            keys = [k for k in tj["kernels"] if k.startswith(prefix)]
+            if len(keys) == 1:   # exactly one instantiation of the dominant kernel ran in the profiled command
+                traffic = tj["kernels"][keys[0]]["hbm_bytes"]
+                tr_note = f"profiles/{files[-1].name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command, kernel sources {tj['csrc_sha']} (= this tree)"
+        elif files:
+            tr_note = f"profiles/{files[-1].name} refused: taken from other kernel sources or another batch size"
     except Exception:
         pass
 
+    # ---- the box's own copy bandwidth, measured in this run (report the spec peak and the measured one)
+    peak_measured = None
+    if rank == 0:
+        nb = 1 << 30
+        a = torch.empty(nb, dtype=torch.uint8, device=dev); b = torch.empty(nb, dtype=torch.uint8, device=dev)
+        a.fill_(1)
+        for _ in range(2):
+            b.copy_(a)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record(); torch.cuda.synchronize()
+        peak_measured = round(5 * 2 * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del a, b
+
+    # ---- PCIe-inclusive rate of the host-buffer entry (matchy_scanner_scan from pinned host memory: H2D in < 1 GiB pieces,
+    # scan, canonical-order sort on the GPU, hit records back). Reported beside the headline, never as `value`.
+    end_to_end = None
+    if rank == 0 and world == 1 and not args.no_e2e:
+        pinned = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        pinned.copy_(host[:nbytes])
+        sc2 = M.Scanner(db, extract_flags=args.extract_flags, device=local_rank)
+        times = []
+        for rep in range(4):
+            te = time.perf_counter()
+            r = sc2.scan_ptr(pinned.data_ptr(), nbytes)
+            times.append(time.perf_counter() - te)
+            e2e_counts = (r.lines, r.n_hits)
+            r.close()
+        sc2.close()
+        best = min(times[1:])
+        end_to_end = {"value": round(nbytes / best / 1e9, 2), "unit": "GB/s", "ms": round(best * 1e3, 2), "entry": "matchy_scanner_scan, pinned host buffer, H2D included",
+                      "same_counts": bool(e2e_counts == (counts[0], counts[2]))}
+        del pinned
+
     cpu = None
+    cpu_t1 = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu:
         # ---- CPU baseline: the oracle ("port" of the reference CPU path) on a bounded sample of the SAME log,
@@ -219,6 +264,12 @@ def main():
         cpu = {"value": round(len(sample) / st.seconds / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
                "sample": f"first {n_cpu_lines} lines ({len(sample)} B) of the same log, {cores} threads, 256 KiB newline-aligned chunks, LRU 10000",
                "lines_per_s": round(st.lines / st.seconds, 1)}
+        # the same path on ONE core (T = all cores and T = 1), on a tenth of the sample
+        n1 = max(1, n_cpu_lines // 10)
+        s1_end = int(nl[n1 - 1]) + 1 if len(nl) >= n1 else sample_end
+        _, _, st1 = odb.scan(sample[:s1_end], threads=1, cache=10000, want_json=False)
+        cpu_t1 = {"value": round(s1_end / st1.seconds / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                  "sample": f"first {n1} lines ({s1_end} B) of the same log, 1 thread, LRU 10000", "lines_per_s": round(st1.lines / st1.seconds, 1)}
         # parity in the same run: GPU hits on the sample == oracle hits
         res = scanner.scan_device(dlog.data_ptr(), sample_end, stream=stream, fetch_mode=3)
         ghits = res.hits()
@@ -248,10 +299,13 @@ def main():
             "hits_per_step": agg["hits"],
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "peak_measured": peak_measured, "peak_measured_note": "device-to-device copy of 1 GiB in this run, read + write bytes / time",
                          "traffic": traffic, "kernel": dom_name, "algorithmic_bytes_per_launch": nbytes, "traffic_source": tr_note},
             "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(pipe_achieved / HBM_PEAK_GBS, 4), "kernels_ms": round(pipe_ms, 4)},
             "cpu_baseline": cpu,
+            "cpu_baseline_t1": cpu_t1,
+            "end_to_end": end_to_end,
             "pipelined": pipelined,
             "parity_vs_oracle": parity,
         }

@@ -169,9 +169,9 @@ def test_reference_c_test_programs(prog, tmp_path):
     """The reference's own C test programs (crates/matchy/tests/test_c_api*.c), compiled unmodified against the
     reference's header and linked with libmatchy_amd.so by `make -C oracle ref_c_tests` (needs /root/reference at build
     time; the binaries travel to the GPU box). They must pass as they do against the reference library."""
-    exe = ROOT / "oracle" / "_ref" / prog
+    exe = ROOT / "tests" / "ref_c_bin" / prog
     if not exe.exists():
-        pytest.skip("oracle/_ref not built (no /root/reference at build time)")
+        pytest.skip("tests/ref_c_bin not built (no /root/reference at build time)")
     r = subprocess.run([str(exe)], capture_output=True, timeout=300, cwd=tmp_path)
     out = r.stdout.decode("utf-8", "replace")
     assert r.returncode == 0, out[-2000:] + r.stderr.decode("utf-8", "replace")[-500:]

@@ -44,4 +44,6 @@ try:
             nbytes = json.loads(line)["config"]["bytes_per_gpu"]
 except OSError:
     pass
-json.dump({"bytes_per_gpu": nbytes, "kernels": traffic}, open(out + "/traffic.json", "w"), indent=1)
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from csrc_hash import csrc_sha
+json.dump({"bytes_per_gpu": nbytes, "csrc_sha": csrc_sha(), "kernels": traffic}, open(out + "/traffic.json", "w"), indent=1)
