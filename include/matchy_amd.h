@@ -225,6 +225,11 @@ typedef struct matchy_scan_hit_t {
   uint8_t prefix_len;    /* IP results */
   uint16_t n_ids;        /* pattern results: number of pattern ids (literal id first, then glob ids ascending) */
 } matchy_scan_hit_t;
+/* Limits of the record, not of the matching: a candidate text of 16 MiB or more (24-bit length) and a candidate that matches
+ * more than 65535 patterns at once (16-bit id count) make the scan fail with an error instead of truncating. Glob matching
+ * itself is unbounded like Paraglob::find_all (any number of results, any nesting of '*': candidates beyond what a lane of
+ * the streaming pass holds are answered by a spill pass), and literal queries of case-insensitive databases are lower-cased
+ * as a stream (no length limit). */
 #define MATCHY_SCAN_HIT_LEN(h) ((h).len_type & 0xFFFFFFu)
 #define MATCHY_SCAN_HIT_END(h) ((uint64_t)(h).start + MATCHY_SCAN_HIT_LEN(h))
 #define MATCHY_SCAN_HIT_TYPE(h) ((uint8_t)((h).len_type >> 24))

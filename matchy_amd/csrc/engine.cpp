@@ -278,6 +278,8 @@ void DeviceDb::upload(const DbImage& img, int dev) {
         view.wild_off = unaligned + (8 - unaligned % 8) % 8;  // recomputed like the reader (pg:1089-1093)
         view.wild_count = r32(60);
         view.glob_seg_off = r32(104);
+        view.glob_max_segs = 1;
+        for (uint32_t pid = 0; pid < view.pattern_count; ++pid) view.glob_max_segs = std::max<uint32_t>(view.glob_max_segs, r32((size_t)view.glob_seg_off + (size_t)pid * 8 + 4) & 0xFFFFu);
         view.lit2pat_off = lit2pat_off.p; view.lit2pat = lit2pat.p; view.n_ac_lits = (uint32_t)off.size() - 1;
         {
             // one dependent load per text byte instead of a node + edge-list walk with failure links: the automaton as a
@@ -458,6 +460,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         if (ddb_->view.has_glob) {
             if (glob_work_.n < cands_.n / 8) glob_work_.alloc(cands_.n / 8);
             lp.glob_work = glob_work_.p; lp.glob_work_cap = (uint32_t)glob_work_.n;
+            setup_spill(lp);
         }
         lp.counters = counters_.p;
         PackParams pp{};
@@ -500,13 +503,14 @@ hipError_t sort_hits(const FinalHit* fin, uint32_t n, unsigned long long* keys, 
 
 void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode, bool sorted) {
     const bool trace = !single_ && getenv("MATCHY_AMD_TRACE");
+    MXY_HIP(hipSetDevice(ddb_->device));   // regrown buffers must land on this scanner's device whatever thread calls
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     for (int attempt = 0; attempt < 6; ++attempt) {
         MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
         MXY_HIP(hipStreamSynchronize(stream));
         const ScanCounters& c = host_counters_;
-        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_dom > dom_slots_ ||
+        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_dom > dom_slots_ || (spill_.n && c.n_spill > spill_.n) ||
                     c.n_final > final_.n || c.n_final_ids > final_ids_.n;
         if (!over) break;
         if (trace) fprintf(stderr, "[matchy_amd] work buffers overflow (attempt %d): regrow and rescan\n", attempt);
@@ -518,6 +522,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         if (c.n_tok > tok_.n) tok_.alloc((size_t)c.n_tok + c.n_tok / 4 + 1024);
         if (c.n_heavy > heavy_.n) heavy_.alloc((size_t)c.n_heavy + c.n_heavy / 4 + 1024);
         if (glob_work_.n && c.n_glob_work > glob_work_.n) glob_work_.alloc((size_t)c.n_glob_work + c.n_glob_work / 4 + 1024);
+        if (spill_.n && c.n_spill > spill_.n) spill_.alloc((size_t)c.n_spill + c.n_spill / 4 + 1024);
         if (c.n_dom > dom_slots_) {
             dom_slots_ = (((size_t)c.n_dom + c.n_dom / 4 + ANCHOR_CHUNK) / ANCHOR_CHUNK) * ANCHOR_CHUNK;
             dom_list_.alloc(dom_slots_ * DOM_PLANES);
@@ -532,10 +537,8 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         scan_device(last_ptr_, last_len_, last_lookup_, stream, last_mirror_);
     }
     const ScanCounters& c = host_counters_;
-    if (c.error & 1) throw HipError{"scan: a candidate matched more than MAX_GLOB_RESULTS glob patterns"};
-    if (c.error & 2) throw HipError{"scan: a glob pattern nests more than MAX_GLOB_STARS '*' segments"};
+    if (c.error & 1) throw HipError{"scan: a candidate matches more than 65535 glob patterns (the hit record counts pattern ids in 16 bits)"};
     if (c.error & 4) throw HipError{"scan: a candidate is longer than 16 MiB (24-bit length field)"};
-    if (c.error & 8) throw HipError{"scan: a non-ASCII candidate longer than 256 bytes met a case-insensitive database whose literal keys are that long"};
     const double t_counters = since();
     if (trace)
         fprintf(stderr, "[matchy_amd] lines=%llu n_dom=%u n_rare=%u n_tok=%u n_heavy=%u n_cand=%u (true %u) n_hits=%u (true %u) n_ids=%u glob_work=%u final=%u\n",
@@ -616,6 +619,19 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     if (want_cands) for (const Candidate& cd : out.cands) { uint32_t ty = cd.len_type >> 24; if (ty < IT_COUNT) out.by_type[ty]++; }
 }
 
+// Spill pass of the glob lookup (k_lookup_spill): list of candidate indices + per-thread scratch (one bit per pattern id and a
+// star stack as deep as the longest pattern).
+void Scanner::setup_spill(LookupParams& lp) {
+    if (!ddb_->view.has_glob) return;
+    constexpr uint32_t SPILL_BLOCKS = 16, SPILL_THREADS = 64;
+    const size_t words = (ddb_->view.pattern_count + 31) / 32 + 2 * ((size_t)ddb_->view.glob_max_segs + 1);
+    const size_t want = std::max<size_t>(1024, cands_.n / 256);
+    if (spill_.n < want) spill_.alloc(want);
+    if (spill_scratch_.n < words * SPILL_BLOCKS * SPILL_THREADS) spill_scratch_.alloc(words * SPILL_BLOCKS * SPILL_THREADS);
+    lp.spill = spill_.p; lp.spill_cap = (uint32_t)spill_.n;
+    lp.spill_scratch = spill_scratch_.p; lp.spill_words = (uint32_t)words; lp.spill_blocks = SPILL_BLOCKS;
+}
+
 void Scanner::lookup_one(const std::string& text, Candidate c, ScanOutput& out) {
     MXY_HIP(hipSetDevice(ddb_->device));
     ensure_capacity(4096);
@@ -630,6 +646,7 @@ void Scanner::lookup_one(const std::string& text, Candidate c, ScanOutput& out) 
     lp.log = staging_.p; lp.len = (uint32_t)text.size(); lp.cands = cands_.p; lp.cand_cap = (uint32_t)cands_.n;
     lp.hits = hits_.p; lp.hit_cap = (uint32_t)hits_.n; lp.ids = ids_.p; lp.ids_cap = (uint32_t)ids_.n;
     lp.counters = counters_.p;
+    setup_spill(lp);
     launch_lookup(lp, ddb_->view, 1, nullptr);
     last_lookup_ = true; last_ptr_ = staging_.p; last_len_ = (uint32_t)text.size();
     bool prof = profile_;
@@ -644,9 +661,12 @@ void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_
                         std::vector<FinalHit>* fin, std::vector<uint32_t>* fin_ids, std::vector<long long>* fin_offs) {
     // Cut into < 2^30-byte pieces at newlines (N4 in SURVEY §8a: no candidate class admits '\n').
     const size_t MAXC = (size_t)1 << 30;
+    // the calling thread may be another one than last time (its current device is thread state): allocations below must land
+    // on this scanner's device
+    MXY_HIP(hipSetDevice(ddb_->device));
     // copies and kernels of a host-buffer scan go to a stream of this scanner's own, so that several scanners on one
     // device (one per host thread, `matchy match --devices 0,0`) overlap one batch's transfer with another's kernels
-    if (!host_stream_) { MXY_HIP(hipSetDevice(ddb_->device)); MXY_HIP(hipStreamCreateWithFlags(&host_stream_, hipStreamNonBlocking)); }
+    if (!host_stream_) MXY_HIP(hipStreamCreateWithFlags(&host_stream_, hipStreamNonBlocking));
     out = ScanOutput();
     size_t pos = 0;
     std::vector<Candidate> all_cands;

@@ -109,6 +109,7 @@ public:
     // sorted: the final records are put into canonical order on the GPU (sort_hits.hip) before they are copied back
     void fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode = HITS_FINAL, bool sorted = false);
     // One synthetic candidate (single-query API): `text` is uploaded, only the lookup kernel runs.
+    void setup_spill(LookupParams& lp);
     void lookup_one(const std::string& text, Candidate c, ScanOutput& out);
     // Convenience: host buffer -> internal device buffer -> scan -> fetch (chunks of < 2^31 bytes).
     // `fin*` vectors receive owned copies of the final hits of all pieces, positions made absolute.
@@ -140,6 +141,7 @@ private:
     DevBuf<uint8_t> sort_tmp_;
     DevBuf<FinalHit> final_sorted_;
     DevBuf<ScanCounters> counters_;
+    DevBuf<uint32_t> spill_, spill_scratch_;   // glob candidates beyond the per-lane storage of the glob pass (k_lookup_spill)
     DevBuf<uint8_t> staging_;  // scan_host only
     // pinned mirror of the final records written by the lookup kernels themselves: FinalHit[mirror_cap_] | u32 ids[mirror_ids_cap_] | i64 offs[..]
     void* mirror_ = nullptr;

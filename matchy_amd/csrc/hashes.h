@@ -97,6 +97,46 @@ MXY_HD uint64_t xxh64(const uint8_t* p, size_t len, uint64_t seed) {
     return h;
 }
 
+// XXH64 of a byte stream that is produced one byte at a time (the lower-cased form of a non-ASCII query of a
+// case-insensitive database, which is never materialised): same digest as xxh64() of the concatenated bytes.
+struct Xxh64Stream {
+    static constexpr uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL,
+                              P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
+    uint64_t v1, v2, v3, v4, lane[4] = {0, 0, 0, 0}, cur = 0, total = 0;
+    uint32_t nlane = 0, ncur = 0;   // complete 8-byte lanes of the current 32-byte stripe, bytes in `cur`
+    MXY_HD explicit Xxh64Stream(uint64_t seed) : v1(seed + P1 + P2), v2(seed + P2), v3(seed), v4(seed - P1) {}
+    static MXY_HD uint64_t round(uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl64(acc, 31); return acc * P1; }
+    static MXY_HD uint64_t merge(uint64_t acc, uint64_t val) { val = round(0, val); acc ^= val; return acc * P1 + P4; }
+    MXY_HD void push(uint32_t byte) {
+        cur |= (uint64_t)(byte & 0xFF) << (8 * ncur);
+        ++total;
+        if (++ncur == 8) {
+            lane[nlane] = cur; cur = 0; ncur = 0;
+            if (++nlane == 4) {
+                v1 = round(v1, lane[0]); v2 = round(v2, lane[1]); v3 = round(v3, lane[2]); v4 = round(v4, lane[3]);
+                nlane = 0;
+            }
+        }
+    }
+    MXY_HD uint64_t finish(uint64_t seed) const {
+        uint64_t h;
+        if (total >= 32) {
+            h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+            h = merge(h, v1); h = merge(h, v2); h = merge(h, v3); h = merge(h, v4);
+        } else {
+            h = seed + P5;
+        }
+        h += total;
+        for (uint32_t k = 0; k < nlane; ++k) { h ^= round(0, lane[k]); h = rotl64(h, 27) * P1 + P4; }
+        uint64_t rest = cur;
+        uint32_t n = ncur;
+        if (n >= 4) { h ^= (rest & 0xFFFFFFFFull) * P1; h = rotl64(h, 23) * P2 + P3; rest >>= 32; n -= 4; }
+        for (; n; --n) { h ^= (rest & 0xFF) * P5; h = rotl64(h, 11) * P1; rest >>= 8; }
+        h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+        return h;
+    }
+};
+
 // Hash of a name of n <= 31 bytes given as four little-endian 8-byte lanes (bytes at and past n are ignored) for the
 // device-side "can any literal key be this name" bitmap (DevDb::lit_bm). Host (bitmap construction from the stored keys)
 // and device (k_validate_dom) only have to agree with each other, so this is a cheap 32-bit multiply-xorshift mix instead

@@ -63,7 +63,6 @@ __device__ bool trie_v6(const DevDb& db, const uint16_t seg[8], uint32_t& data_o
 
 // ---- case-insensitive databases: Rust str::to_lowercase on the device (texts with non-ASCII characters only; pure ASCII is
 // folded inline). The character data comes from matchy_amd/data/lowercase.bin (DevDb::lc_*).
-constexpr uint32_t CI_LOWER_MAX = 256;   // bytes of a lower-cased non-ASCII text that can still be compared with a key (error bit 3 beyond)
 __device__ __forceinline__ uint32_t d_utf8_decode(const uint8_t* s, uint32_t& cp) {   // valid UTF-8 only
     const uint32_t c = s[0];
     if (c < 0x80) { cp = c; return 1; }
@@ -98,62 +97,71 @@ __device__ bool d_cased_ahead(const DevDb& db, const uint8_t* s, uint32_t i, uin
     }
     return false;
 }
-// Lower-cases s[0, n) into out[0, CI_LOWER_MAX) and returns the length of the lower-cased text; bytes past CI_LOWER_MAX are
-// counted but not stored.
-__device__ uint32_t d_to_lowercase(const DevDb& db, const uint8_t* s, uint32_t n, uint8_t* out) {
-    uint32_t o = 0;
-    for (uint32_t i = 0; i < n;) {
-        uint32_t cp;
-        const uint32_t a = d_utf8_decode(s + i, cp);
-        uint32_t len = a, w0 = 0, w1 = 0;
-        bool mapped = false;
-        if (cp < 0x80) {
-            if (o < CI_LOWER_MAX) out[o] = (uint8_t)ascii_lower1(cp);
-            ++o;
-            i += a;
-            continue;
-        }
-        if (cp == 0x3A3) {   // capital sigma: final form iff preceded by a cased letter and not followed by one
-            const bool fin = d_cased_behind(db, s, i) && !d_cased_ahead(db, s, i + a, n);
-            len = 2; w0 = 0xCFu | ((fin ? 0x82u : 0x83u) << 8); mapped = true;
-        } else {
-            uint32_t lo = 0, hi = db.lc_n;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (db.lc_map[mid * 3] < cp) lo = mid + 1; else hi = mid; }
-            if (lo < db.lc_n && db.lc_map[lo * 3] == cp) {
-                const uint32_t e1 = db.lc_map[lo * 3 + 1];
-                len = e1 & 0xFF; w0 = e1 >> 8; w1 = db.lc_map[lo * 3 + 2]; mapped = true;
+// Rust str::to_lowercase of the valid UTF-8 text s[0, n) as a byte stream: the lower-cased form is hashed and compared
+// while it is produced and never stored, so its length is not limited by a buffer.
+struct LowerStream {
+    const DevDb& db;
+    const uint8_t* s;
+    uint32_t n, i = 0, np = 0;
+    uint64_t pend = 0;   // lower-cased bytes of the current character (at most 7)
+    __device__ LowerStream(const DevDb& d, const uint8_t* text, uint32_t len) : db(d), s(text), n(len) {}
+    __device__ bool next(uint32_t& b) {
+        if (np == 0) {
+            if (i >= n) return false;
+            uint32_t cp;
+            const uint32_t a = d_utf8_decode(s + i, cp);
+            if (cp < 0x80) { pend = ascii_lower1(cp); np = 1; }
+            else if (cp == 0x3A3) {   // capital sigma: final form iff preceded by a cased letter and not followed by one
+                const bool fin = d_cased_behind(db, s, i) && !d_cased_ahead(db, s, i + a, n);
+                pend = 0xCFull | ((fin ? 0x82ull : 0x83ull) << 8); np = 2;
+            } else {
+                uint32_t lo = 0, hi = db.lc_n;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (db.lc_map[mid * 3] < cp) lo = mid + 1; else hi = mid; }
+                if (lo < db.lc_n && db.lc_map[lo * 3] == cp) {
+                    const uint32_t e1 = db.lc_map[lo * 3 + 1];
+                    np = e1 & 0xFF; pend = (uint64_t)(e1 >> 8) | ((uint64_t)db.lc_map[lo * 3 + 2] << 24);
+                } else {
+                    pend = 0; np = a;
+                    for (uint32_t k = 0; k < a; ++k) pend |= (uint64_t)s[i + k] << (8 * k);
+                }
             }
+            i += a;
         }
-        const uint64_t bytes = (uint64_t)w0 | ((uint64_t)w1 << 24);
-        for (uint32_t k = 0; k < len; ++k)
-            if (o + k < CI_LOWER_MAX) out[o + k] = mapped ? (uint8_t)(bytes >> (8 * k)) : s[i + k];
-        o += len;
-        i += a;
+        b = (uint32_t)pend & 0xFF; pend >>= 8; --np;
+        return true;
     }
-    return o;
-}
+};
 
 // LiteralHash::lookup (lh:467-525) over the re-hashed device table. Case-insensitive databases (lh:469-472): the query is
-// lower-cased first — pure-ASCII text inline while it is hashed and compared, anything else through d_to_lowercase.
-__device__ bool lit_lookup(const DevDb& db, const uint8_t* s0, uint32_t n0, uint32_t& pattern_id, uint32_t* err) {
+// lower-cased first — pure-ASCII text inline while it is hashed and compared, anything else through LowerStream.
+__device__ bool lit_lookup(const DevDb& db, const uint8_t* s0, uint32_t n0, uint32_t& pattern_id) {
     const uint8_t* s = s0;
     uint32_t n = n0;
-    bool fold = false;
-    uint8_t lowbuf[CI_LOWER_MAX];
+    bool fold = false, stream = false;
+    uint64_t h;
     if (db.ci) {
         uint64_t hi = 0;
         uint32_t k = 0;
         for (; k + 8 <= n0; k += 8) { uint64_t x; __builtin_memcpy(&x, s0 + k, 8); hi |= x; }
         for (; k < n0; ++k) hi |= s0[k];
         if ((hi & 0x8080808080808080ull) == 0) fold = true;
-        else {
-            n = d_to_lowercase(db, s0, n0, lowbuf);
-            if (n > db.lit_max_len) return false;                      // longer than every key
-            if (n > CI_LOWER_MAX) { atomicOr(err, 8u); return false; }  // a database with keys this long and such a query
-            s = lowbuf;
-        }
+        else stream = true;
     }
-    const uint64_t h = fold ? xxh64<true>(s, n, 0) : xxh64<false>(s, n, 0);
+    if (stream) {
+        // non-ASCII query of a case-insensitive database: hash the lower-cased stream (first pass), compare it with the
+        // key of a matching slot while producing it again (second pass)
+        LowerStream ls(db, s0, n0);
+        Xxh64Stream xs(0);
+        uint32_t b;
+        n = 0;
+        while (ls.next(b)) {
+            xs.push(b);
+            if (++n > db.lit_max_len) return false;   // longer than every key
+        }
+        h = xs.finish(0);
+    } else {
+        h = fold ? xxh64<true>(s, n, 0) : xxh64<false>(s, n, 0);
+    }
     uint32_t slot = (uint32_t)(h ^ (h >> 32)) & db.lit_mask;
     for (;;) {
         LitSlot e = db.lit_slots[slot];
@@ -162,16 +170,22 @@ __device__ bool lit_lookup(const DevDb& db, const uint8_t* s0, uint32_t n0, uint
             const uint8_t* q = db.lit_pool + e.str_off;
             uint32_t sl = (uint32_t)q[0] | ((uint32_t)q[1] << 8);
             if (sl == n) {
-                // 8 bytes per step, no early exit: the loads are independent of each other
                 uint64_t diff = 0;
-                uint32_t k = 0;
-                for (; k + 8 <= n; k += 8) {
-                    uint64_t x, y;
-                    __builtin_memcpy(&x, q + 2 + k, 8);
-                    __builtin_memcpy(&y, s + k, 8);
-                    diff |= x ^ (fold ? ascii_lower8(y) : y);
+                if (stream) {
+                    LowerStream ls(db, s0, n0);
+                    uint32_t b, k = 0;
+                    while (ls.next(b)) { diff |= (uint64_t)(q[2 + k] ^ b); ++k; }
+                } else {
+                    // 8 bytes per step, no early exit: the loads are independent of each other
+                    uint32_t k = 0;
+                    for (; k + 8 <= n; k += 8) {
+                        uint64_t x, y;
+                        __builtin_memcpy(&x, q + 2 + k, 8);
+                        __builtin_memcpy(&y, s + k, 8);
+                        diff |= x ^ (fold ? ascii_lower8(y) : y);
+                    }
+                    for (; k < n; ++k) diff |= (uint64_t)(q[2 + k] ^ (fold ? ascii_lower1(s[k]) : (uint32_t)s[k]));
                 }
-                for (; k < n; ++k) diff |= (uint64_t)(q[2 + k] ^ (fold ? ascii_lower1(s[k]) : (uint32_t)s[k]));
                 if (diff == 0) { pattern_id = e.pattern_id; return true; }
             }
         }
@@ -250,11 +264,58 @@ __device__ __forceinline__ TextView text_stage(const uint8_t* log, uint32_t log_
     return tv;
 }
 
+// Storage of the glob matcher. The streaming pass keeps the star stack and the result list of a candidate in a few dozen
+// words per lane (StarStackFixed, GlobSetList); a candidate that needs more — a pattern with more nested '*' than
+// MAX_GLOB_STARS, more than MAX_GLOB_RESULTS matching patterns — is handed to the spill pass (k_lookup_spill), which gives
+// each lane a stack as deep as the longest pattern and one bit per pattern id in global memory (StarStackMem,
+// GlobSetBitmap): Paraglob::find_all has no such limits (pg:1028-1182), so neither has the scan.
+struct StarStackFixed {
+    uint32_t seg[MAX_GLOB_STARS], pos[MAX_GLOB_STARS];
+    __device__ __forceinline__ uint32_t cap() const { return MAX_GLOB_STARS; }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t s, uint32_t p) { seg[i] = s; pos[i] = p; }
+    __device__ __forceinline__ void get(uint32_t i, uint32_t& s, uint32_t& p) const { s = seg[i]; p = pos[i]; }
+};
+struct StarStackMem {
+    uint32_t* mem;   // 2 * n words
+    uint32_t n;
+    __device__ __forceinline__ uint32_t cap() const { return n; }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t s, uint32_t p) { mem[2 * i] = s; mem[2 * i + 1] = p; }
+    __device__ __forceinline__ void get(uint32_t i, uint32_t& s, uint32_t& p) const { s = mem[2 * i]; p = mem[2 * i + 1]; }
+};
+struct GlobSetList {     // sorted unique ids, MAX_GLOB_RESULTS entries
+    uint32_t* out;
+    uint32_t n = 0;
+    bool over = false;
+    __device__ __forceinline__ bool contains(uint32_t id) const { for (uint32_t k = 0; k < n; ++k) if (out[k] == id) return true; return false; }
+    __device__ __forceinline__ void insert(uint32_t id) {
+        uint32_t k = 0;
+        while (k < n && out[k] < id) ++k;
+        if (k < n && out[k] == id) return;
+        if (n >= MAX_GLOB_RESULTS) { over = true; return; }
+        for (uint32_t m = n; m > k; --m) out[m] = out[m - 1];
+        out[k] = id;
+        ++n;
+    }
+};
+struct GlobSetBitmap {   // one bit per pattern id (zeroed by the caller)
+    uint32_t* bits;
+    uint32_t n_ids;      // ids the bitmap covers
+    uint32_t n = 0;
+    bool over = false;
+    __device__ __forceinline__ bool contains(uint32_t id) const { return id < n_ids && ((bits[id >> 5] >> (id & 31)) & 1u); }
+    __device__ __forceinline__ void insert(uint32_t id) {
+        if (id >= n_ids || contains(id)) return;
+        bits[id >> 5] |= 1u << (id & 31);
+        ++n;
+    }
+};
+
 // match_glob_from_buffer / match_segments_impl (pg:1364-1639), case-sensitive. The recursion is replayed with an
 // explicit stack of Star frames; every call of the reference consumes one unit of the 100 000-step budget here too.
 // The header of the segment last looked at and the first 8 bytes of its literal stay in registers: a star re-enters the
 // same segment once per text position.
-__device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView& text, uint32_t* err) {
+template <class ST>
+__device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView& text, ST& stk, bool& over) {
     const uint8_t* pg = db.pg;
     const bool ci = db.ci != 0;
     const uint32_t tn = text.n;
@@ -263,7 +324,7 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
     uint32_t first = ld32(pg + io);
     uint32_t count = ld32(pg + io + 4) & 0xFFFF;
     uint32_t steps = 100000;
-    uint32_t st_seg[MAX_GLOB_STARS], st_pos[MAX_GLOB_STARS], t_seg = 0, t_pos = 0;
+    uint32_t t_seg = 0, t_pos = 0;
     int sp = 0;
     uint32_t pos = 0, seg = 0;
     bool result = false;
@@ -313,9 +374,9 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
                     if (ok) { pos += dlen; ++seg; } else { result = false; ret = true; }
                 } else if (st == 1) {
                     if (seg + 1 >= count) { result = true; ret = true; }
-                    else if (sp >= (int)MAX_GLOB_STARS) { atomicOr(err, 2u); return false; }
+                    else if (sp >= (int)stk.cap()) { over = true; return false; }   // deeper than this pass's stack: spill pass
                     else {
-                        if (sp > 0) { st_seg[sp - 1] = t_seg; st_pos[sp - 1] = t_pos; }   // the innermost frame lives in registers
+                        if (sp > 0) stk.set(sp - 1, t_seg, t_pos);   // the innermost frame lives in registers
                         t_seg = seg; t_pos = pos; ++sp; ++seg;
                     }
                 } else if (st == 2) {
@@ -347,7 +408,7 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
             uint32_t fp = t_pos;
             if (result || fp >= tn) {  // star returns true, or is exhausted and returns false: propagate
                 --sp;
-                if (sp > 0) { t_seg = st_seg[sp - 1]; t_pos = st_pos[sp - 1]; }
+                if (sp > 0) stk.get(sp - 1, t_seg, t_pos);
                 continue;
             }
             fp += utf8_adv(text.at(fp));
@@ -359,34 +420,27 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
     }
 }
 
-// Paraglob::find_all (pg:1028-1182): returns the sorted unique pattern ids in out[0..n)
-__device__ uint32_t glob_find_all(const DevDb& db, const DfaView& dv, const TextView& text, uint32_t* oq, uint32_t* out, uint32_t* err) {
+// Paraglob::find_all (pg:1028-1182): collects the matching pattern ids in `rs`; rs.over is set when this pass's storage is too
+// small for the candidate (it then goes to the spill pass and the partial result is dropped).
+template <class RS, class ST>
+__device__ void glob_find_all(const DevDb& db, const DfaView& dv, const TextView& text, uint32_t* oq, RS& rs, ST& stk) {
     const uint32_t tn = text.n;
-    uint32_t n = 0;
-    auto insert = [&](uint32_t id) {
-        uint32_t k = 0;
-        while (k < n && out[k] < id) ++k;
-        if (k < n && out[k] == id) return;
-        if (n >= MAX_GLOB_RESULTS) { atomicOr(err, 1u); return; }
-        for (uint32_t m = n; m > k; --m) out[m] = out[m - 1];
-        out[k] = id;
-        ++n;
-    };
-    auto contains = [&](uint32_t id) { for (uint32_t k = 0; k < n; ++k) if (out[k] == id) return true; return false; };
+    auto insert = [&](uint32_t id) { rs.insert(id); };
+    auto contains = [&](uint32_t id) { return rs.contains(id); };
     auto consider = [&](uint32_t pid) {
         uint32_t eo = db.patterns_off + pid * 16;
         if (eo + 16 > db.pg_len) return;
         uint32_t entry_id = ld32(db.pg + eo);
         uint32_t ptype = db.pg[eo + 4];
         if (contains(entry_id)) return;
-        if (ptype == 0 || glob_match(db, entry_id, text, err)) insert(entry_id);
+        if (ptype == 0 || glob_match(db, entry_id, text, stk, rs.over)) insert(entry_id);
     };
     for (uint32_t i = 0; i < db.wild_count; ++i) {
         uint32_t wo = db.wild_off + i * 8;
         if (wo + 8 > db.pg_len) continue;
         uint32_t pid = ld32(db.pg + wo);
         if (db.patterns_off + pid * 16 + 16 > db.pg_len) continue;
-        if (!contains(pid) && glob_match(db, pid, text, err)) insert(pid);
+        if (!contains(pid) && glob_match(db, pid, text, stk, rs.over)) insert(pid);
     }
     if (db.ac_size > 0 && tn > 0) {
         const uint8_t* ac = db.pg + db.ac_start;
@@ -439,7 +493,6 @@ __device__ uint32_t glob_find_all(const DevDb& db, const DfaView& dv, const Text
             }
         }
     }
-    return n;
 }
 
 // true when the text reaches a state of the flattened AC automaton that has output literals (necessary for any glob
@@ -549,7 +602,7 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
         uint32_t i = base + threadIdx.x;
         Hit h{};
-        bool emit = false, defer = false;
+        bool emit = false, defer = false, spill = false;
         uint32_t globs[GLOB ? MAX_GLOB_RESULTS : 1];
         uint32_t ng = 0;
         Candidate c{0, 0xFFFFFFFFu, 0, 0};
@@ -574,9 +627,15 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
                 if (!GLOB && p.ac_filter && ac_touches_output(db, dv, text, tl)) defer = true;
                 else {
                     uint32_t pid = 0xFFFFFFFFu;
-                    if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q, &p.counters->error)) pid = q; }
-                    if constexpr (GLOB) ng = glob_find_all(db, dv, text_stage(p.log, p.len, c.start, tl, twin + threadIdx.x * GLOB_WIN_WORDS), outq + threadIdx.x * GLOB_OUTQ, globs, &p.counters->error);
-                    if (pid != 0xFFFFFFFFu || ng) { h.kind = 3; h.a = pid; h.n_globs = (uint16_t)ng; emit = true; }
+                    if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q)) pid = q; }
+                    if constexpr (GLOB) {
+                        GlobSetList rs{globs};
+                        StarStackFixed stk;
+                        glob_find_all(db, dv, text_stage(p.log, p.len, c.start, tl, twin + threadIdx.x * GLOB_WIN_WORDS), outq + threadIdx.x * GLOB_OUTQ, rs, stk);
+                        ng = rs.n;
+                        spill = rs.over;   // more results / deeper star nesting than this pass holds: the spill pass answers
+                    }
+                    if (!spill && (pid != 0xFFFFFFFFu || ng)) { h.kind = 3; h.a = pid; h.n_globs = (uint16_t)ng; emit = true; }
                 }
             }
         }
@@ -592,9 +651,68 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
             cw.append(emit, h, p.hits, p.hit_cap, &p.counters->n_hits, SH);
         }
         if (!GLOB && p.ac_filter) ww.append(defer, i, p.glob_work, p.glob_work_cap, &p.counters->n_glob_work);
+        if (GLOB && spill) {   // rare: one atomic per candidate
+            const uint32_t q = atomicAdd(&p.counters->n_spill, 1u);
+            if (q < p.spill_cap) p.spill[q] = i;
+        }
     }
     cw.pad_rest(p.hits, p.hit_cap, SH);
     if (!GLOB && p.ac_filter) ww.flush(p.glob_work, p.glob_work_cap, &p.counters->n_glob_work);
+    if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->hits_true, cw.total);
+}
+
+// k_lookup_spill — the candidates the glob pass could not hold (GlobSetList / StarStackFixed overflow): one lane per candidate,
+// result set = one bit per pattern id, star stack as deep as the longest pattern, both in global scratch owned by the thread
+// (LookupParams::spill_scratch). The ids leave in ascending order through the id list, so the record has the same form as
+// one written by k_lookup.
+constexpr int SPILL_THREADS = 64;
+__global__ __launch_bounds__(SPILL_THREADS) void k_lookup_spill(LookupParams p, DevDb db) {
+    __shared__ uint8_t cls[256];
+    __shared__ uint32_t rows[DFA_LDS_ENTRIES_GLOB];
+    __shared__ uint64_t twin[SPILL_THREADS * GLOB_WIN_WORDS];
+    __shared__ uint32_t outq[SPILL_THREADS * GLOB_OUTQ];
+    const DfaView dv = dfa_stage<DFA_LDS_ENTRIES_GLOB>(db, cls, rows);
+    __syncthreads();
+    const uint32_t n = min(p.counters->n_spill, p.spill_cap);
+    const uint32_t stride = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t bit_words = (db.pattern_count + 31) / 32;
+    uint32_t* bits = p.spill_scratch + (size_t)tid * p.spill_words;
+    ChunkWriter<Hit, HIT_CHUNK> cw;
+    Hit SH{};
+    SH.kind = 0xFF;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint32_t k = base + threadIdx.x;
+        Hit h{};
+        bool emit = false;
+        if (k < n) {
+            const uint32_t i = p.spill[k];
+            const Candidate c = i < p.cand_cap ? p.cands[i] : Candidate{0, 0xFFFFFFFFu, 0, 0};
+            if (c.len_type != 0xFFFFFFFFu) {
+                const uint32_t tl = c.len_type & 0xFFFFFF;
+                h.cand = i; h.start = c.start; h.len_type = c.len_type;
+                uint32_t pid = 0xFFFFFFFFu;
+                if (db.has_literal) { uint32_t q; if (lit_lookup(db, p.log + c.start, tl, q)) pid = q; }
+                for (uint32_t w = 0; w < bit_words; ++w) bits[w] = 0;
+                GlobSetBitmap rs{bits, db.pattern_count};
+                StarStackMem stk{bits + bit_words, (p.spill_words - bit_words) / 2};
+                glob_find_all(db, dv, text_stage(p.log, p.len, c.start, tl, twin + threadIdx.x * GLOB_WIN_WORDS), outq + threadIdx.x * GLOB_OUTQ, rs, stk);
+                uint32_t ng = rs.n;
+                if (rs.over || ng > 0xFFFFu) { atomicOr(&p.counters->error, 1u); ng = 0; }   // the record counts ids in 16 bits
+                if (ng) {
+                    const uint32_t io = atomicAdd(&p.counters->n_ids, ng);
+                    h.ids_off = io;
+                    uint32_t o = io;
+                    for (uint32_t w = 0; w < bit_words; ++w)
+                        for (uint32_t m = bits[w]; m; m &= m - 1, ++o)
+                            if (o < p.ids_cap) p.ids[o] = 32 * w + (uint32_t)__builtin_ctz(m);
+                }
+                if (pid != 0xFFFFFFFFu || ng) { h.kind = 3; h.a = pid; h.n_globs = (uint16_t)ng; emit = true; }
+            }
+        }
+        if (p.direct) pack_record(p.pk, emit, h, nullptr);   // ids from the id list (h.ids_off)
+        else cw.append(emit, h, p.hits, p.hit_cap, &p.counters->n_hits, SH);
+    }
+    cw.pad_rest(p.hits, p.hit_cap, SH);
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->hits_true, cw.total);
 }
 
@@ -614,6 +732,8 @@ void launch_lookup(const LookupParams& p_in, const DevDb& db, int grid, hipStrea
     } else {
         hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(256), 0, stream, p, db);
     }
+    // candidates beyond the glob pass's per-lane storage (normally none: the kernel reads the counter and returns)
+    if (db.has_glob && p.spill_scratch) hipLaunchKernelGGL(k_lookup_spill, dim3(p.spill_blocks), dim3(SPILL_THREADS), 0, stream, p, db);
 }
 
 }  // namespace mxy

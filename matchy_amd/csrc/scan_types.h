@@ -78,6 +78,7 @@ struct DevDb {
     uint32_t patterns_off, pattern_count;
     uint32_t wild_off, wild_count;
     uint32_t glob_seg_off;
+    uint32_t glob_max_segs;   // longest pattern in segments: bounds the star nesting of the matcher
     // dense DFA of the Aho-Corasick automaton (DbImage::build_ac_dfa), or null: next state = dfa[state * dfa_k +
     // dfa_cls[byte]] (bit 31: that state has output literals), dfa_node[state] = its node offset in the AC section
     const uint32_t* dfa;
@@ -123,7 +124,7 @@ struct ScanCounters {
     alignas(128) unsigned long long lines;        // '\n' bytes
     uint32_t cand_true;              // candidates really written (n_cand counts chunk-allocated slots incl. padding)
     uint32_t hits_true;
-    uint32_t error;                  // bit0: glob result list overflow, bit1: glob star-stack overflow, bit2: candidate > 16 MiB, bit3: lower-cased non-ASCII candidate > 256 B (case-insensitive DB)
+    uint32_t error;                  // bit0: a candidate matches more than 65535 glob patterns (16-bit id count of the hit record), bit2: candidate > 16 MiB (24-bit length)
     uint32_t reserved0;
     alignas(128) uint32_t n_cand;    // candidates appended (may exceed capacity → overflow)
     alignas(128) uint32_t n_dom;     // domain anchors (first byte of a label that follows a dot)
@@ -135,6 +136,7 @@ struct ScanCounters {
     alignas(128) uint32_t n_final;   // dense final hit records written by pack_record
     uint32_t n_final_ids;            // entries of the pattern-id / data-offset side arrays
     alignas(128) uint32_t n_glob_work;   // candidates whose text reaches an output state of the AC automaton (glob work list)
+    uint32_t n_spill;                // candidates handed to k_lookup_spill (more glob results / deeper star nesting than a lane of the glob pass holds)
 };
 
 struct TokParams {
@@ -214,6 +216,13 @@ struct LookupParams {
     uint32_t* glob_work;
     uint32_t glob_work_cap;
     uint32_t ac_filter, from_work;
+    // glob candidates that exceed the per-lane storage of the glob pass: candidate indices, and per-thread scratch of the
+    // spill pass (spill_words words per thread: one bit per pattern id, then the star stack)
+    uint32_t* spill;
+    uint32_t spill_cap;
+    uint32_t* spill_scratch;
+    uint32_t spill_words;
+    uint32_t spill_blocks;
     // bulk scans: direct = 1 -> every hit is written as its final record at once (pack_record) instead of going through
     // the hit list and k_pack
     uint32_t direct;

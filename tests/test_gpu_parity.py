@@ -741,3 +741,73 @@ def test_case_insensitive_database(M, oracle, seed):
         else:
             assert got is None, (q, got)
     db.close()
+
+
+def test_glob_results_and_star_nesting_beyond_lane_storage(M, oracle):
+    """Paraglob::find_all has no cap on results or on '*' nesting (paraglob_offset.rs:1028-1182, 1402-1639). The glob pass of
+    k_lookup keeps 32 ids and 24 star frames per lane; a candidate beyond that goes to the spill pass (one bit per pattern id,
+    a stack as deep as the longest pattern) and gets the same answer as from the CPU path — scan and single query."""
+    b = M.DatabaseBuilder(build_epoch=7)
+    name = "alpha.bravo.charlie.delta.echo.foxtrot.golf.hotel.example.com"
+    n_over = 0
+    # 100 distinct globs that all match `name`
+    for i in range(100):
+        head = name[: 1 + (i % 40)]
+        tail = name[len(name) - 4 - (i // 40) * 3:]
+        key = head + "*" + tail if i % 2 else "*" + name[i % 30 + 1:]
+        b.add_entry(key + ("" if i < 50 else "*"), {"g": i})
+        n_over += 1
+    # a pattern with 40 '*' (deeper than the 24 frames a lane of the glob pass holds)
+    deep = "*".join(name[k] for k in range(0, 41)) + "*com"
+    b.add_entry(deep, {"deep": 1})
+    b.add_entry("*.other-suffix.org", {"o": 1})
+    b.add_entry("plain.example.net", {"lit": 1})
+    blob = b.build()
+    b.close()
+    log = (b"GET http://" + name.encode() + b"/x 1.2.3.4\n" + b"host=www.other-suffix.org plain.example.net\n") * 3 + b"ref=" + name.encode() + b"\n"
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, log)
+    assert gs == ws
+    assert gh == wh
+    assert gl == wl
+    big = [h for h in wh if log[h["start"]:h["end"]] == name.encode()]
+    assert len(big) == 4 and all(len(h["ids"]) > 60 for h in big)
+    db = M.Database(blob)
+    odb = oracle.Database(blob)
+    for q in (name, "www.other-suffix.org", "plain.example.net", "nothing.example.org"):
+        want, got = odb.lookup(q), db.lookup(q)
+        if want["kind"] == "pattern" and want["data"] and want["data"][0] is not None:
+            assert got == {"found": True, "prefix_len": 0, "data": want["data"][0]}, q
+        else:
+            assert got is None, (q, got)
+    db.close()
+
+
+def test_case_insensitive_long_non_ascii_key(M, oracle):
+    """A case-insensitive database with a non-ASCII literal key far longer than 256 bytes (the device lower-cases the query as a
+    stream, no buffer limits it): lit:467-525 with to_lowercase, scan and single query against the oracle."""
+    label = "Ünï-Çödé" * 9                      # 8 chars / 12 bytes each: 108 bytes per label
+    body = ".".join([label] * 4)                # > 400 bytes, valid domain labels (high bytes are domain characters)
+    key = body + ".example.com"
+    b = M.DatabaseBuilder(build_epoch=7, case_insensitive=True)
+    b.add_entry(key, {"long": 1})
+    b.add_entry("short-ünï.example.org", {"short": 1})
+    blob = b.build()
+    b.close()
+    # the public-suffix test of the extractor is case-sensitive (Q1): the suffix stays lower-case, the labels vary
+    variants = [key, body.upper() + ".example.com", body.lower() + ".example.com",
+                "".join(c.upper() if i % 3 else c.lower() for i, c in enumerate(body)) + ".example.com"]
+    log = b"".join(b"GET http://" + v.encode() + b"/p " for v in variants) + "\nhost=SHORT-ÜNÏ.example.org x\n".encode() + b"http://" + key.encode()[:-5] + b"x.com/\n"
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, log)
+    assert gs == ws
+    assert gh == wh
+    assert gl == wl
+    assert len(wh) == 5
+    db = M.Database(blob)
+    odb = oracle.Database(blob)
+    for q in variants + ["SHORT-ÜNÏ.example.org", key[:-1], key.upper()]:
+        want, got = odb.lookup(q), db.lookup(q)
+        if want["kind"] == "pattern" and want["data"] and want["data"][0] is not None:
+            assert got == {"found": True, "prefix_len": 0, "data": want["data"][0]}, q
+        else:
+            assert got is None, (q, got)
+    db.close()

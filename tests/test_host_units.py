@@ -15,3 +15,9 @@ def test_anchor_bit_planes(tmp_path):
     # bit transpose + byte classes of k_anchor's bit-sliced front end, all byte values in every bit slot
     out = _build_and_run("tests/cpp/test_anchor_planes.cpp", tmp_path)
     assert "anchor_planes ok" in out
+
+
+def test_xxh64_stream(tmp_path):
+    # the byte-at-a-time XXH64 used for lower-cased non-ASCII queries equals the one-shot hash (spec vector included)
+    out = _build_and_run("tests/cpp/test_xxh64_stream.cpp", tmp_path)
+    assert "xxh64 stream ok" in out
