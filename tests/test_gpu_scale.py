@@ -183,3 +183,55 @@ def test_submit_wait_overlapping_batches(M, oracle):
         hip.hipStreamDestroy(st)
         hip.hipFree(p)
     db.close()
+
+
+def test_config5_full_database(M, oracle):
+    """BASELINE configs[4] at its real database size: 10 M indicators (9 M CIDR-heavy IPs + 1 M domains), the record width
+    chosen by the node count of the finished tree (no environment hook), 1 M log lines against the oracle: counters and
+    the complete hit set. Nearly every line hits (the /24 bitmap filters little): the dense output path."""
+    from tools import synth
+    cfg = synth.config("c5")
+    blob = synth.build_db(cfg)
+    lines = int(os.environ.get("MXY_C5_LINES", "1000000"))
+    log = synth.make_log(cfg, 0, lines)
+    db = M.Database(blob)
+    md = db.metadata()
+    assert md["node_count"] > (1 << 24) and md["record_size"] == 28, (md["node_count"], md["record_size"])
+    sc = M.Scanner(db)
+    res = sc.scan(log)
+    hits = res.hits()
+    stats = (res.lines, res.candidates)
+    res.close()
+    odb = oracle.Database(blob)
+    want, _, st = odb.scan(log, threads=min(len(os.sched_getaffinity(0)), 16), cache=0, want_json=False)
+    assert stats == (st.lines, st.candidates)
+    assert len(hits) == len(want) and len(want) > lines
+    assert hits == want
+    sc.close(); db.close()
+
+
+@pytest.mark.parametrize("cfgname", ["c3", "c4"])
+def test_full_database_multi_batch(M, oracle, cfgname):
+    """BASELINE configs[2] (1 M domain / hash literals) and configs[3] (100 K indicators incl. 10 K globs) at full database size:
+    three consecutive batches of the log through one scanner (buffers and lists are reused between batches), each against the
+    oracle."""
+    from tools import synth
+    cfg = synth.config(cfgname)
+    blob = synth.build_db(cfg)
+    db = M.Database(blob)
+    sc = M.Scanner(db)
+    odb = oracle.Database(blob)
+    per = 250000
+    total = 0
+    for bi in range(3):
+        log = synth.make_log(cfg, bi * per, per if bi != 1 else per // 3)   # a short batch in the middle
+        res = sc.scan(log)
+        hits = res.hits()
+        stats = (res.lines, res.candidates)
+        res.close()
+        want, _, st = odb.scan(log, threads=min(len(os.sched_getaffinity(0)), 16), cache=0, want_json=False)
+        assert stats == (st.lines, st.candidates)
+        assert hits == want
+        total += len(want)
+    assert total > 1000
+    sc.close(); db.close()
