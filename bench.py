@@ -160,6 +160,27 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_bytes / (elapsed / args.steps) / 1e9
 
+    # ---- the same K steps with the hit records left in device memory (MATCHY_SCAN_FETCH_DEVICE): what a consumer that stays on
+    # the GPU gets, and the only way a workload where nearly every line hits is not bound by 16 bytes per hit over PCIe
+    def step_dev():
+        res = scanner.scan_device(dlog.data_ptr(), nbytes, stream=stream, fetch_mode=4)
+        out = (res.lines, res.candidates, res.n_hits)
+        res._raw.hits = None
+        res.close()
+        return out
+    for _ in range(2):
+        dcounts = step_dev()
+    barrier()
+    td0 = time.perf_counter()
+    for _ in range(args.steps):
+        dcounts = step_dev()
+    barrier()
+    tdev = time.perf_counter() - td0
+    dagg = sharding.aggregate(dist, world, coll_dev, tdev, nbytes, dcounts[0], dcounts[2], dcounts[1])
+    device_results = {"value": round(float(dagg["bytes"]) / (dagg["elapsed_s"] / args.steps) / 1e9, 3), "unit": "GB/s",
+                      "ms_per_step": round(dagg["elapsed_s"] / args.steps * 1e3, 4), "same_counts": bool(tuple(dcounts) == tuple(counts)),
+                      "note": "hit records stay in HBM (fetch_mode 4); `value` above moves them to host memory"}
+
     # ---- the same K steps once more with several batches in flight (how a streaming host drives the scanners: submit /
     # wait, one stream per scanner). Reported beside the headline numbers, never instead of them: with overlapping
     # batches the kernels time-share the GPU and their individual durations say nothing about the kernels.
@@ -306,6 +327,7 @@ def main():
             "cpu_baseline": cpu,
             "cpu_baseline_t1": cpu_t1,
             "end_to_end": end_to_end,
+            "device_results": device_results,
             "pipelined": pipelined,
             "parity_vs_oracle": parity,
         }

@@ -260,6 +260,10 @@ int32_t matchy_scanner_scan(matchy_scanner_t *scanner, const uint8_t *data, size
  * from the scanner and stay valid until its next scan or matchy_scanner_free; 3 = owned copy in canonical order. */
 #define MATCHY_SCAN_FETCH_COUNTS 0u
 #define MATCHY_SCAN_FETCH_HITS 1u
+/* 4 = the records stay in device memory: hits / pattern_ids / data_offsets are DEVICE pointers borrowed from the scanner
+ * (device order, valid until its next scan), only the counters cross the bus. For consumers that aggregate or filter on the
+ * GPU, and for inputs where nearly every line hits: 16 bytes per hit over PCIe otherwise bound the scan. */
+#define MATCHY_SCAN_FETCH_DEVICE 4u
 #define MATCHY_SCAN_FETCH_SORTED 3u
 int32_t matchy_scanner_scan_device(matchy_scanner_t *scanner, const void *device_ptr, size_t len, void *hip_stream,
                                    uint32_t fetch_mode, matchy_scan_result_t *out);

@@ -174,6 +174,17 @@ void fill_result(const FinalHit* fin, size_t n_fin, const uint32_t* ids, const l
     out->_internal = in;
 }
 
+// fetch_mode MATCHY_SCAN_FETCH_DEVICE: the records stay where the lookup kernel wrote them (device memory); only the counters
+// come back.
+void fill_device_result(Scanner& sc, const ScanOutput& so, uint64_t bytes, matchy_scan_result_t* out) {
+    memset(out, 0, sizeof(*out));
+    out->lines = so.lines; out->candidates = so.n_cand; out->bytes = bytes;
+    out->n_hits = so.n_hits; out->n_ids = sc.device_final_id_count();
+    out->hits = reinterpret_cast<const matchy_scan_hit_t*>(sc.device_final());
+    out->pattern_ids = sc.device_final_ids();
+    out->data_offsets = reinterpret_cast<const int64_t*>(sc.device_final_offs());
+}
+
 }  // namespace
 
 extern "C" {
@@ -660,6 +671,7 @@ int32_t matchy_scanner_scan_device(matchy_scanner_t* s, const void* dptr, size_t
         h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st, (fetch_mode & 1) && !sorted);
         ScanOutput so;
         h->sc->fetch(so, false, st, (fetch_mode & 1) ? HITS_FINAL : HITS_NONE, sorted);
+        if (fetch_mode == MATCHY_SCAN_FETCH_DEVICE) { fill_device_result(*h->sc, so, len, out); return MATCHY_SUCCESS; }
         fill_result(so.fin, so.n_fin, so.fin_ids, so.fin_offs, so.n_fin_ids, so.lines, so.n_cand, len, !sorted, sorted, out);
         if (!(fetch_mode & 1)) out->n_hits = so.n_hits;  // count only; `hits` stays NULL
         return MATCHY_SUCCESS;
@@ -693,6 +705,7 @@ int32_t matchy_scanner_wait(matchy_scanner_t* s, matchy_scan_result_t* out) {
         hipStream_t st = reinterpret_cast<hipStream_t>(h->pending_stream);
         ScanOutput so;
         h->sc->fetch(so, false, st, (fetch_mode & 1) ? HITS_FINAL : HITS_NONE, sorted);
+        if (fetch_mode == MATCHY_SCAN_FETCH_DEVICE) { fill_device_result(*h->sc, so, h->pending_len, out); return MATCHY_SUCCESS; }
         fill_result(so.fin, so.n_fin, so.fin_ids, so.fin_offs, so.n_fin_ids, so.lines, so.n_cand, h->pending_len, !sorted, sorted, out);
         if (!(fetch_mode & 1)) out->n_hits = so.n_hits;
         return MATCHY_SUCCESS;

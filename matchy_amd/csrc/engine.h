@@ -110,6 +110,11 @@ public:
     void fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode = HITS_FINAL, bool sorted = false);
     // One synthetic candidate (single-query API): `text` is uploaded, only the lookup kernel runs.
     void setup_spill(LookupParams& lp);
+    // the dense hit records of the last lookup scan as the kernel left them in device memory (MATCHY_SCAN_FETCH_DEVICE)
+    const FinalHit* device_final() const { return final_.p; }
+    const uint32_t* device_final_ids() const { return final_ids_.p; }
+    const long long* device_final_offs() const { return final_offs_.p; }
+    size_t device_final_id_count() const { return host_counters_.n_final_ids; }
     void lookup_one(const std::string& text, Candidate c, ScanOutput& out);
     // Convenience: host buffer -> internal device buffer -> scan -> fetch (chunks of < 2^31 bytes).
     // `fin*` vectors receive owned copies of the final hits of all pieces, positions made absolute.

@@ -137,6 +137,16 @@ def test_scan_device_fetch_modes(M, oracle, cfgname, mirror, monkeypatch):
         r3.close()
         assert h3 == want
         assert sorted(h1, key=key) == sorted(want, key=key)
+        # fetch_mode 4: the records stay in device memory (borrowed device pointers); copied back here they are the same set
+        r4 = sc.scan_device(d.data_ptr(), len(log), fetch_mode=4)
+        assert (r4.lines, r4.candidates, r4.n_hits) == (st.lines, st.candidates, len(want))
+        buf = (M._ScanHit * r4.n_hits)()
+        src = ctypes.cast(r4._raw.hits, ctypes.c_void_p)
+        assert hip.hipMemcpy(buf, src, ctypes.c_size_t(16 * r4.n_hits), 2) == 0
+        recs4 = sorted((b.start, b.start + (b.len_type & 0xFFFFFF), M.ITEM_TYPE_NAMES[b.len_type >> 24], b.kind, b.prefix_len, b.n_ids) for b in buf)
+        r4._raw.hits = None   # device pointers: nothing for the host-side accessors to read
+        r4.close()
+        assert recs4 == sorted((h["start"], h["end"], h["type"], 2 if h["kind"] == "ip" else 3, h["prefix_len"], len(h["ids"])) for h in want)
     sc.close(); db.close()
     hip.hipFree(dptr)
 
