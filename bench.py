@@ -23,6 +23,124 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
+def run_strong(args, rank, local_rank, world, rehearse, torch, dist, dev, coll_dev):
+    """--scaling strong: ONE job (BASELINE configs[3]: 100 M lines of the C4 log by default) cut into `world` contiguous line
+    ranges (sharding.strong_block_for_rank = split_at_newlines semantics), database replicated, no data-path collective.
+    Reported separately: `value` = the whole job from HBM-resident input (every rank's range uploaded before the timed
+    region, scanned in batches of <= --batch-lines lines), and `end_to_end` = the same ranges' first batches from pinned host
+    memory through two scanners on two streams per GPU (H2D of one batch under the kernels of the other)."""
+    import threading
+    import matchy_amd as M
+    from matchy_amd import sharding
+    from tools import synth
+    cfg = synth.config(args.config)
+    blob = synth.build_db(cfg)
+    db = M.Database(blob)
+    blk = sharding.strong_block_for_rank(rank, world, args.lines)
+    per = args.batch_lines
+    batches = [(blk.first_line + o, min(per, blk.n_lines - o)) for o in range(0, blk.n_lines, per)]
+    # generate (all host cores of this rank's share, the generator is counter-based) and upload, batch by batch
+    cap = per * 200 + (1 << 20)
+    dlog = torch.empty(len(batches) * cap, dtype=torch.uint8, device=dev)
+    stage = torch.empty(cap, dtype=torch.uint8).pin_memory()
+    keep_host = []                       # the first batches stay in pinned host memory for the end-to-end measurement
+    sizes, lines_total = [], 0
+    nthreads = max(1, min(16, len(os.sched_getaffinity(0)) // max(1, min(world, 8))))
+    for bi, (first, n) in enumerate(batches):
+        # sub-blocks generated in parallel straight into the pinned stage; they are contiguous because every sub-block is
+        # sized first (the generator reports the bytes it needs)
+        sub = [(first + k * (n // nthreads), (n // nthreads) if k < nthreads - 1 else n - (nthreads - 1) * (n // nthreads)) for k in range(nthreads)]
+        need = [0] * nthreads
+        def size_of(k):
+            need[k] = synth.make_log_into(cfg, sub[k][0], sub[k][1], 0, 0) if sub[k][1] else 0
+        ths = [threading.Thread(target=size_of, args=(k,)) for k in range(nthreads)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+        offs = [sum(need[:k]) for k in range(nthreads)]
+        total = sum(need)
+        if total > cap:
+            raise SystemExit("batch larger than its buffer: lower --batch-lines")
+        def gen(k):
+            if sub[k][1]:
+                synth.make_log_into(cfg, sub[k][0], sub[k][1], stage.data_ptr() + offs[k], need[k])
+        ths = [threading.Thread(target=gen, args=(k,)) for k in range(nthreads)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+        dlog[bi * cap: bi * cap + total].copy_(stage[:total])
+        torch.cuda.synchronize()
+        if len(keep_host) < args.e2e_batches:
+            h = torch.empty(total, dtype=torch.uint8).pin_memory()
+            h.copy_(stage[:total])
+            keep_host.append(h)
+        sizes.append(total)
+        lines_total += n
+    nbytes = sum(sizes)
+    stream = torch.cuda.current_stream().cuda_stream
+    scanner = M.Scanner(db, device=local_rank, profile=True)
+
+    def one_pass():
+        ln = cand = hits = 0
+        kms = 0.0
+        for bi, sz in enumerate(sizes):
+            r = scanner.scan_device(dlog.data_ptr() + bi * cap, sz, stream=stream, fetch_mode=1)
+            ln += r.lines; cand += r.candidates; hits += r.n_hits
+            r.close()
+            kms += scanner.timing_ms()["total"]
+        return ln, cand, hits, kms
+
+    def barrier():
+        sharding.barrier(dist, world, torch.cuda.synchronize)
+    for _ in range(max(1, args.warmup)):
+        counts = one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(args.steps):
+        counts = one_pass()
+        kernel_ms += counts[3]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    agg = sharding.aggregate(dist, world, coll_dev, elapsed, nbytes, counts[0], counts[2], counts[1])
+    kagg = sharding.aggregate(dist, world, coll_dev, kernel_ms * 1e-3, 0, 0, 0, 0)
+    # ---- end to end from pinned host memory: two scanners, two threads, alternating batches
+    e2e = None
+    if keep_host:
+        scs = [M.Scanner(db, device=local_rank), M.Scanner(db, device=local_rank)]
+        def worker(w, out):
+            n = 0
+            for bi in range(w, len(keep_host), 2):
+                r = scs[w].scan_ptr(keep_host[bi].data_ptr(), keep_host[bi].numel())
+                n += r.n_hits
+                r.close()
+            out[w] = n
+        for rep in range(2):   # first repetition warms the staging buffers
+            out = [0, 0]
+            barrier()
+            te = time.perf_counter()
+            ths = [threading.Thread(target=worker, args=(w, out)) for w in range(2)]
+            [t.start() for t in ths]; [t.join() for t in ths]
+            barrier()
+            te = time.perf_counter() - te
+        eb = sum(h.numel() for h in keep_host)
+        eagg = sharding.aggregate(dist, world, coll_dev, te, eb, 0, sum(out), 0)
+        e2e = {"value": round(eagg["bytes"] / eagg["elapsed_s"] / 1e9, 2), "unit": "GB/s", "bytes": eagg["bytes"],
+               "entry": "matchy_scanner_scan from pinned host memory, two scanners per GPU on their own streams, H2D included"}
+        for sc in scs:
+            sc.close()
+    if rank == 0:
+        step_s = agg["elapsed_s"] / args.steps
+        print(json.dumps({
+            "metric": "log GB/s scanned (matchy match hot path, 100K IoCs)", "value": round(agg["bytes"] / step_s / 1e9, 3), "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]-style strong scaling: ONE job of {args.lines} nginx-style lines ({agg['bytes']} B), config {args.config}, "
+                                   f"cut into {world} contiguous newline-aligned ranges, batches of <= {per} lines, DB replicated, no collective",
+                       "total_lines": args.lines, "total_bytes": agg["bytes"]},
+            "lines_per_s": round(agg["lines"] / step_s, 1), "hits_per_step": agg["hits"], "candidates_per_step": agg["candidates"],
+            "kernel_only": {"value": round(agg["bytes"] / (kagg["elapsed_s"] / args.steps) / 1e9, 3), "unit": "GB/s",
+                            "note": "sum of the kernel time of all batches on the slowest rank (HIP events), input resident in HBM"},
+            "end_to_end": e2e}))
+    scanner.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -38,7 +156,16 @@ def main():
                     "(scanners on their own streams) and report it as the extra object `pipelined`. Off by default so that a profile "
                     "of the default command shows every kernel running alone")
     ap.add_argument("--extract-flags", type=int, default=0, help="diagnostics only: MATCHY_EXTRACT_* bit mask (0 = what the DB needs)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="strong: --lines is the size of ONE job that is cut across the GPUs "
+                    "(default 100 M lines of --config c4 = BASELINE configs[3])")
+    ap.add_argument("--batch-lines", type=int, default=5_000_000, help="strong scaling: lines per batch (a batch must stay below 2 GiB)")
+    ap.add_argument("--e2e-batches", type=int, default=4, help="strong scaling: batches per rank kept in pinned host memory for the end-to-end measurement")
     args = ap.parse_args()
+    if args.scaling == "strong":
+        if "--lines" not in " ".join(sys.argv):
+            args.lines = 100_000_000
+        if "--config" not in " ".join(sys.argv):
+            args.config = "c4"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -61,6 +188,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     coll_dev = torch.device("cpu") if rehearse else dev   # where the reduced scalars live
+    if args.scaling == "strong":
+        run_strong(args, rank, local_rank, world, rehearse, torch, dist, dev, coll_dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     import matchy_amd as M
     from matchy_amd import sharding

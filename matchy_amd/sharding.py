@@ -24,6 +24,16 @@ def block_for_rank(rank: int, world: int, lines_per_gpu: int) -> Block:
     return Block(first_line=rank * lines_per_gpu, n_lines=lines_per_gpu)
 
 
+def strong_block_for_rank(rank: int, world: int, total_lines: int) -> Block:
+    """Strong scaling: ONE job of `total_lines` lines cut into `world` contiguous line ranges whose sizes differ by at most
+    one line (the generator is line-indexed, so every cut falls on a newline: the split_at_newlines rule for a real file)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, rem = divmod(total_lines, world)
+    first = rank * base + min(rank, rem)
+    return Block(first_line=first, n_lines=base + (1 if rank < rem else 0))
+
+
 def split_at_newlines(data: bytes, parts: int):
     """Strong-scaling helper for a real file: cut `data` into `parts` contiguous ranges that end on '\\n'
     (the last range takes the unterminated tail). Returns [(start, end)]; empty ranges are possible."""

@@ -346,3 +346,26 @@ def test_inspect_and_validate(cli, tmp_path):
     assert vb.returncode == 1 and b"VALIDATION FAILED" in vb.stdout
     assert json.loads(_run([cli, "validate", str(bad), "-j"]).stdout)["is_valid"] is False
     assert _run([cli, "validate", str(dbp), "--level", "paranoid"]).returncode == 1
+
+
+@pytest.mark.gpu
+def test_match_on_several_devices(cli, tmp_path, oracle):
+    """`matchy match --devices 0,1` / `--devices all` on a box with at least two GPUs: line blocks go to one worker and
+    scanner per device (database uploaded to each), output and counters equal the oracle's. Skipped on one-GPU boxes (the
+    same code path runs there with one device listed several times: test_match_config1_end_to_end)."""
+    import matchy_amd as M
+    from tools import synth
+    if M.lib().matchy_amd_device_count() < 2:
+        pytest.skip("needs at least two GPUs")
+    cfg, rows = _c1_csv(tmp_path / "c1.csv")
+    dbp = tmp_path / "c1.mxy"
+    assert _run([cli, "build", str(tmp_path / "c1.csv"), "-o", str(dbp), "-f", "csv"]).returncode == 0
+    log = synth.make_log(cfg, 0, 60000)
+    logp = tmp_path / "access.log"
+    logp.write_bytes(log)
+    want_hits, want_lines, st = oracle.Database(dbp.read_bytes()).scan(log, source=str(logp))
+    for devs in ("0,1", "all", "1"):
+        r = _run([cli, "match", str(dbp), str(logp), "--devices", devs, "--batch-bytes", "400000", "-s"])
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.decode().splitlines() == want_lines
+        assert f"[INFO] Candidates tested: {st.candidates:,}".encode() in r.stderr

@@ -77,6 +77,19 @@ def test_block_for_rank_and_split():
     assert sharding.split_at_newlines(b"no newline at all", 2) == [(0, 17), (17, 17)]
 
 
+def test_strong_blocks_cover_the_job_once():
+    from matchy_amd import sharding
+    for total, world in ((100, 8), (7, 3), (5, 8), (100_000_000, 8), (1, 1)):
+        blocks = [sharding.strong_block_for_rank(r, world, total) for r in range(world)]
+        assert blocks[0].first_line == 0
+        for a, b in zip(blocks, blocks[1:]):
+            assert a.first_line + a.n_lines == b.first_line
+        assert blocks[-1].first_line + blocks[-1].n_lines == total
+        assert max(b.n_lines for b in blocks) - min(b.n_lines for b in blocks) <= 1
+    with pytest.raises(ValueError):
+        sharding.strong_block_for_rank(3, 3, 10)
+
+
 def test_aggregate_single_rank():
     from matchy_amd import sharding
     a = sharding.aggregate(None, 1, None, 0.5, 10, 2, 1, 3)
