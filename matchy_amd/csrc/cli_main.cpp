@@ -1052,8 +1052,10 @@ int cmd_inspect(int argc, char** argv) {
     return 0;
 }
 
-// matchy validate (bin/commands/validate_cmd.rs): the structural checks of matchy_validate (= what opening the file checks:
-// section bounds, headers, metadata); exit status 0 = valid. The reference's detailed statistics block is not reproduced.
+// matchy validate (bin/commands/validate_cmd.rs): the structural checks of matchy_validate = DbImage::check_structure, the same
+// checks every matchy_open runs before a file is uploaded (headers, metadata, section bounds, every pointer the kernels follow:
+// IP data records, literal-hash strings, wildcard / pattern / glob-segment arrays, the reachable Aho-Corasick nodes). Both
+// levels run the same checks here; exit status 0 = valid. The reference's detailed statistics block is not reproduced.
 int cmd_validate(int argc, char** argv) {
     std::vector<std::string> pos;
     std::string level = "strict";
@@ -1086,7 +1088,7 @@ int cmd_validate(int argc, char** argv) {
     } else {
         printf("Validating: %s\nLevel:      %s\n\n", pos[0].c_str(), level.c_str());
         if (!valid) printf("\xE2\x9D\x8C ERRORS (1):\n  \xE2\x80\xA2 %s\n\n", msg ? msg : "validation failed");
-        printf("%s\n", valid ? "\xE2\x9C\x85 VALIDATION PASSED" : "\xE2\x9D\x8C VALIDATION FAILED");
+        printf("%s\n", valid ? "\xE2\x9C\x85 VALIDATION PASSED (structural checks: every offset the readers follow lies inside its section)" : "\xE2\x9D\x8C VALIDATION FAILED");
     }
     if (msg) matchy_free_string(msg);
     return valid ? 0 : 1;

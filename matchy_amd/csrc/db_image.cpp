@@ -101,6 +101,111 @@ bool DbImage::open(std::vector<uint8_t>&& data, std::string& err) {
         }
         has_literal = true;
     }
+    return check_structure(err);
+}
+
+bool DbImage::check_structure(std::string& err) const {
+    const uint8_t* d = bytes.data();
+    const size_t n = bytes.size();
+    // ---- IP tree: a record above node_count points into the data section (tree.rs:93-125)
+    {
+        const size_t dlen = n - (tree_size + 16);
+        const uint64_t limit = (uint64_t)node_count + 16 + dlen;
+        const size_t stride = (size_t)record_size * 2 / 8;
+        for (uint32_t i = 0; i < node_count; ++i) {
+            const uint8_t* b = d + (size_t)i * stride;
+            uint32_t l, r;
+            if (record_size == 24) { l = ((uint32_t)b[0] << 16) | ((uint32_t)b[1] << 8) | b[2]; r = ((uint32_t)b[3] << 16) | ((uint32_t)b[4] << 8) | b[5]; }
+            else if (record_size == 28) { l = ((uint32_t)(b[3] >> 4) << 24) | ((uint32_t)b[0] << 16) | ((uint32_t)b[1] << 8) | b[2]; r = ((uint32_t)(b[3] & 0xF) << 24) | ((uint32_t)b[4] << 16) | ((uint32_t)b[5] << 8) | b[6]; }
+            else { l = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3]; r = ((uint32_t)b[4] << 24) | ((uint32_t)b[5] << 16) | ((uint32_t)b[6] << 8) | b[7]; }
+            if ((uint64_t)l >= limit || (uint64_t)r >= limit) { err = "IP tree record points outside the data section"; return false; }
+        }
+    }
+    // ---- literal hash: the length-prefixed string of every occupied slot lies inside the pool (lh:467-543)
+    if (has_literal) {
+        const uint8_t* lh = d + lh_off;
+        for (uint32_t i = 0; i < lh_table_size; ++i) {
+            const uint32_t so = rd32(lh + lh_table_start + (size_t)i * 16 + 8);
+            if (so == 0xFFFFFFFFu) continue;
+            if ((uint64_t)so + 2 > lh_strings_size) { err = "Literal hash entry points outside the string pool"; return false; }
+            const uint32_t sl = (uint32_t)lh[lh_strings_offset + so] | ((uint32_t)lh[lh_strings_offset + so + 1] << 8);
+            if ((uint64_t)so + 2 + sl > lh_strings_size) { err = "Literal hash string extends beyond the string pool"; return false; }
+        }
+    }
+    if (!has_glob) return true;
+    const uint8_t* pg = d + pg_off;
+    // ---- pure-wildcard list, pattern entries and their strings, glob segments (offset_format.rs:73-476)
+    {
+        const uint64_t unaligned = (uint64_t)rd32(pg + 40) + rd32(pg + 44);
+        const uint64_t wild_off = unaligned + (8 - unaligned % 8) % 8, wild_count = rd32(pg + 60);
+        if (wild_count && wild_off + wild_count * 8 > pg_len) { err = "Wildcard list out of bounds"; return false; }
+        for (uint64_t i = 0; i < wild_count; ++i)
+            if (rd32(pg + wild_off + i * 8) >= pattern_count) { err = "Wildcard entry names an unknown pattern"; return false; }
+        const uint32_t patterns_off = rd32(pg + 36), gso = rd32(pg + 104);
+        for (uint32_t pid = 0; pid < pattern_count; ++pid) {
+            const uint8_t* e = pg + (size_t)patterns_off + (size_t)pid * 16;
+            if ((uint64_t)rd32(e + 8) + rd32(e + 12) > pg_len) { err = "Pattern string out of bounds"; return false; }
+            const uint64_t first = rd32(pg + (size_t)gso + (size_t)pid * 8), count = rd32(pg + (size_t)gso + (size_t)pid * 8 + 4) & 0xFFFFu;
+            if (count == 0) continue;
+            if (first + count * 12 > pg_len) { err = "Glob segment list out of bounds"; return false; }
+            for (uint64_t k = 0; k < count; ++k) {
+                const uint8_t* sh = pg + first + k * 12;
+                const uint32_t st = sh[0];
+                if ((st == 0 || st == 3) && (uint64_t)rd32(sh + 8) + rd32(sh + 4) > pg_len) { err = "Glob segment data out of bounds"; return false; }
+            }
+        }
+    }
+    // ---- ACLH literal -> pattern table (literal_hash.rs:48-77): ids name patterns
+    {
+        const uint32_t map_off = rd32(pg + 96), map_cnt = rd32(pg + 100);
+        if (map_cnt && map_off) {
+            if ((uint64_t)map_off + 24 > pg_len || memcmp(pg + map_off, "ACLH", 4) != 0) { err = "AC literal map header invalid"; return false; }
+            const uint8_t* a = pg + map_off;
+            const uint64_t alen = pg_len - map_off, table_size = rd32(a + 12), pstart = rd32(a + 16);
+            if (24 + table_size * 16 > alen) { err = "AC literal map table out of bounds"; return false; }
+            for (uint64_t s2 = 0; s2 < table_size; ++s2) {
+                const uint8_t* e = a + 24 + s2 * 16;
+                if (rd32(e) == 0xFFFFFFFFu) continue;
+                const uint64_t po = rd32(e + 4), pc = rd32(e + 8);
+                if (pstart + po + pc * 4 > alen) { err = "AC literal map pattern list out of bounds"; return false; }
+                for (uint64_t k = 0; k < pc; ++k)
+                    if (rd32(a + pstart + po + k * 4) >= pattern_count) { err = "AC literal map names an unknown pattern"; return false; }
+            }
+        }
+    }
+    // ---- Aho-Corasick nodes reachable from the root (matchy-ac/src/lib.rs:118-124, 201-516)
+    {
+        const uint64_t ac_start = rd32(pg + 20), ac_size = rd32(pg + 24);
+        if (ac_size >= 20) {
+            const uint8_t* ac = pg + ac_start;
+            std::vector<uint8_t> seen(ac_size / 4 + 1, 0);
+            std::vector<uint32_t> queue{0};
+            seen[0] = 1;
+            auto visit = [&](uint64_t target) -> bool {
+                if ((target & 3) || target + 20 > ac_size) return false;
+                if (!seen[target / 4]) { seen[target / 4] = 1; queue.push_back((uint32_t)target); }
+                return true;
+            };
+            for (size_t qi = 0; qi < queue.size(); ++qi) {
+                const uint64_t off = queue[qi];
+                const uint32_t w0 = rd32(ac + off), kind = w0 & 0xFF, pc = ac[off + 3];
+                const uint64_t eo = rd32(ac + off + 12), fo = rd32(ac + off + 8), po = rd32(ac + off + 16);
+                bool ok = true;
+                if (kind == 1) ok = visit(eo);
+                else if (kind == 2) {
+                    const uint64_t cnt = (w0 >> 16) & 0xFF;
+                    ok = eo + cnt * 8 <= ac_size;
+                    for (uint64_t i = 0; ok && i < cnt; ++i) ok = visit(rd32(ac + eo + i * 8 + 4));
+                } else if (kind == 3) {
+                    ok = eo + 1024 <= ac_size;
+                    for (uint64_t c = 0; ok && c < 256; ++c) { const uint32_t t = rd32(ac + eo + c * 4); if (t) ok = visit(t); }
+                } else if (kind != 0) ok = false;
+                if (ok && fo != 0) ok = visit(fo);              // failure link (0 = root / none)
+                if (ok && pc) ok = po + (uint64_t)pc * 4 <= ac_size;   // output literal ids
+                if (!ok) { err = "Aho-Corasick automaton malformed (node at offset " + std::to_string(off) + ")"; return false; }
+            }
+        }
+    }
     return true;
 }
 

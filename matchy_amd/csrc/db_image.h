@@ -38,6 +38,12 @@ struct DbImage {
     uint32_t pattern_count = 0;
 
     bool open(std::vector<uint8_t>&& data, std::string& err);
+    // Structural validation of everything the device kernels and the host decoders dereference without a per-access check
+    // of their own (called by open(): a file that fails is never uploaded; matchy_validate reports the message): data
+    // pointers of the IP tree, the string of every literal-hash slot, the wildcard / pattern / glob-segment arrays and the
+    // reachable part of the Aho-Corasick automaton (edges, dense tables, failure links, output lists). All arithmetic in
+    // 64 bits.
+    bool check_structure(std::string& err) const;
 
     const uint8_t* data_section() const { return bytes.data() + tree_size + 16; }
     size_t data_section_len() const { return bytes.size() - (tree_size + 16); }

@@ -344,7 +344,7 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
                     c_seg = seg;
                     c_h0 = ld32(pg + so); c_dlen = ld32(pg + so + 4); c_doff = ld32(pg + so + 8);
                     c_lit8 = 0;
-                    if ((c_h0 & 0xFF) == 0 && c_doff + c_dlen <= db.pg_len) {
+                    if ((c_h0 & 0xFF) == 0 && (uint64_t)c_doff + c_dlen <= db.pg_len) {
                         if (c_dlen >= 8) __builtin_memcpy(&c_lit8, pg + c_doff, 8);
                         else for (uint32_t k = 0; k < c_dlen; ++k) c_lit8 |= (uint64_t)pg[c_doff + k] << (8 * k);
                         // case-insensitive (pg:1456-1478): characters compare with eq_ignore_ascii_case, which on UTF-8 bytes
@@ -354,7 +354,7 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
                 }
                 const uint32_t st = c_h0 & 0xFF, fl = (c_h0 >> 8) & 0xFF, dlen = c_dlen, doff = c_doff;
                 if (st == 0) {
-                    bool ok = doff + dlen <= db.pg_len && tn - pos >= dlen;
+                    bool ok = (uint64_t)doff + dlen <= db.pg_len && tn - pos >= dlen;
                     if (ok && dlen) {
                         const uint64_t m0 = dlen >= 8 ? ~0ull : (1ull << (dlen * 8)) - 1;
                         const uint64_t t0 = text.load8(pos);
@@ -382,7 +382,7 @@ __device__ bool glob_match(const DevDb& db, uint32_t pattern_id, const TextView&
                 } else if (st == 2) {
                     if (pos < tn) { pos += utf8_adv(text.at(pos)); ++seg; } else { result = false; ret = true; }
                 } else if (st == 3) {
-                    if (pos >= tn || doff + dlen > db.pg_len) { result = false; ret = true; }
+                    if (pos >= tn || (uint64_t)doff + dlen > db.pg_len) { result = false; ret = true; }
                     else {
                         uint32_t c = text.at(pos), adv = utf8_adv(c);
                         uint32_t cp = adv == 1 ? c : adv == 2 ? (c & 0x1F) : adv == 3 ? (c & 0x0F) : (c & 0x07);
@@ -449,7 +449,7 @@ __device__ void glob_find_all(const DevDb& db, const DfaView& dv, const TextView
             const uint32_t pc = ac[cur + 3];
             if (!pc) return;
             const uint32_t po = ld32(ac + cur + 16);
-            if (po + pc * 4 > db.ac_size) return;
+            if ((uint64_t)po + pc * 4 > db.ac_size) return;
             for (uint32_t k = 0; k < pc; ++k) {
                 const uint32_t lit = ld32(ac + po + k * 4);
                 if (lit >= db.n_ac_lits) continue;

@@ -313,3 +313,60 @@ def test_case_insensitive_reference_vectors(oracle):
     # case-sensitive databases are untouched
     db = oracle.Database(build([("Test*", {"p": 0})]))
     assert db.metadata()["match_mode"] == 0 and db.lookup("test1")["kind"] != "pattern" and db.lookup("Test1")["kind"] == "pattern"
+
+
+def test_validate_rejects_structurally_corrupt_files(tmp_path):
+    """matchy_validate (= what matchy_open checks before anything is uploaded): a file whose IP records, literal-hash slots, glob
+    segments or Aho-Corasick nodes point outside their sections is refused with a message; the intact file passes. Offsets as
+    in SURVEY.md Appendix A."""
+    import ctypes as C
+    import struct
+    import matchy_amd as M
+    from tools import synth
+    blob = synth.build_db(synth.config("c1"))
+    L = M.lib()
+
+    def validate(data):
+        p = tmp_path / "t.mxy"
+        p.write_bytes(data)
+        msg = C.c_void_p()
+        rc = L.matchy_validate(str(p).encode(), 0, C.byref(msg))
+        text = C.cast(msg, C.c_char_p).value.decode() if msg.value else ""
+        if msg.value:
+            L.matchy_free_string(msg)
+        return rc, text
+
+    assert validate(blob) == (0, "")
+    u32 = lambda b, o: struct.unpack_from("<I", b, o)[0]
+    # IP tree: first record of node 0 far beyond the data section
+    bad = bytearray(blob); bad[0:3] = b"\xff\xff\xff"
+    rc, text = validate(bytes(bad)); assert rc != 0 and "IP tree" in text
+    # literal hash: the string offset of the first occupied slot moved to the last byte of the pool
+    lit = blob.index(b"MMDB_LITERAL") + 16
+    table_size, strings_size, shards = u32(blob, lit + 12), u32(blob, lit + 20), u32(blob, lit + 24)
+    t0 = lit + 32 + (shards + 1) * 4
+    slot = next(i for i in range(table_size) if u32(blob, t0 + 16 * i + 8) != 0xFFFFFFFF)
+    bad = bytearray(blob); struct.pack_into("<I", bad, t0 + 16 * slot + 8, strings_size - 1)
+    rc, text = validate(bytes(bad)); assert rc != 0 and "Literal hash" in text
+    # paraglob: data offset of the first glob segment that carries data, wrapped to the top of the 32-bit range
+    pg = blob.index(b"MMDB_PATTERN") + 16 + 8
+    assert blob[pg:pg + 8] == b"PARAGLOB"
+    gso, count = u32(blob, pg + 104), u32(blob, pg + 32)
+    seg = None
+    for pid in range(count):
+        first, cnt = u32(blob, pg + gso + 8 * pid), u32(blob, pg + gso + 8 * pid + 4) & 0xFFFF
+        for k in range(cnt):
+            if blob[pg + first + 12 * k] in (0, 3):
+                seg = pg + first + 12 * k
+                break
+        if seg:
+            break
+    bad = bytearray(blob); struct.pack_into("<I", bad, seg + 8, 0xFFFFFFF0)
+    rc, text = validate(bytes(bad)); assert rc != 0 and "Glob segment" in text
+    # Aho-Corasick: the root's edge table moved outside the automaton
+    ac = pg + u32(blob, pg + 20)
+    bad = bytearray(blob); struct.pack_into("<I", bad, ac + 12, 0xFFFFFFF0)
+    rc, text = validate(bytes(bad)); assert rc != 0 and "Aho-Corasick" in text
+    # wildcard count inflated
+    bad = bytearray(blob); struct.pack_into("<I", bad, pg + 60, 0x40000000)
+    rc, text = validate(bytes(bad)); assert rc != 0 and "Wildcard" in text
