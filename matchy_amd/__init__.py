@@ -133,6 +133,7 @@ def lib():
         "matchy_get_pattern_string": (vp, [vp, C.c_uint32]),
         "matchy_pattern_count": (C.c_size_t, [vp]),
         "matchy_extractor_create": (vp, [C.c_uint32]),
+        "matchy_amd_extractor_create": (vp, [C.c_uint32, C.c_uint32]),
         "matchy_extractor_extract_chunk": (C.c_int32, [vp, cp, C.c_size_t, C.POINTER(_Matches)]),
         "matchy_matches_free": (None, [C.POINTER(_Matches)]),
         "matchy_extractor_free": (None, [vp]),
@@ -345,8 +346,10 @@ class Database:
 class Extractor:
     """Extractor::extract_from_chunk on the GPU (matchy_extractor_*). Returns (type_name, start, end, value)."""
 
-    def __init__(self, flags=EXTRACT_ALL):
-        self._h = lib().matchy_extractor_create(flags)
+    def __init__(self, flags=EXTRACT_ALL, min_domain_labels=2):
+        # min_domain_labels: ExtractorBuilder::min_domain_labels (matchy-extractor/src/lib.rs:101-104), through the additive entry
+        self._h = (lib().matchy_extractor_create(flags) if min_domain_labels == 2
+                   else lib().matchy_amd_extractor_create(flags, min_domain_labels))
         if not self._h:
             raise RuntimeError("matchy_extractor_create failed: " + last_error())
 

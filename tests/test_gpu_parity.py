@@ -34,13 +34,11 @@ def test_extractor_golden_vectors(M, gpu_extractor, oracle):
     exs = {}
     for c in cases:
         data = bytes.fromhex(c["input_hex"]) if "input_hex" in c else c["input"].encode()
-        if c["min_labels"] != 2:
-            continue  # the C ABI has no min_domain_labels knob (neither has the reference's), covered by the oracle test
-        key = c["flags"]
+        key = (c["flags"], c["min_labels"])   # min_labels != 2: matchy_amd_extractor_create(flags, min_domain_labels)
         if key not in exs:
-            exs[key] = M.Extractor(flags=key)
+            exs[key] = M.Extractor(flags=c["flags"], min_domain_labels=c["min_labels"])
         got = exs[key].extract_from_chunk(data)
-        want = oracle.extract(data, flags=c["flags"])
+        want = oracle.extract(data, flags=c["flags"], min_labels=c["min_labels"])
         assert norm(got) == norm(want), (c["ref"], data)
         by_type = {}
         for t, s, e, v in got:
@@ -811,3 +809,30 @@ def test_case_insensitive_long_non_ascii_key(M, oracle):
         else:
             assert got is None, (q, got)
     db.close()
+
+
+def test_handmade_database_files(M, oracle):
+    """The product reader, uploader and kernels on tests/golden/handmade_*.mxy — files assembled byte by byte from the format
+    description (make_handmade_mxy.py), not by any builder of this repository: single queries give the answers that follow from
+    the construction, and a scan of a log made of the query strings equals the oracle's."""
+    exp = json.loads((GOLD / "handmade_expect.json").read_text())
+    for name in ("24", "28", "32", "v6"):
+        blob = (GOLD / f"handmade_{name}.mxy").read_bytes()
+        db = M.Database(blob)
+        md = db.metadata()
+        assert md["record_size"] == exp[name]["record_size"] and md["ip_version"] == exp[name]["ip_version"]
+        for q in exp[name]["queries"]:
+            got, want = db.lookup(q["query"]), q["expect"]
+            if want["kind"] == "ip":
+                assert got == {"found": True, "prefix_len": want["prefix_len"], "data": want["data"]}, (name, q, got)
+            elif want["kind"] == "pattern":
+                assert got == {"found": True, "prefix_len": 0, "data": want["data"][0]}, (name, q, got)
+            else:
+                assert got is None, (name, q, got)
+        db.close()
+        log = b"".join(b"GET http://" + q["query"].encode() + b"/x HTTP/1.1\" \"ref=" + q["query"].encode() + b"\n" for q in exp[name]["queries"])
+        gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, log)
+        assert gs == ws
+        assert gh == wh
+        assert gl == wl
+        assert len(wh) >= 30
