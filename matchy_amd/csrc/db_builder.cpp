@@ -319,7 +319,13 @@ struct ParaglobBuilder {
         std::vector<uint8_t> aclh;
         if (!ac_lits.empty()) {
             size_t n = ac_lits.size();
-            size_t table_size = std::max<size_t>((n * 5 + 3) / 4, 16);
+            // The table is written completely FULL (table_size = number of literals). The reference reader probes from
+            // FxHasher(literal_id) % table_size for at most table_size steps and gives up at the first empty slot
+            // (literal_hash.rs:263-299); rustc-hash 2.1.1's FxHasher cannot be verified in this image, and
+            // with no empty slot every probe sequence reaches every entry whatever the function really is. The slots are
+            // still assigned from the believed function, so if it is right the reference finds an entry after a few steps.
+            // This repository's readers do not use the slot function at all (they enumerate the table once at open).
+            size_t table_size = n;
             std::vector<uint8_t> lists;
             std::vector<uint32_t> offs(n);
             for (size_t l = 0; l < n; ++l) { offs[l] = (uint32_t)lists.size(); for (uint32_t pid : lit_pats[l]) put32(lists, pid); }
