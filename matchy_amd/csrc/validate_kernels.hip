@@ -55,16 +55,22 @@ struct BackReader {
 // without it the caller already knows that the last label alone is a public suffix, so the first dot decides.
 struct WalkInit {          // state of the walk after the bytes the caller has already consumed (none: the defaults)
     uint64_t rh;
-    uint32_t cur = 0, last_c = 0;
-    bool high = false, bad = false;
+    uint32_t cur = 0, last_c = 0, labels = 1;
+    bool high = false, bad = false, found = false;
 };
+// State of a walk that was interrupted inside a long run (WALK_LONG): the wave finishes the bulk of the run together
+// (coop_domain_skip) and the lane resumes from the updated state.
+struct WalkState { uint32_t pos, cur, last_c, labels; bool high, bad, found; };
+constexpr int WALK_NO = 0, WALK_YES = 1, WALK_LONG = 2;
+constexpr uint32_t WALK_BUDGET_WORDS = 128;   // 8-byte words one lane walks alone before it asks the wave for help
 template <bool HASH>
-__device__ __forceinline__ bool domain_walk_back(const LogView& lg, const DevDb& db, uint32_t min_labels, uint32_t e, BackReader& br,
-                                                  const WalkInit& wi, uint32_t& start) {
+__device__ __forceinline__ int domain_walk_back(const LogView& lg, const DevDb& db, uint32_t min_labels, uint32_t e, BackReader& br,
+                                                 const WalkInit& wi, uint32_t& start, WalkState* long_out, bool* defer_utf8 = nullptr) {
     uint64_t rh = wi.rh;
-    bool found = false, bad = wi.bad, high = wi.high;
-    uint32_t labels = 1, cur = wi.cur, last_c = wi.last_c;
+    bool found = wi.found, bad = wi.bad, high = wi.high;
+    uint32_t labels = wi.labels, cur = wi.cur, last_c = wi.last_c;
     uint32_t first_c = 0x100;  // byte in front of the run (0x100 = buffer start)
+    uint32_t words = 0;
     while (br.pos > 0) {
         // Long runs (hostile input: one lane walks the whole run): once the public-suffix question is settled no hash is
         // needed any more, and whole 8-byte words of domain characters are handled with the SWAR masks — the rules only
@@ -91,13 +97,17 @@ __device__ __forceinline__ bool domain_walk_back(const LogView& lg, const DevDb&
                 pos -= 8;
                 any = true;
                 if (pos < 24) break;
+                if (long_out && ++words >= WALK_BUDGET_WORDS) {   // a long run: hand the state to the wave
+                    *long_out = WalkState{pos, cur, last_c, labels, high, bad, found};
+                    return WALK_LONG;
+                }
                 w = wn;
             }
             if (any) { br.init(lg.p, pos); continue; }
         }
         uint32_t c = br.next();
         if (!d_is_domain_char_fast(c)) { first_c = c; ++br.pos; break; }
-        if (HASH && !found && e - br.pos - 1 > db.max_suffix_len) return false;   // longer than every public suffix: no TLD
+        if (HASH && !found && e - br.pos - 1 > db.max_suffix_len) return WALK_NO;   // longer than every public suffix: no TLD
         if (c == '.') {
             if (cur == 0 || last_c == '-') bad = true;
             if (HASH) { if (!found && !bad) found = psl_contains(db, psl_hash_finish(rh), lg.p + br.pos + 1, e - br.pos - 1); }
@@ -114,18 +124,91 @@ __device__ __forceinline__ bool domain_walk_back(const LogView& lg, const DevDb&
     }
     const uint32_t s = br.pos;
     if (cur == 0 || last_c == '-') bad = true;  // leftmost label empty / starts with '-'
-    if (bad || !found || labels < min_labels) return false;
-    if (first_c != 0x100 && !d_is_boundary(first_c)) return false;
-    if (high && !d_valid_utf8(lg.p + s, e - s)) return false;
+    if (bad || !found || labels < min_labels) return WALK_NO;
+    if (first_c != 0x100 && !d_is_boundary(first_c)) return WALK_NO;
+    // a long run with bytes >= 0x80: the caller validates it with the whole wave (coop_valid_utf8)
+    if (high && defer_utf8) *defer_utf8 = true;
+    else if (high && !d_valid_utf8(lg.p + s, e - s)) return WALK_NO;
     start = s;
-    return true;
+    return WALK_YES;
+}
+
+// core::str::from_utf8 acceptance of p[0, n) (wave-uniform arguments) by the whole wave, 64 bytes per step: byte classes
+// become lane masks (ballots), a sequence is well formed iff the positions where continuation bytes are expected
+// (1 / 2 / 3 after a 2- / 3- / 4-byte lead) are exactly the positions that hold one, plus the four restricted second bytes
+// (E0: A0..BF, ED: 80..9F, F0: 90..BF, F4: 80..8F). Expectations that run past a step are carried into the next one.
+__device__ __forceinline__ bool coop_valid_utf8(const uint8_t* p, uint32_t n) {
+    const uint32_t lane = lane_id();
+    uint64_t carry = 0;          // expected-continuation bits for the first positions of the next step
+    uint32_t c2 = 0;             // restricted-second-byte kinds pending for position 0 of the next step: 1 E0, 2 ED, 4 F0, 8 F4
+    bool ok = true;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t b = base + lane < n ? p[base + lane] : 0u;
+        const uint64_t cont = __ballot((b & 0xC0u) == 0x80u);
+        const uint64_t l2 = __ballot(b >= 0xC2u && b <= 0xDFu), l3 = __ballot((b & 0xF0u) == 0xE0u), l4 = __ballot(b >= 0xF0u && b <= 0xF4u);
+        const uint64_t badb = __ballot(b == 0xC0u || b == 0xC1u || b >= 0xF5u);
+        const uint64_t e0 = __ballot(b == 0xE0u), ed = __ballot(b == 0xEDu), f0 = __ballot(b == 0xF0u), f4 = __ballot(b == 0xF4u);
+        const uint64_t ltA0 = __ballot(b < 0xA0u), gt9F = __ballot(b > 0x9Fu), lt90 = __ballot(b < 0x90u), gt8F = __ballot(b > 0x8Fu);
+        const uint64_t lead = l2 | l3 | l4, lead34 = l3 | l4;
+        const uint64_t exp = (lead << 1) | (lead34 << 2) | (l4 << 3) | carry;
+        carry = (lead >> 63) | (lead34 >> 62) | (l4 >> 61);
+        uint64_t bad2 = ((e0 << 1) & ltA0) | ((ed << 1) & gt9F) | ((f0 << 1) & lt90) | ((f4 << 1) & gt8F);
+        if (c2 & 1) bad2 |= ltA0 & 1; if (c2 & 2) bad2 |= gt9F & 1; if (c2 & 4) bad2 |= lt90 & 1; if (c2 & 8) bad2 |= gt8F & 1;
+        c2 = (uint32_t)(e0 >> 63) | ((uint32_t)(ed >> 63) << 1) | ((uint32_t)(f0 >> 63) << 2) | ((uint32_t)(f4 >> 63) << 3);
+        if ((exp ^ cont) | badb | bad2) { ok = false; break; }
+    }
+    return ok && carry == 0;
+}
+
+// The bulk of a long domain-character run, walked by the whole wave: 512 bytes per step (lane i takes the 8 bytes at
+// pos - 512 + 8 i), the same per-word rules as the lane's own word loop above, combined with ballots. All arguments are
+// wave-uniform (the state of ONE lane's walk, broadcast by the caller). Stops in front of the 512-byte step that holds the
+// start of the run (or near the start of the buffer); the lane finishes from there. One lane alone needs a dependent load
+// per 8 bytes — a multi-megabyte token cost tens of milliseconds.
+__device__ __forceinline__ void coop_domain_skip(const LogView& lg, WalkState& st) {
+    constexpr uint64_t H = 0x8080808080808080ull;
+    const uint32_t lane = lane_id();
+    while (st.pos >= 512 + 32) {
+        const uint32_t base = st.pos - 512;
+        const uint64_t w = BackReader::load8(lg.p + base + 8 * lane);
+        const ByteMasks m = domain_masks(w);
+        const uint64_t stop = __ballot((~m.dc & H) != 0);
+        const int hi = stop ? 63 - (int)__clzll((long long)stop) : -1;   // the run starts in this lane's word (the walk consumes lanes 63 down to hi + 1)
+        const bool valid = (int)lane > hi;
+        // right-hand neighbour of the word's top byte: the lowest byte of the next lane's word; lane 63: the last byte consumed
+        uint32_t nb = (uint32_t)__shfl_down((int)((uint32_t)w & 0xFFu), 1);
+        if (lane == 63) nb = st.last_c;
+        const uint64_t dr = (m.dot >> 8) | (nb == '.' ? (0x80ull << 56) : 0ull);
+        const uint64_t sr = (m.dash >> 8) | (nb == '-' ? (0x80ull << 56) : 0ull);
+        const bool badl = ((m.dot & (dr | sr)) | (m.dash & dr)) != 0;   // empty label, label starting / ending with '-'
+        if (__ballot(valid && badl)) st.bad = true;
+        if (__ballot(valid && m.dot != 0) && !st.bad) st.found = true;
+        if (__ballot(valid && m.high != 0)) st.high = true;
+        uint32_t nd = valid ? (uint32_t)__popcll(m.dot) : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nd += (uint32_t)__shfl_xor((int)nd, off);
+        st.labels += nd;
+        const uint32_t low = (uint32_t)w & 0xFFu;
+        if (hi >= 0) {
+            if (hi < 63) {
+                st.pos = base + 8 * (uint32_t)(hi + 1);
+                st.last_c = (uint32_t)__shfl((int)low, hi + 1);
+                st.cur = st.last_c == '.' ? 0u : 1u;
+            }
+            return;
+        }
+        st.pos = base;
+        st.last_c = (uint32_t)__shfl((int)low, 0);
+        st.cur = st.last_c == '.' ? 0u : 1u;
+    }
 }
 
 // Domain (ext:537-689). `j` is the first byte after a dot (anchor: label-char, '.', label-char). Only the LAST dot
 // of a maximal domain-char run owns the run; it validates the run as a whole. `tldtab` is the LDS copy of
 // DevDb::tld_tab (exact table of the last labels of <= 7 bytes), `bloom` covers the longer ones.
-__device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* bloom, const uint2* tldtab, uint32_t min_labels,
-                           uint32_t j, uint32_t& start, uint32_t& end) {
+struct DomLong { WalkState st; uint32_t e; bool alone; };
+__device__ int val_domain(const LogView& lg, const DevDb& db, const uint32_t* bloom, const uint2* tldtab, uint32_t min_labels,
+                          uint32_t j, uint32_t& start, uint32_t& end, DomLong* long_out) {
     uint32_t p = j, th = 2166136261u;
     bool open = true;  // last label not yet terminated
     uint32_t stop_c = 0x100;  // byte that ended the run on the right (0x100 = buffer end)
@@ -178,9 +261,25 @@ __device__ bool val_domain(const LogView& lg, const DevDb& db, const uint32_t* b
     br.init(lg.p, e);
     WalkInit wi;
     wi.rh = psl_hash_init();
-    const bool ok = alone ? domain_walk_back<false>(lg, db, min_labels, e, br, wi, s) : domain_walk_back<true>(lg, db, min_labels, e, br, wi, s);
-    if (!ok) return false;
+    WalkState ws{};
+    const int r = alone ? domain_walk_back<false>(lg, db, min_labels, e, br, wi, s, long_out ? &ws : nullptr)
+                        : domain_walk_back<true>(lg, db, min_labels, e, br, wi, s, long_out ? &ws : nullptr);
+    if (r == WALK_LONG) { long_out->st = ws; long_out->e = e; long_out->alone = alone; return WALK_LONG; }
+    if (r != WALK_YES) return WALK_NO;
     start = s; end = e;
+    return WALK_YES;
+}
+// the rest of a walk that coop_domain_skip has brought near the start of the run
+__device__ bool val_domain_resume(const LogView& lg, const DevDb& db, uint32_t min_labels, const DomLong& dl, uint32_t& start, uint32_t& end, bool& need_utf8) {
+    BackReader br;
+    br.init(lg.p, dl.st.pos);
+    WalkInit wi;
+    wi.rh = psl_hash_init();   // the public-suffix question is settled by the time a walk reports a long run
+    wi.cur = dl.st.cur; wi.last_c = dl.st.last_c; wi.labels = dl.st.labels; wi.high = dl.st.high; wi.bad = dl.st.bad; wi.found = dl.st.found;
+    uint32_t s;
+    // HASH only matters while `found` is open; it is closed here (word mode is entered only then)
+    if (domain_walk_back<false>(lg, db, min_labels, dl.e, br, wi, s, nullptr, &need_utf8) != WALK_YES) return false;
+    start = s; end = dl.e;
     return true;
 }
 
@@ -339,10 +438,14 @@ __device__ __forceinline__ LocalMasks email_local_masks(uint64_t x) {
     m.loc = (dig | alp | ~ndot | ~ndash | ~nus | ~npl) & ~x & H;   // is_email_local_char (ext:1644)
     return m;
 }
-__device__ bool val_email(const LogView& lg, const DevDb& db, uint32_t at, uint32_t& start, uint32_t& end) {
+// State of the leftward scan over the local part: s = its current start, prev = the last byte consumed.
+struct EmailState { uint32_t s, prev; bool has_letter, dotdot; };
+// Scans the local part leftwards from `at`. With `budget` the word loop gives up after WALK_BUDGET_WORDS words and returns true
+// ("long run": the wave continues with coop_email_skip, then the lane calls this again without budget to finish).
+__device__ __forceinline__ bool email_local_scan(const LogView& lg, EmailState& es, bool budget) {
     constexpr uint64_t H = 0x8080808080808080ull;
-    uint32_t s = at, prev = '@';
-    bool has_letter = false, dotdot = false;
+    uint32_t s = es.s, prev = es.prev, words = 0;
+    bool has_letter = es.has_letter, dotdot = es.dotdot, is_long = false;
     if (s >= 32) {
         uint64_t w = BackReader::load8(lg.p + s - 8);
         for (;;) {
@@ -355,17 +458,52 @@ __device__ bool val_email(const LogView& lg, const DevDb& db, uint32_t at, uint3
             prev = (uint32_t)w & 0xFF;
             s -= 8;
             if (s < 32) break;
+            if (budget && ++words >= WALK_BUDGET_WORDS) { is_long = true; break; }
             w = wn;
         }
     }
-    while (s > 0) {
-        const uint32_t c = lg.at(s - 1);
-        if (!d_is_email_local(c)) break;
-        dotdot |= c == '.' && prev == '.';
-        has_letter |= d_is_alpha(c);
-        prev = c;
-        --s;
+    if (!is_long) {
+        while (s > 0) {
+            const uint32_t c = lg.at(s - 1);
+            if (!d_is_email_local(c)) break;
+            dotdot |= c == '.' && prev == '.';
+            has_letter |= d_is_alpha(c);
+            prev = c;
+            --s;
+        }
     }
+    es = EmailState{s, prev, has_letter, dotdot};
+    return is_long;
+}
+// the whole wave on one lane's long local part: 512 bytes per step, same rules as the word loop above (wave-uniform state)
+__device__ __forceinline__ void coop_email_skip(const LogView& lg, EmailState& es) {
+    constexpr uint64_t H = 0x8080808080808080ull;
+    const uint32_t lane = lane_id();
+    while (es.s >= 512 + 32) {
+        const uint32_t base = es.s - 512;
+        const uint64_t w = BackReader::load8(lg.p + base + 8 * lane);
+        const LocalMasks m = email_local_masks(w);
+        const uint64_t stop = __ballot((~m.loc & H) != 0);
+        const int hi = stop ? 63 - (int)__clzll((long long)stop) : -1;
+        const bool valid = (int)lane > hi;
+        uint32_t nb = (uint32_t)__shfl_down((int)((uint32_t)w & 0xFFu), 1);
+        if (lane == 63) nb = es.prev;
+        const uint64_t dr = (m.dot >> 8) | (nb == '.' ? (0x80ull << 56) : 0ull);
+        if (__ballot(valid && (m.dot & dr) != 0)) es.dotdot = true;
+        if (__ballot(valid && m.alp != 0)) es.has_letter = true;
+        const uint32_t low = (uint32_t)w & 0xFFu;
+        if (hi >= 0) {
+            if (hi < 63) { es.s = base + 8 * (uint32_t)(hi + 1); es.prev = (uint32_t)__shfl((int)low, hi + 1); }
+            return;
+        }
+        es.s = base;
+        es.prev = (uint32_t)__shfl((int)low, 0);
+    }
+}
+// everything after the local part: boundary in front of it, the domain part, the public-suffix test
+__device__ bool val_email_finish(const LogView& lg, const DevDb& db, uint32_t at, const EmailState& es, uint32_t& start, uint32_t& end) {
+    constexpr uint64_t H = 0x8080808080808080ull;
+    const uint32_t s = es.s;
     if (s == at) return false;
     if (s > 0 && !d_is_boundary(lg.at(s - 1))) return false;
     uint32_t e = at + 1;
@@ -390,7 +528,7 @@ __device__ bool val_email(const LogView& lg, const DevDb& db, uint32_t at, uint3
     }
     if (e == at + 1) return false;
     if (e < lg.len && !d_is_boundary(lg.at(e))) return false;
-    if (dotdot || !has_letter || !has_dot) return false;
+    if (es.dotdot || !es.has_letter || !has_dot) return false;
     if (!psl_suffix_exists(db, lg.p, at + 1, e)) return false;
     start = s; end = e;  // all bytes are ASCII: from_utf8 always succeeds
     return true;
@@ -830,18 +968,53 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
                 ok = val_ipv6(lg, ra.pos, s, e);
             }
             if (ok) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV6 << 24); emit = true; }
-        } else if (kind == RARE_AT) {
+        }
+        // e-mail anchors: the local part leftwards (a lane that meets a long run gets the wave's help), then the rest
+        {
+            EmailState es{ra.pos, (uint32_t)'@', false, false};
+            const bool is_at = kind == RARE_AT;
+            bool el = is_at && email_local_scan(lg, es, true);
+            for (uint64_t lm = __ballot(el); lm; lm &= lm - 1) {
+                const int src = __ffsll((long long)lm) - 1;
+                EmailState st;
+                st.s = (uint32_t)__shfl((int)es.s, src); st.prev = (uint32_t)__shfl((int)es.prev, src);
+                st.has_letter = __shfl((int)es.has_letter, src) != 0; st.dotdot = __shfl((int)es.dotdot, src) != 0;
+                coop_email_skip(lg, st);
+                if ((int)lane_id() == src) es = st;
+            }
+            if (el) (void)email_local_scan(lg, es, false);
             uint32_t s, e;
-            if (val_email(lg, db, ra.pos, s, e)) {
+            if (is_at && val_email_finish(lg, db, ra.pos, es, s, e)) {
                 if (e - s > 0xFFFFFFu) atomicOr(&p.counters->error, 4u);   // the record format holds 24-bit lengths
                 c.start = s; c.len_type = (e - s) | ((uint32_t)IT_EMAIL << 24); emit = true;
             }
-        } else if (kind == RARE_DOM) {
-            uint32_t s, e;
-            if (val_domain(lg, db, bloom, tldtab, p.min_labels, ra.pos, s, e)) {
-                if (e - s > 0xFFFFFFu) atomicOr(&p.counters->error, 4u);
-                c.start = s; c.len_type = (e - s) | ((uint32_t)IT_DOMAIN << 24); emit = true;
-            }
+        }
+        // domain anchors k_validate_dom left undecided: the general walk; a lane that meets a long run (hostile input: one
+        // token of megabytes) reports it, the wave walks the bulk of that run together, the lane finishes
+        DomLong dl{};
+        int dr = WALK_NO;
+        uint32_t ds = 0, de = 0;
+        if (kind == RARE_DOM) dr = val_domain(lg, db, bloom, tldtab, p.min_labels, ra.pos, ds, de, &dl);
+        for (uint64_t lm = __ballot(dr == WALK_LONG); lm; lm &= lm - 1) {
+            const int src = __ffsll((long long)lm) - 1;
+            WalkState st;
+            st.pos = (uint32_t)__shfl((int)dl.st.pos, src); st.cur = (uint32_t)__shfl((int)dl.st.cur, src);
+            st.last_c = (uint32_t)__shfl((int)dl.st.last_c, src); st.labels = (uint32_t)__shfl((int)dl.st.labels, src);
+            st.high = __shfl((int)dl.st.high, src) != 0; st.bad = __shfl((int)dl.st.bad, src) != 0; st.found = __shfl((int)dl.st.found, src) != 0;
+            coop_domain_skip(lg, st);
+            if ((int)lane_id() == src) dl.st = st;
+        }
+        bool need_u8 = false;
+        if (dr == WALK_LONG) dr = val_domain_resume(lg, db, p.min_labels, dl, ds, de, need_u8) ? WALK_YES : WALK_NO;
+        for (uint64_t lm = __ballot(dr == WALK_YES && need_u8); lm; lm &= lm - 1) {   // long runs with non-ASCII bytes
+            const int src = __ffsll((long long)lm) - 1;
+            const uint32_t us = (uint32_t)__shfl((int)ds, src), ue = (uint32_t)__shfl((int)de, src);
+            const bool good = coop_valid_utf8(lg.p + us, ue - us);
+            if ((int)lane_id() == src && !good) dr = WALK_NO;
+        }
+        if (dr == WALK_YES) {
+            if (de - ds > 0xFFFFFFu) atomicOr(&p.counters->error, 4u);
+            c.start = ds; c.len_type = (de - ds) | ((uint32_t)IT_DOMAIN << 24); emit = true;
         }
         cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand);
     }

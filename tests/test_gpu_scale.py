@@ -245,3 +245,36 @@ def test_full_database_multi_batch(M, oracle, cfgname):
         total += len(want)
     assert total > 1000
     sc.close(); db.close()
+
+
+def test_hostile_long_runs(M, oracle):
+    """Single tokens of megabytes (one lane used to walk them alone, a dependent load per 8 bytes: 76-88 ms each): the wave
+    walks the bulk of such a run together (coop_domain_skip / coop_email_skip). Same items as the oracle, and fast."""
+    import time
+    cases = [
+        ("1 MB label", (b"a" * 1_000_000 + b".com ") * 4),
+        ("2 MB of short labels", b"x " + b"a." * 1_000_000 + b"com "),
+        ("2 MB local part", b"x" * 2_000_000 + b"@a.com "),
+        ("long run with a bad label deep inside", b"b" * 700_000 + b"..c" + b"d" * 700_000 + b".org "),
+        ("long run ending in a dash label", b"-" + b"e" * 900_000 + b".net y"),
+        ("long local part with two dots", b"y" * 600_000 + b".." + b"z" * 600_000 + b"@b.org "),
+        ("digits only local part", b"1" * 900_000 + b"@c.net "),
+        ("non-ASCII inside a long run", b" " + b"f" * 500_000 + "é".encode() + b"g" * 500_000 + b".com "),
+        ("run that starts at the buffer start", b"h" * 300_000 + b".io"),
+        ("overlong sequence deep inside", b" " + b"i" * 400_000 + b"\xe0\x80\x80" + b"j" * 400_000 + b".com "),
+        ("surrogate deep inside", b" " + b"k" * 400_001 + b"\xed\xa0\x80" + b"l" * 400_000 + b".com "),
+        ("truncated sequence at a step edge", b" " + b"m" * 63 + b"\xf0\x9f\x98" + b"n" * 300_000 + b".com "),
+        ("four-byte characters across step edges", b" " + ("o" * 61 + "😀").encode() * 4000 + b".com "),
+        ("stray continuation byte", b" " + b"p" * 200_000 + b"\x80" + b"q" * 200_000 + b".com "),
+    ]
+    ex = M.Extractor()
+    ex.extract_from_chunk(b"warm.up.example.com 1.2.3.4 a@b.com")
+    for name, buf in cases:
+        t0 = time.perf_counter()
+        got = ex.extract_from_chunk(buf)
+        dt = time.perf_counter() - t0
+        want = oracle.extract(buf)
+        assert [(t, s, e) for t, s, e, v in got] == [(t, s, e) for t, s, e, v in want], name
+        assert [v for *_, v in got] == [v for *_, v in want], name
+        assert dt < 0.05, (name, dt)   # includes the upload of the buffer; the old single-lane walk took 0.08 s and more
+    ex.close()
