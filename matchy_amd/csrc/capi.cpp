@@ -562,7 +562,10 @@ matchy_extractor_t* matchy_amd_extractor_create(uint32_t flags, uint32_t min_dom
         e->img = std::make_shared<DbImage>();  // no sections: has_ip/has_literal/has_glob all false
         e->img->node_count = 0;
         e->ddb = std::make_shared<DeviceDb>();
-        e->ddb->upload(*e->img, 0);
+        int dev0 = 0;   // like matchy_open: one process per GPU selects its device with MATCHY_AMD_DEVICE
+        if (const char* ev = getenv("MATCHY_AMD_DEVICE")) dev0 = atoi(ev);
+        if (dev0 < 0 || dev0 >= ndev) { set_error("MATCHY_AMD_DEVICE out of range"); return nullptr; }
+        e->ddb->upload(*e->img, dev0);
         e->scanner = std::make_unique<Scanner>(e->img, e->ddb, flags, min_domain_labels ? min_domain_labels : 2);
         return reinterpret_cast<matchy_extractor_t*>(e.release());
     } catch (const HipError& e) { set_error(e.what); return nullptr; }

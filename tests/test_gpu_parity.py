@@ -836,3 +836,40 @@ def test_handmade_database_files(M, oracle):
         assert gh == wh
         assert gl == wl
         assert len(wh) >= 30
+
+
+def test_case_insensitive_special_casing_from_the_unicode_standard(M, oracle):
+    """Lower-case forms hand-listed from the Unicode standard (UnicodeData / SpecialCasing: what Rust's str::to_lowercase
+    implements), NOT taken from the table generator of this repository: a case-insensitive database keyed by the lower-case
+    form must answer the upper-case spelling. Pins the device's mapping table and Final_Sigma rule independently of the
+    tools/gen_lowercase.py / oracle pair, which share an origin."""
+    pairs = [
+        ("İstanbul.example.com", "i̇stanbul.example.com"),      # U+0130 -> U+0069 U+0307 (SpecialCasing)
+        ("STRAẞE.example.com", "straße.example.com"),                 # U+1E9E -> U+00DF
+        ("ΟΔΥΣΣΕΥΣ-1.example.com", "οδυσσευς-1.example.com"),         # Final_Sigma: preceded by a cased letter, not followed by one
+        ("ΑΣ9.example.com", "ας9.example.com"),
+        ("ΟΔΥΣΣΕΥΣ.example.com", "οδυσσευσ.example.com"),             # '.' is Case_Ignorable and 'e' is cased: NOT final here
+        ("Σ.example.com", "σ.example.com"),                           # a lone capital sigma is not final
+        ("Ǆungla.example.com", "ǆungla.example.com"),                 # U+01C4 -> U+01C6
+        ("Kelvin.example.com", "kelvin.example.com"),            # KELVIN SIGN -> k
+        ("Ångstrom.example.com", "ångstrom.example.com"),        # ANGSTROM SIGN -> U+00E5
+        ("\U00010400\U00010401.example.com", "\U00010428\U00010429.example.com"),   # Deseret, 4-byte characters
+        ("ÀÉÎÕÜ.example.com", "àéîõü.example.com"),
+        ("ΆΈΉΊΌΎΏ.example.com", "άέήίόύώ.example.com"),
+        ("ЖЁЛТЫЙ.example.com", "жёлтый.example.com"),
+    ]
+    b = M.DatabaseBuilder(build_epoch=7, case_insensitive=True)
+    for i, (_, low) in enumerate(pairs):
+        b.add_entry(low, {"k": i})
+    blob = b.build()
+    b.close()
+    db = M.Database(blob)
+    odb = oracle.Database(blob)
+    for i, (up, low) in enumerate(pairs):
+        for q in (up, low):
+            assert db.lookup(q) == {"found": True, "prefix_len": 0, "data": {"k": i}}, q
+            assert odb.lookup(q)["data"] == [{"k": i}], q
+    db.close()
+    log = "".join(f"GET http://{up}/x http://{low}/y\n" for up, low in pairs).encode()
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, log)
+    assert gs == ws and gh == wh and gl == wl and len(wh) == 2 * len(pairs)
