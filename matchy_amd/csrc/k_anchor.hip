@@ -19,9 +19,10 @@
 //     label is some public suffix's last label — Bloom filter) and the survivors leave with 32 bytes of context for
 //     k_validate_dom. Anchors whose look-ahead lies in the block that is not staged yet go back into the ring.
 //     Lists are written through wave-private chunks (one atomic per chunk, coalesced stores).
-// Tokens long enough to be hashes / crypto addresses (>= 26 bytes) are found without per-byte work: one bit per dword
-// ("no boundary byte in it") travels five lanes down the wave (DPP rotate); a dword with a boundary byte whose five
-// predecessors are boundary-free closes a token of >= 20 bytes, and only then is the exact length computed from ballots.
+// Tokens long enough to be hashes / crypto addresses (>= 26 bytes) are found without per-byte work: every accepted form is
+// made of ASCII letters and digits, so one bit per dword ("all four bytes alphanumeric") travels down the wave (DPP rotate);
+// only when three such dwords stand in a row somewhere (rare in logs) is the chain taken to five, and a dword with a
+// boundary byte behind five of them closes a candidate whose exact length is then computed from ballots.
 //
 // Anchor rules (exact-coverage arguments in DESIGN.md §Anchors; differential-tested against oracle/). The streaming
 // pass may list MORE positions than these rules (the look-ahead of the last bytes of a block is taken as "anything", the
@@ -391,13 +392,14 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         }
         // Token state: the boundary plane of the previous block (row 7 = the 256 bytes in front of this block) and its
         // "dword holds no boundary byte" bits. In front of the buffer: a boundary at position -1.
-        uint32_t Bprev = lane == 63 ? 0x80000000u : 0u, Sprev = 0;
+        uint32_t Bprev = lane == 63 ? 0x80000000u : 0u, Aprev = 0;
         if (en_tok && seg_start) {
             const uint32_t x = *reinterpret_cast<const uint32_t*>(p.log + seg_start - AB_ROW_BYTES + lane_off);
             const uint32_t c = (uint32_t)ctab[x & 0xFF] | ((uint32_t)ctab[(x >> 8) & 0xFF] << 8) | ((uint32_t)ctab[(x >> 16) & 0xFF] << 16) |
                                ((uint32_t)ctab[x >> 24] << 24);
             Bprev = (c << 7) & 0x80808080u;
-            Sprev = (Bprev ? 0u : 0x80u) | ((Bprev & 0x80808000u) ? 0u : 0x800000u);   // row 7: free / bytes 1..3 free
+            // all four bytes ASCII alphanumerics (label bytes below 0x80): row 7 of the previous block for the token chain
+            Aprev = ((c & (C_LD * 0x01010101u)) == C_LD * 0x01010101u && (x & 0x80808080u) == 0) ? 0x80u : 0u;
         }
 
         uint32_t nx[8];
@@ -508,31 +510,38 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             if (!(p.debug & 16))
 #endif
             if (en_tok) {
-                // Per row q of this lane's dwords (bit q): nb = the dword holds a boundary byte, G = it holds none ("free"),
-                // t3 = its bytes 1..3 are free, only3 = its only boundary byte is byte 3.
-                const uint32_t u1 = cl.B >> 8, u2 = cl.B >> 16, u3 = cl.B >> 24;
-                const uint32_t o123 = u1 | u2 | u3;
-                const uint32_t nb = (cl.B | o123) & 0xFFu;
-                const uint32_t G = nb ^ 0xFFu;
-                const uint32_t S = G | ((~o123 & 0xFFu) << 16);           // free bits, and the bytes-1..3-free bits in the upper half
-                const uint32_t only3 = u3 & ~(cl.B | u1 | u2) & 0xFFu;
-                // x: bit q + 1 = row q of this lane, bit 0 = row 7 of the previous block (both halves). The value travels down
-                // the wave (rotate by one lane per step); when it wraps from lane 63 to lane 0 it moves one row up, which is
-                // one bit to the left. After k steps x is the state of the dword k places earlier in the byte stream.
-                uint32_t x = (S << 1) | ((Sprev >> 7) & 0x00010001u), r5 = 0xFFFFFFFFu;
+                // Every token the validators accept (hex hashes, Base58 / Bech32 / 0x-hex addresses) consists of ASCII letters
+                // and digits only, and a token of >= 26 such bytes that ends in dword i makes dwords i-1 .. i-5 all-alphanumeric.
+                // a4: bit q set when all four bytes of this lane's dword of row q are ASCII alphanumerics.
+                const uint32_t an = cl.LD & ~w[7];
+                const uint32_t a4 = an & (an >> 8) & (an >> 16) & (an >> 24) & 0xFFu;
+                // x: bit q + 1 = row q of this lane, bit 0 = row 7 of the previous block. The value travels down the wave (rotate
+                // by one lane per step); when it wraps from lane 63 to lane 0 it moves one row up, which is one bit to the left.
+                // After k steps x is the state of the dword k places earlier in the byte stream.
+                uint32_t x = (a4 << 1) | (Aprev >> 7), r = 0xFFFFFFFFu;
+                Aprev = a4;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
+                for (int k = 0; k < 3; ++k) {
                     x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_WAVE_ROR1, 0xF, 0xF, false);
                     x += x & lane0_ones;
-                    if (k < 5) r5 &= x;
+                    r &= x;
                 }
-                // A token of >= 26 bytes that ends at byte b0 of dword i leaves dwords i-1..i-5 boundary-free and needs 6 - b0
-                // more free bytes in front of them: dword i-6 free as well, or b0 = 3 and the last three bytes of dword i-6
-                // free (necessary conditions; the exact length is computed below). Only the lowest boundary byte of a dword
-                // can close a long token.
-                const uint32_t cand = nb & (r5 >> 1) & ((x >> 1) | (only3 & (x >> 17)));
-                const uint32_t Gprev = Sprev & 0xFFu;
+                // three all-alphanumeric dwords in a row (12+ such bytes) are rare in logs: the rest only then
+                uint32_t cand = 0;
+                if (__ballot(r != 0)) {
+#pragma unroll
+                    for (int k = 3; k < 5; ++k) {
+                        x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_WAVE_ROR1, 0xF, 0xF, false);
+                        x += x & lane0_ones;
+                        r &= x;
+                    }
+                    // only the lowest boundary byte of a dword can close a long token
+                    cand = (cl.B | (cl.B >> 8) | (cl.B >> 16) | (cl.B >> 24)) & (r >> 1) & 0xFFu;
+                }
                 if (__ballot(cand != 0)) {
+                    // exact length from the boundary-free dwords (G) around the candidate
+                    const uint32_t G = ~(cl.B | (cl.B >> 8) | (cl.B >> 16) | (cl.B >> 24)) & 0xFFu;
+                    const uint32_t Gprev = (Bprev & 0x80808080u) ? 0u : 0x80u;   // row 7 of the previous block
                     const uint64_t Zp = __ballot((Gprev & 0x80u) != 0);   // free dwords of the previous block's last row
                     uint64_t Zprev_row = Zp;
 #pragma unroll
@@ -569,7 +578,6 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                         Zprev_row = Zq;
                     }
                 }
-                Sprev = S;
                 Bprev = cl.B;
             }
         }
