@@ -29,7 +29,7 @@
 // first byte of a public-suffix label is a superset class): the drains and the validation kernels decide exactly.
 //   IPv4    '.' at j preceded by 1-3 digits preceded by a boundary / buffer start, followed by 1-3 digits and '.'
 //                                                                                    (ext:1120-1179, 813-869)
-//   domain  byte that can start a PSL last label at j, '.' at j-1, label byte at j-2 (ext:537-628)
+//   domain  byte that can start a PSL last label at j, '.' at j-1 (ext:537-628)
 //   IPv6    "::" ending at j, no third ':' before it                                (ext:1044-1116)
 //   e-mail  '@' at j                                                                 (ext:1182-1196)
 //   token   boundary at j closing a token of length 26..62, 64, 90..110 or 128       (ext:1212-1409)
@@ -381,14 +381,14 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         const uint32_t seg_end = min(seg_start + p.seg_bytes, len + 1);
         // Plane carries = the word a lane 63 of a block in front of the segment would hold; only its row-7 bits (8 b + 7 =
         // class of byte seg_start - 4 + b) are ever used. In front of the buffer: boundary.
-        uint32_t cB = 0x80808080u, cD = 0, cT = 0, cLD = 0, cC = 0;
+        uint32_t cB = 0x80808080u, cD = 0, cT = 0, cC = 0;
         if (seg_start) {
             uint32_t c4 = 0;
             for (uint32_t k = 0; k < 4; ++k) c4 |= (uint32_t)ctab[p.log[seg_start - 4 + k]] << (8 * k);
             c4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c4);
             static_assert(C_B == 1 && C_DIG == 2 && C_DOT == 4 && C_COLON == 8 && C_LD == 32, "carry shifts");
             cB = (c4 << 7) & 0x80808080u; cD = (c4 << 6) & 0x80808080u; cT = (c4 << 5) & 0x80808080u;
-            cC = (c4 << 4) & 0x80808080u; cLD = (c4 << 2) & 0x80808080u;
+            cC = (c4 << 4) & 0x80808080u;
         }
         // Token state: the boundary plane of the previous block (row 7 = the 256 bytes in front of this block) and its
         // "dword holds no boundary byte" bits. In front of the buffer: a boundary at position -1.
@@ -438,21 +438,18 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             uint32_t PV_T = 0;
             if (en_v4 || en_dom) PV_T = plane_prev_dword(cl.T, cT);
             if (en_v4) {
-                // '.' at j, digit at j-1, then boundary | digit,boundary | digit,digit,boundary ...
+                // '.' at j, digit at j-1, a boundary 2..4 positions back ...
                 const uint32_t PV_D = plane_prev_dword(cl.D, cD), PV_B = plane_prev_dword(cl.B, cB);
-                const uint32_t lookback = back<1>(cl.D, PV_D) &
-                                          (back<2>(cl.B, PV_B) | (back<2>(cl.D, PV_D) & (back<3>(cl.B, PV_B) | (back<3>(cl.D, PV_D) & back<4>(cl.B, PV_B)))));
-                // ... and followed by a second octet and a second dot: digit, then '.' | digit,'.' | digit,digit,'.'
-                // (necessary for a dotted quad; drops "HTTP/1.1", "Mozilla/5.0", "Safari/537.36" style anchors)
+                const uint32_t lookback = back<1>(cl.D, PV_D) & (back<2>(cl.B, PV_B) | back<3>(cl.B, PV_B) | back<4>(cl.B, PV_B));
+                // ... and a digit at j+1 and a second dot 2..4 positions ahead (necessary for a dotted quad whose first dot this is;
+                // drops "HTTP/1.1", "Mozilla/5.0", "Safari/537.36" style anchors). The drain checks the digits in between.
                 const uint32_t NV_D = plane_next_dword(cl.D, 0x80808080u), NV_T = plane_next_dword(cl.T, 0x80808080u);
-                const uint32_t lookahead = ahead<1>(cl.D, NV_D) &
-                                           (ahead<2>(cl.T, NV_T) | (ahead<2>(cl.D, NV_D) & (ahead<3>(cl.T, NV_T) | (ahead<3>(cl.D, NV_D) & ahead<4>(cl.T, NV_T)))));
+                const uint32_t lookahead = ahead<1>(cl.D, NV_D) & (ahead<2>(cl.T, NV_T) | ahead<3>(cl.T, NV_T) | ahead<4>(cl.T, NV_T));
                 F4 = cl.T & lookback & lookahead;
             }
             if (en_dom) {
-                // byte that can start a public suffix's last label at j, '.' at j-1, label byte at j-2
-                const uint32_t PV_LD = plane_prev_dword(cl.LD, cLD);
-                Fd = cl.TL & back<1>(cl.T, PV_T) & back<2>(cl.LD, PV_LD);
+                // byte that can start a public suffix's last label at j, '.' at j-1 (what stands at j-2 is the validators' business)
+                Fd = cl.TL & back<1>(cl.T, PV_T);
             }
             if (en_v6) {
                 // "::" ending at j without a third ':'

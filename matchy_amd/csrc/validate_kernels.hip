@@ -234,6 +234,7 @@ __device__ int val_domain(const LogView& lg, const DevDb& db, const uint32_t* bl
         uint32_t c = lg.at(p);
         if (!d_is_domain_char_fast(c)) { stop_c = c; break; }
         if (c == '.') return false;  // a later dot owns this run
+        if (p - j >= db.max_tld_len) return false;   // longer than every last label of the list (bounds the scan on hostile input)
         th = tld_hash_step(th, c);
         ++p;
     }

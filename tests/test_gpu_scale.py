@@ -257,6 +257,7 @@ def test_hostile_long_runs(M, oracle):
         ("2 MB local part", b"x" * 2_000_000 + b"@a.com "),
         ("long run with a bad label deep inside", b"b" * 700_000 + b"..c" + b"d" * 700_000 + b".org "),
         ("long run ending in a dash label", b"-" + b"e" * 900_000 + b".net y"),
+        ("long last label after a dot", b"x.c" + b"d" * 700_000 + b".org " + b"y.c" + b"d" * 700_000 + b" "),
         ("long local part with two dots", b"y" * 600_000 + b".." + b"z" * 600_000 + b"@b.org "),
         ("digits only local part", b"1" * 900_000 + b"@c.net "),
         ("non-ASCII inside a long run", b" " + b"f" * 500_000 + "é".encode() + b"g" * 500_000 + b".com "),
