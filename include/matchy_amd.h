@@ -64,7 +64,8 @@ typedef struct matchy_t matchy_t;                 /* opaque (matchy.h:396-398) *
 typedef struct matchy_extractor_t matchy_extractor_t; /* opaque (matchy.h:513-515) */
 
 /* matchy.h:361-391. auto_reload / reload_callback are accepted and ignored (watching is out of scope);
- * cache_capacity is accepted and ignored (no per-thread LRU: every query is answered by the device tables). */
+ * cache_capacity: entries of the query cache of matchy_query (LRU keyed by the query string, "not found" included; 0 disables it:
+ * c_api/matchy.rs:805-808). The reference keeps one such cache per thread, this build one per handle. */
 typedef struct matchy_open_options_t {
   uint32_t cache_capacity;
   bool auto_reload;
@@ -136,8 +137,8 @@ void matchy_matches_free(matchy_matches_t *matches);                            
 void matchy_extractor_free(matchy_extractor_t *extractor);                                    /* matchy.h:1445 */
 const char *matchy_item_type_name(uint8_t item_type);                                         /* matchy.h:1460 */
 
-/* ---- statistics (matchy.h:403-432, 894, 917). This build has no per-thread LRU: cache_hits / cache_misses stay 0 and
- * matchy_clear_cache is a no-op. Query-type accounting follows Database::lookup (database.rs:725-804), including its
+/* ---- statistics (matchy.h:403-432, 894, 917). cache_hits / cache_misses count the query cache of matchy_query (bulk scans do not
+ * use it: their lookups run on the device). Query-type accounting follows Database::lookup (database.rs:725-804), including its
  * quirk that a miss is always counted as a string query. */
 typedef struct matchy_stats_t {
   uint64_t total_queries, queries_with_match, queries_without_match, cache_hits, cache_misses, ip_queries, string_queries;

@@ -17,6 +17,9 @@
 #include "engine.h"
 #include "netaddr.h"
 
+#include <list>
+#include <unordered_map>
+
 using namespace mxy;
 
 namespace {
@@ -37,8 +40,29 @@ struct Db {
     DevBuf<Candidate> qcand;
     std::string format;
     int default_device = 0;
-    // DatabaseStats (database.rs:728-795); no LRU here, so cache_hits / cache_misses stay 0
-    mutable std::atomic<uint64_t> st_total{0}, st_match{0}, st_nomatch{0}, st_ip{0}, st_str{0};
+    // DatabaseStats (database.rs:728-795)
+    mutable std::atomic<uint64_t> st_total{0}, st_match{0}, st_nomatch{0}, st_ip{0}, st_str{0}, st_chit{0}, st_cmiss{0};
+    // Query cache of Database::lookup (database.rs:32-40, 384-407, 725-804): LRU keyed by the query string, holds "not found"
+    // too. The reference keeps one cache per thread; here one per handle (guarded by `mu`, like the single-query path), so
+    // a query repeated by another thread hits as well. 0 entries = disabled (matchy_open_options_t.cache_capacity).
+    struct Cached { int kind; uint8_t prefix_len; bool has_data; DataValue data; };   // kind: 0 not found, 2 IP, 3 pattern
+    size_t cache_cap = 10000;
+    std::list<std::pair<std::string, Cached>> lru;
+    std::unordered_map<std::string, std::list<std::pair<std::string, Cached>>::iterator> lru_index;
+    const Cached* cache_get(const std::string& q) {
+        auto it = lru_index.find(q);
+        if (it == lru_index.end()) return nullptr;
+        lru.splice(lru.begin(), lru, it->second);
+        return &it->second->second;
+    }
+    void cache_put(const std::string& q, Cached&& c) {
+        if (!cache_cap) return;
+        auto it = lru_index.find(q);
+        if (it != lru_index.end()) { it->second->second = std::move(c); lru.splice(lru.begin(), lru, it->second); return; }
+        lru.emplace_front(q, std::move(c));
+        lru_index[q] = lru.begin();
+        if (lru.size() > cache_cap) { lru_index.erase(lru.back().first); lru.pop_back(); }
+    }
 
     std::shared_ptr<DeviceDb> device_db(int device) {
         if ((int)dev.size() <= device) dev.resize(device + 1);
@@ -265,7 +289,9 @@ matchy_t* matchy_open(const char* filename) {
 }
 matchy_t* matchy_open_with_options(const char* filename, const matchy_open_options_t* options) {
     if (!filename || !options) return nullptr;
-    return matchy_open(filename);
+    matchy_t* db = matchy_open(filename);
+    if (db) reinterpret_cast<Db*>(db)->cache_cap = options->cache_capacity;   // 0 disables the query cache (c_api/matchy.rs:805-808)
+    return db;
 }
 matchy_t* matchy_open_buffer(const uint8_t* buffer, uintptr_t size) {
     if (!buffer || size == 0) return nullptr;
@@ -283,9 +309,15 @@ bool matchy_has_pattern_data(const matchy_t* db) { return matchy_has_string_data
 void matchy_get_stats(const matchy_t* dbc, matchy_stats_t* st) {
     if (!dbc || !st) return;
     const Db* db = reinterpret_cast<const Db*>(dbc);
-    *st = matchy_stats_t{db->st_total.load(), db->st_match.load(), db->st_nomatch.load(), 0, 0, db->st_ip.load(), db->st_str.load()};
+    *st = matchy_stats_t{db->st_total.load(), db->st_match.load(), db->st_nomatch.load(), db->st_chit.load(), db->st_cmiss.load(), db->st_ip.load(),
+                         db->st_str.load()};
 }
-void matchy_clear_cache(const matchy_t*) {}
+void matchy_clear_cache(const matchy_t* dbc) {
+    if (!dbc) return;
+    Db* db = const_cast<Db*>(reinterpret_cast<const Db*>(dbc));
+    std::lock_guard<std::mutex> lk(db->mu);
+    db->lru.clear(); db->lru_index.clear();
+}
 uintptr_t matchy_pattern_count(const matchy_t* db) { return db ? reinterpret_cast<const Db*>(db)->img->pattern_count : 0; }
 char* matchy_metadata(const matchy_t* db) {
     if (!db) return nullptr;
@@ -335,16 +367,34 @@ void matchy_query_into(const matchy_t* dbc, const char* query, matchy_result_t* 
     if (!valid_utf8_host((const uint8_t*)query, qn)) return;  // CStr::to_str failure -> found=false
     try {
         std::lock_guard<std::mutex> lk(db->mu);
-        if (!db->query_scanner) db->query_scanner = std::make_unique<Scanner>(db->img, db->device_db(db->default_device), EX_ALL, 2);
+        const std::string key(query, qn);
         IpAddr ip;
         bool is_ip;
         std::string text;
         Candidate c;
+        if (const Db::Cached* hit = db->cache_get(key)) {
+            // cache hit (database.rs:727-757): same accounting as a lookup, except that a cached miss is typed by parsing the query
+            db->st_total++; db->st_chit++;
+            if (hit->kind == 0) { if (parse_ip(query, qn, ip)) db->st_ip++; else db->st_str++; db->st_nomatch++; return; }
+            if (hit->kind == 2) db->st_ip++; else db->st_str++;
+            db->st_match++;
+            if (!hit->has_data) return;
+            result->found = true; result->prefix_len = hit->prefix_len;
+            result->_data_cache = new DataValue(hit->data);
+            result->_db_ref = dbc;
+            return;
+        }
+        if (!db->query_scanner) db->query_scanner = std::make_unique<Scanner>(db->img, db->device_db(db->default_device), EX_ALL, 2);
         if (!query_candidate(query, qn, ip, is_ip, text, c)) return;
         ScanOutput so;
         db->query_scanner->lookup_one(text, c, so);
         db->st_total++;
-        if (so.hits.empty()) { db->st_str++; db->st_nomatch++; return; }   // a miss counts as a string query (database.rs:786-790)
+        if (db->cache_cap) db->st_cmiss++;
+        if (so.hits.empty()) {   // a miss counts as a string query (database.rs:786-790)
+            db->st_str++; db->st_nomatch++;
+            db->cache_put(key, Db::Cached{0, 0, false, DataValue()});
+            return;
+        }
         const Hit& h = so.hits[0];
         if (h.kind == 2) db->st_ip++; else db->st_str++;
         db->st_match++;
@@ -359,10 +409,11 @@ void matchy_query_into(const matchy_t* dbc, const char* query, matchy_result_t* 
             else if ((h.a == 0xFFFFFFFFu || !db->img->lit_data_offset(h.a, off)) && h.n_globs > 0) have = db->img->glob_data_offset(so.ids[h.ids_off], off);
             ok = have && db->img->decode_data(off, *dv);
         }
-        if (!ok) { delete dv; result->prefix_len = 0; return; }
+        if (!ok) { delete dv; result->prefix_len = 0; db->cache_put(key, Db::Cached{h.kind, 0, false, DataValue()}); return; }
         result->found = true;
         result->_data_cache = dv;
         result->_db_ref = dbc;
+        db->cache_put(key, Db::Cached{h.kind, result->prefix_len, true, *dv});
     } catch (const HipError& e) { set_error(e.what); }
     catch (const std::exception& e) { set_error(e.what()); }
 }

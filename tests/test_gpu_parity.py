@@ -640,15 +640,25 @@ def test_structured_data_walkers_and_stats(M):
     assert lst == [(T_MAP, 8), (T_U16, 13335), (T_U64, 2 ** 40), (T_STR, "US"), (T_BOOL, True), (T_MAP, 2), (T_DBL, 37.75),
                    (T_STR, "somewhere"), (T_DBL, 0.5), (T_I32, -7), (T_ARR, 3), (T_STR, "a"), (T_STR, "bb"), (T_MAP, 1), (T_STR, "x")]
     assert db.entry_data_list("9.9.9.9") is None
-    # statistics: Database::lookup accounting, misses count as string queries (database.rs:786-790)
+    # statistics: Database::lookup accounting (database.rs:725-804). Uncached: a miss counts as a string query (:786-790);
+    # from the query cache: a cached miss is typed by parsing the query (:743-752), so "9.9.9.9" is an IP query then
+    M.lib().matchy_clear_cache(db.handle)
     st0 = db.stats()
-    db.lookup("8.8.8.8"); db.lookup("evil.example"); db.lookup("9.9.9.9"); db.lookup("nope.example")
+    answers = [db.lookup(q) for q in ("8.8.8.8", "evil.example", "9.9.9.9", "nope.example")]
     st1 = db.stats()
     d = {k: st1[k] - st0[k] for k in st1}
-    assert d == {"total_queries": 4, "queries_with_match": 2, "queries_without_match": 2, "cache_hits": 0, "cache_misses": 0,
+    assert d == {"total_queries": 4, "queries_with_match": 2, "queries_without_match": 2, "cache_hits": 0, "cache_misses": 4,
                  "ip_queries": 1, "string_queries": 3}
+    again = [db.lookup(q) for q in ("8.8.8.8", "evil.example", "9.9.9.9", "nope.example")]
+    st2 = db.stats()
+    d = {k: st2[k] - st1[k] for k in st2}
+    assert again == answers
+    assert d == {"total_queries": 4, "queries_with_match": 2, "queries_without_match": 2, "cache_hits": 4, "cache_misses": 0,
+                 "ip_queries": 2, "string_queries": 2}
     assert M.lib().matchy_has_pattern_data(db.handle) is True
     M.lib().matchy_clear_cache(db.handle)
+    db.lookup("8.8.8.8")
+    assert db.stats()["cache_misses"] - st2["cache_misses"] == 1
     db.close()
 
 
