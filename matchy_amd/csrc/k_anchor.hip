@@ -381,14 +381,15 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         const uint32_t seg_end = min(seg_start + p.seg_bytes, len + 1);
         // Plane carries = the word a lane 63 of a block in front of the segment would hold; only its row-7 bits (8 b + 7 =
         // class of byte seg_start - 4 + b) are ever used. In front of the buffer: boundary.
-        uint32_t cB = 0x80808080u, cD = 0, cT = 0, cC = 0;
+        uint32_t cB = 0x80808080u, cX = 0;   // cX: carry of the packed word X = [C.b2, C.b3, D.b3, T.b3] (see the block loop)
         if (seg_start) {
             uint32_t c4 = 0;
             for (uint32_t k = 0; k < 4; ++k) c4 |= (uint32_t)ctab[p.log[seg_start - 4 + k]] << (8 * k);
             c4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c4);
             static_assert(C_B == 1 && C_DIG == 2 && C_DOT == 4 && C_COLON == 8 && C_LD == 32, "carry shifts");
-            cB = (c4 << 7) & 0x80808080u; cD = (c4 << 6) & 0x80808080u; cT = (c4 << 5) & 0x80808080u;
-            cC = (c4 << 4) & 0x80808080u;
+            cB = (c4 << 7) & 0x80808080u;
+            const uint32_t c2 = (c4 >> 16) & 0xFFu, c3 = c4 >> 24;   // classes of the bytes at seg_start - 2 and seg_start - 1
+            cX = ((c2 << 4) & 0x80u) | (((c3 << 4) & 0x80u) << 8) | (((c3 << 6) & 0x80u) << 16) | (((c3 << 5) & 0x80u) << 24);
         }
         // Token state: the boundary plane of the previous block (row 7 = the 256 bytes in front of this block) and its
         // "dword holds no boundary byte" bits. In front of the buffer: a boundary at position -1.
@@ -435,12 +436,14 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             const uint32_t ent_base = blk | (lane << 5);   // ring entries: anchor_pos()
 
             uint32_t Fd = 0, F4 = 0, F6 = 0;
-            uint32_t PV_T = 0;
-            if (en_v4 || en_dom) PV_T = plane_prev_dword(cl.T, cT);
+            // The patterns need one byte of the previous dword's '.' and digit planes and two of its ':' plane: they travel
+            // together as X = [C.b2, C.b3, D.b3, T.b3] (one cross-lane step instead of three; `v_perm` puts the bytes in place)
+            const uint32_t X = __builtin_amdgcn_perm(cl.T, __builtin_amdgcn_perm(cl.D, cl.C, 0x07070302u), 0x07020100u);
+            const uint32_t PV_X = plane_prev_dword(X, cX);
             if (en_v4) {
                 // '.' at j, digit at j-1, a boundary 2..4 positions back ...
-                const uint32_t PV_D = plane_prev_dword(cl.D, cD), PV_B = plane_prev_dword(cl.B, cB);
-                const uint32_t lookback = back<1>(cl.D, PV_D) & (back<2>(cl.B, PV_B) | back<3>(cl.B, PV_B) | back<4>(cl.B, PV_B));
+                const uint32_t PV_B = plane_prev_dword(cl.B, cB);
+                const uint32_t lookback = __builtin_amdgcn_perm(cl.D, PV_X, 0x06050402u) & (back<2>(cl.B, PV_B) | back<3>(cl.B, PV_B) | back<4>(cl.B, PV_B));
                 // ... and a digit at j+1 and a second dot 2..4 positions ahead (necessary for a dotted quad whose first dot this is;
                 // drops "HTTP/1.1", "Mozilla/5.0", "Safari/537.36" style anchors). The drain checks the digits in between.
                 const uint32_t NV_D = plane_next_dword(cl.D, 0x80808080u), NV_T = plane_next_dword(cl.T, 0x80808080u);
@@ -449,12 +452,11 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             }
             if (en_dom) {
                 // byte that can start a public suffix's last label at j, '.' at j-1 (what stands at j-2 is the validators' business)
-                Fd = cl.TL & back<1>(cl.T, PV_T);
+                Fd = cl.TL & back<1>(cl.T, PV_X);
             }
             if (en_v6) {
                 // "::" ending at j without a third ':'
-                const uint32_t PV_C = plane_prev_dword(cl.C, cC);
-                F6 = cl.C & back<1>(cl.C, PV_C) & ~back<2>(cl.C, PV_C);
+                F6 = cl.C & __builtin_amdgcn_perm(cl.C, PV_X, 0x06050401u) & ~__builtin_amdgcn_perm(cl.C, PV_X, 0x05040100u);
             }
 #ifdef MXY_ANCHOR_DEBUG
             if (p.debug & 4) F4 = 0;
