@@ -97,7 +97,13 @@ bool DbImage::open(std::vector<uint8_t>&& data, std::string& err) {
             lit_data_offsets.resize(cnt);
             for (uint32_t i = 0; i < cnt; ++i) lit_data_offsets[i] = rd32(lh + mstart + 8 + (size_t)i * 8);
         } else {
-            for (uint32_t i = 0; i < cnt; ++i) lit_data_map.emplace(rd32(lh + mstart + 4 + (size_t)i * 8), rd32(lh + mstart + 8 + (size_t)i * 8));
+            // not in id order: still ids 0..cnt-1 (mmdb_builder.rs:562-564 numbers the literals by enumerate()); a larger id would
+            // size the per-pattern offset table of the upload from a field of the file
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint32_t pid = rd32(lh + mstart + 4 + (size_t)i * 8);
+                if (pid >= cnt) { err = "Literal mappings name an implausible pattern id"; return false; }
+                lit_data_map.emplace(pid, rd32(lh + mstart + 8 + (size_t)i * 8));
+            }
         }
         has_literal = true;
     }
@@ -166,6 +172,9 @@ bool DbImage::check_structure(std::string& err) const {
             for (uint64_t s2 = 0; s2 < table_size; ++s2) {
                 const uint8_t* e = a + 24 + s2 * 16;
                 if (rd32(e) == 0xFFFFFFFFu) continue;
+                // literal ids are dense (paraglob_offset.rs:587: enumerate() over the AC literals), so the table has at least as
+                // many slots as the largest id + 1; the host tables indexed by literal id are sized from the largest id
+                if (rd32(e) >= table_size) { err = "AC literal map names an implausible literal id"; return false; }
                 const uint64_t po = rd32(e + 4), pc = rd32(e + 8);
                 if (pstart + po + pc * 4 > alen) { err = "AC literal map pattern list out of bounds"; return false; }
                 for (uint64_t k = 0; k < pc; ++k)
@@ -173,23 +182,29 @@ bool DbImage::check_structure(std::string& err) const {
             }
         }
     }
-    // ---- Aho-Corasick nodes reachable from the root (matchy-ac/src/lib.rs:118-124, 201-516)
+    // ---- Aho-Corasick nodes reachable from the root (matchy-ac/src/lib.rs:118-124, 201-516). Breadth-first over the goto
+    // edges, so every node gets its depth (= length of the shortest text that reaches it = length of its string). Failure
+    // links must lead to a goto-reachable node of SMALLER depth (a proper suffix): that is what lets the device walk follow
+    // failure chains without a bound of its own — a cycle of failure links would never end.
     {
         const uint64_t ac_start = rd32(pg + 20), ac_size = rd32(pg + 24);
         if (ac_size >= 20) {
             const uint8_t* ac = pg + ac_start;
-            std::vector<uint8_t> seen(ac_size / 4 + 1, 0);
+            constexpr uint32_t UNSEEN = 0xFFFFFFFFu;
+            std::vector<uint32_t> depth(ac_size / 4 + 1, UNSEEN);
             std::vector<uint32_t> queue{0};
-            seen[0] = 1;
+            depth[0] = 0;
+            uint32_t cur_depth = 0;
             auto visit = [&](uint64_t target) -> bool {
                 if ((target & 3) || target + 20 > ac_size) return false;
-                if (!seen[target / 4]) { seen[target / 4] = 1; queue.push_back((uint32_t)target); }
+                if (depth[target / 4] == UNSEEN) { depth[target / 4] = cur_depth + 1; queue.push_back((uint32_t)target); }
                 return true;
             };
             for (size_t qi = 0; qi < queue.size(); ++qi) {
                 const uint64_t off = queue[qi];
+                cur_depth = depth[off / 4];
                 const uint32_t w0 = rd32(ac + off), kind = w0 & 0xFF, pc = ac[off + 3];
-                const uint64_t eo = rd32(ac + off + 12), fo = rd32(ac + off + 8), po = rd32(ac + off + 16);
+                const uint64_t eo = rd32(ac + off + 12), po = rd32(ac + off + 16);
                 bool ok = true;
                 if (kind == 1) ok = visit(eo);
                 else if (kind == 2) {
@@ -200,9 +215,15 @@ bool DbImage::check_structure(std::string& err) const {
                     ok = eo + 1024 <= ac_size;
                     for (uint64_t c = 0; ok && c < 256; ++c) { const uint32_t t = rd32(ac + eo + c * 4); if (t) ok = visit(t); }
                 } else if (kind != 0) ok = false;
-                if (ok && fo != 0) ok = visit(fo);              // failure link (0 = root / none)
                 if (ok && pc) ok = po + (uint64_t)pc * 4 <= ac_size;   // output literal ids
                 if (!ok) { err = "Aho-Corasick automaton malformed (node at offset " + std::to_string(off) + ")"; return false; }
+            }
+            for (const uint32_t off : queue) {
+                const uint64_t fo = rd32(ac + off + 8);   // failure link (0 = root)
+                if (fo == 0) continue;
+                if ((fo & 3) || fo + 20 > ac_size || depth[fo / 4] == UNSEEN || depth[fo / 4] >= depth[off / 4]) {
+                    err = "Aho-Corasick automaton malformed (failure link of the node at offset " + std::to_string(off) + ")"; return false;
+                }
             }
         }
     }

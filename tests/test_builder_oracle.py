@@ -371,6 +371,25 @@ def test_validate_rejects_structurally_corrupt_files(tmp_path):
     # wildcard count inflated
     bad = bytearray(blob); struct.pack_into("<I", bad, pg + 60, 0x40000000)
     rc, text = validate(bytes(bad)); assert rc != 0 and "Wildcard" in text
+    # Aho-Corasick: a failure link that does not lead to a shallower node (here: a child of the root pointing at itself) would
+    # make the device walk follow failure links for ever
+    w0, eo = u32(blob, ac), u32(blob, ac + 12)
+    kind = w0 & 0xFF
+    child = eo if kind == 1 else u32(blob, ac + eo + 4) if kind == 2 else next(t for t in (u32(blob, ac + eo + 4 * c) for c in range(256)) if t)
+    bad = bytearray(blob); struct.pack_into("<I", bad, ac + child + 8, child)
+    rc, text = validate(bytes(bad)); assert rc != 0 and "failure link" in text
+    # AC literal map: a literal id far beyond the table (the upload sizes its literal -> pattern index from the largest id)
+    aclh = pg + u32(blob, pg + 96)
+    assert blob[aclh:aclh + 4] == b"ACLH"
+    slots = u32(blob, aclh + 12)
+    used = next(i for i in range(slots) if u32(blob, aclh + 24 + 16 * i) != 0xFFFFFFFF)
+    bad = bytearray(blob); struct.pack_into("<I", bad, aclh + 24 + 16 * used, 0xFFFFFFF0)
+    rc, text = validate(bytes(bad)); assert rc != 0 and "implausible literal id" in text
+    # literal mappings: a pattern id beyond the number of literals
+    mstart = lit + u32(blob, lit + 16) + strings_size
+    assert u32(blob, mstart) > 1
+    bad = bytearray(blob); struct.pack_into("<I", bad, mstart + 4 + 8, 0x7FFFFFFF)
+    rc, text = validate(bytes(bad)); assert rc != 0 and "implausible pattern id" in text
 
 
 HANDMADE = ("24", "28", "32", "v6")

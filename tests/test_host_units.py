@@ -21,3 +21,22 @@ def test_xxh64_stream(tmp_path):
     # the byte-at-a-time XXH64 used for lower-cased non-ASCII queries equals the one-shot hash (spec vector included)
     out = _build_and_run("tests/cpp/test_xxh64_stream.cpp", tmp_path)
     assert "xxh64 stream ok" in out
+
+
+def test_mutated_database_files_under_sanitizers(tmp_path):
+    # The host side of the .mxy reader under AddressSanitizer + UBSan (GPU sanitizers are not available on the pool): mutated
+    # copies of builder-made and handmade databases are either rejected with a message or opened and then walked the way the
+    # device upload walks them (tree nodes, literal table, AC literal map, flattened automaton, pattern strings, data values)
+    # without an out-of-bounds access or an allocation sized by a field of the file.
+    import os
+    csrc = ROOT / "matchy_amd" / "csrc"
+    exe = tmp_path / "fuzz_db_image"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", str(csrc), str(ROOT / "tests/cpp/fuzz_db_image.cpp"),
+                    *(str(csrc / f) for f in ("db_image.cpp", "data_codec.cpp", "db_builder.cpp", "unicode_lower.cpp")), "-o", str(exe)], check=True)
+    seeds = sorted(str(p) for p in (ROOT / "tests" / "golden").glob("handmade_*.mxy"))
+    assert seeds
+    env = dict(os.environ, MATCHY_AMD_LOWERCASE=str(ROOT / "matchy_amd" / "data" / "lowercase.bin"))
+    r = subprocess.run([str(exe), "4000", "7", *seeds], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.startswith("OK: 4000 mutated images")
