@@ -99,6 +99,56 @@ def test_full_size_parity_and_properties(M, oracle):
     sc.close(); db.close()
 
 
+@pytest.mark.parametrize("size", ["headline", "largest"])
+def test_headline_batch_as_one_launch(M, oracle, size):
+    """BASELINE configs[1] exactly as bench.py runs it: 10 M lines (1.8 GB) resident in HBM, ONE launch of every kernel
+    (matchy_scanner_scan_device; the host-buffer entry would cut the log into < 1 GiB pieces), and the largest batch one
+    launch accepts (just below 2^31 - 2^16 bytes: 32-bit positions). Counters and the whole hit set against the oracle on
+    the same bytes; then the property the sharding relies on: the two halves of the batch, cut at a newline and scanned
+    as launches of their own, give the same counters and hits."""
+    import ctypes
+    from tools import synth
+    cfg = synth.config("c2")
+    blob = synth.build_db(cfg)
+    lines = int(os.environ.get("MXY_HEADLINE_LINES", "10000000"))
+    if size == "largest":
+        log = synth.make_log(cfg, 0, lines + lines // 5)
+        if lines >= 10_000_000:
+            assert len(log) >= 0x7FFF0000
+        log = log[: log.rfind(b"\n", 0, min(len(log), 0x7FFF0000 - 1)) + 1]
+    else:
+        log = synth.make_log(cfg, 0, lines)
+    assert lines < 10_000_000 or len(log) > (3 << 29)
+    want, _, st = oracle.Database(blob).scan(log, threads=min(len(os.sched_getaffinity(0)), 16), cache=0, want_json=False)
+    db = M.Database(blob)
+    sc = M.Scanner(db)
+    hip = ctypes.CDLL("libamdhip64.so")
+    dptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(len(log) + 64)) == 0
+    assert hip.hipMemcpy(dptr, log, ctypes.c_size_t(len(log)), 1) == 0
+    r = sc.scan_device(dptr.value, len(log), fetch_mode=3)
+    got = r.hits()
+    assert (r.lines, r.candidates, r.n_hits) == (st.lines, st.candidates, len(want))
+    r.close()
+    assert got == want
+    # halves: 16-byte aligned start of the second one (the entry requires it), so the cut is moved to a newline that
+    # is followed by an aligned offset by scanning the second half from a copy
+    cut = log.rfind(b"\n", 0, len(log) // 2) + 1
+    r1 = sc.scan_device(dptr.value, cut, fetch_mode=3)
+    h1, c1 = r1.hits(), (r1.lines, r1.candidates)
+    r1.close()
+    d2 = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d2), ctypes.c_size_t(len(log) - cut + 64)) == 0
+    assert hip.hipMemcpy(d2, ctypes.c_void_p(dptr.value + cut), ctypes.c_size_t(len(log) - cut), 3) == 0
+    r2 = sc.scan_device(d2.value, len(log) - cut, fetch_mode=3)
+    h2, c2 = r2.hits(), (r2.lines, r2.candidates)
+    r2.close()
+    assert (c1[0] + c2[0], c1[1] + c2[1]) == (st.lines, st.candidates)
+    assert h1 + _rebased(h2, cut) == want
+    sc.close(); db.close()
+    hip.hipFree(dptr); hip.hipFree(d2)
+
+
 @pytest.mark.parametrize("cfgname,mirror", [("c4/10", "64"), ("c2/10", "64"), ("c2/10", "0")])
 def test_scan_device_fetch_modes(M, oracle, cfgname, mirror, monkeypatch):
     """matchy_scanner_scan_device on a buffer that lives in HBM: fetch_mode 0 (counts), 1 (records straight from the
