@@ -217,6 +217,7 @@ void DeviceDb::upload(const DbImage& img, int dev) {
             uint64_t set = 0;
             for (uint32_t wv : bm) set += (uint64_t)__builtin_popcount(wv);
             view.ip_bm24_permille = (uint32_t)(set * 1000 / ((uint64_t)bm.size() * 32));
+            view.ip_bm24_any = set ? 1u : 0u;
         }
         bytes_uploaded += bm.size() * 4;
     }
@@ -364,12 +365,18 @@ Scanner::Scanner(std::shared_ptr<const DbImage> img, std::shared_ptr<DeviceDb> d
     n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     counters_.alloc(1);
     for (auto& e : ev_) MXY_HIP(hipEventCreate(&e));
+    MXY_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    MXY_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    MXY_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
 }
 
 Scanner::~Scanner() {
     if (pinned_) (void)hipHostFree(pinned_);
     if (mirror_) (void)hipHostFree(mirror_);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
     if (host_stream_) (void)hipStreamDestroy(host_stream_);
 }
 
@@ -377,6 +384,7 @@ void Scanner::ensure_capacity(uint32_t len) {
     size_t want_c = std::max<size_t>(4096, (size_t)len / 24);
     size_t want_r = std::max<size_t>(1024, (size_t)len / 256);
     if (cands_.n < want_c) { cands_.alloc(want_c); hits_.alloc(std::max<size_t>(1024, want_c / 4)); ids_.alloc(std::max<size_t>(1024, want_c / 4)); }
+    if (cands_a_.n < want_c) cands_a_.alloc(want_c);
     if (rare_.n < want_r) rare_.alloc(want_r);
     if (tok_.n < want_r) tok_.alloc(want_r);
     if (heavy_.n < want_r) heavy_.alloc(want_r);
@@ -413,6 +421,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.filter_lit = (lookup && (!ddb_->view.has_glob || ac_ok)) ? 1u : 0u;
     if (const char* dbg = getenv("MATCHY_AMD_DEBUG")) tp.debug = (uint32_t)atoi(dbg);
     tp.cands = cands_.p; tp.cand_cap = (uint32_t)cands_.n;
+    tp.cands_a = cands_a_.p; tp.cand_a_cap = (uint32_t)cands_a_.n;
     // IPv4 candidates are listed sparsely when the /24 bitmap of the database filters most of the address space
     tp.cand_chunk = (lookup && ddb_->view.ip_bm24_permille <= 250) ? 64u : 1024u;
     tp.rare = rare_.p; tp.rare_cap = (uint32_t)rare_.n;
@@ -445,16 +454,9 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     }
     int grid_tok = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * gm[0]);
     if (grid_tok < 1) grid_tok = 1;
-    if (profile_) MXY_HIP(hipEventRecord(ev_[0], stream));
-    launch_anchor(tp, ddb_->view, grid_tok, stream);
-    if (profile_) MXY_HIP(hipEventRecord(ev_[1], stream));
-    launch_validate(tp, ddb_->view, n_cu_ * gm[1], n_cu_, stream);
-    if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
-    bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
-    if (rare_possible) launch_rare(tp, ddb_->view, n_cu_ * 4, stream);   // one wave per SIMD (297 VGPRs)
-    if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
+    // lookup parameters first: what they may allocate (mirror, glob work list) must not sit between the launches
+    LookupParams lp{};
     if (lookup) {
-        LookupParams lp{};
         lp.log = dptr; lp.len = len; lp.cands = cands_.p; lp.cand_cap = (uint32_t)cands_.n;
         lp.hits = hits_.p; lp.hit_cap = (uint32_t)hits_.n; lp.ids = ids_.p; lp.ids_cap = (uint32_t)ids_.n;
         if (ddb_->view.has_glob) {
@@ -485,7 +487,43 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         // single-query path (lookup_one) reads the raw hit list
         lp.direct = 1u;
         lp.pk = pp;
+    }
+    if (profile_) MXY_HIP(hipEventRecord(ev_[0], stream));
+    launch_anchor(tp, ddb_->view, grid_tok, stream);
+    if (profile_) MXY_HIP(hipEventRecord(ev_[1], stream));
+    // k_anchor's IPv4 candidates are complete now: their trie lookups (and the PCIe writes of their hit records, which is
+    // most of the result traffic of a log scan) go to a stream of their own and run beside the validation kernels; both
+    // lookup passes append to the same final arrays (atomic slot reservation). MATCHY_AMD_NO_FORK=1 keeps one stream.
+    static const bool no_fork = getenv("MATCHY_AMD_NO_FORK") != nullptr;
+    LookupParams la = lp;
+    static const int ip_wgs = getenv("MATCHY_AMD_IPGRID") ? atoi(getenv("MATCHY_AMD_IPGRID")) : 0;
+    // one workgroup on every other CU: enough lanes to keep the result traffic on the bus, and the validation kernels beside it
+    // keep nearly all of their resident waves (128 / 256 / 512 workgroups measured 1.199 / 1.213 / 1.241 ms per headline batch)
+    // (dense lists — a database that answers most addresses, C5 — are latency-bound trie walks for every line: full grid)
+    const bool ip_dense = tp.cand_chunk != 64u;
+    const int ip_grid = ip_wgs > 0 ? ip_wgs : ip_dense ? n_cu_ * gm[2] : std::max(1, n_cu_ / 2);
+    // a database without any IPv4 answer lists no IPv4 candidate (the /24 bitmap is empty): nothing to look up
+    const bool ip_pass = lookup && (ddb_->view.ip_bm24_any || !tp.filter_v4);
+    if (ip_pass) {
+        la.cands = cands_a_.p; la.cand_cap = (uint32_t)cands_a_.n; la.n_in = &counters_.p->n_cand_a;
+        la.glob_work = nullptr; la.glob_work_cap = 0;
+        if (!no_fork) {
+            hipEvent_t fork = profile_ ? ev_[1] : ev_fork_;
+            if (!profile_) MXY_HIP(hipEventRecord(ev_fork_, stream));
+            MXY_HIP(hipStreamWaitEvent(aux_stream_, fork, 0));
+            launch_lookup_ip(la, ddb_->view, ip_grid, ip_dense, aux_stream_);
+            MXY_HIP(hipEventRecord(ev_join_, aux_stream_));
+        }
+    }
+    launch_validate(tp, ddb_->view, n_cu_ * gm[1], n_cu_, stream);
+    if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
+    bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
+    if (rare_possible) launch_rare(tp, ddb_->view, n_cu_ * 4, stream);   // one wave per SIMD (297 VGPRs)
+    if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
+    if (lookup) {
+        if (ip_pass && no_fork) launch_lookup_ip(la, ddb_->view, ip_grid, ip_dense, stream);
         launch_lookup(lp, ddb_->view, n_cu_ * gm[2], stream);
+        if (ip_pass && !no_fork) MXY_HIP(hipStreamWaitEvent(stream, ev_join_, 0));
     }
     if (profile_) MXY_HIP(hipEventRecord(ev_[4], stream));
 }
@@ -510,7 +548,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
         MXY_HIP(hipStreamSynchronize(stream));
         const ScanCounters& c = host_counters_;
-        bool over = c.n_cand > cands_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_dom > dom_slots_ || (spill_.n && c.n_spill > spill_.n) ||
+        bool over = c.n_cand > cands_.n || c.n_cand_a > cands_a_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_dom > dom_slots_ || (spill_.n && c.n_spill > spill_.n) ||
                     c.n_final > final_.n || c.n_final_ids > final_ids_.n;
         if (!over) break;
         if (trace) fprintf(stderr, "[matchy_amd] work buffers overflow (attempt %d): regrow and rescan\n", attempt);
@@ -518,6 +556,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         if (attempt == 5) throw HipError{"scan: work buffers still overflow after regrowing"};
         // grow and run again: the kernels count past the capacity without writing, so the counts are exact demands
         if (c.n_cand > cands_.n) cands_.alloc((size_t)c.n_cand + c.n_cand / 4 + 1024);
+        if (c.n_cand_a > cands_a_.n) cands_a_.alloc((size_t)c.n_cand_a + c.n_cand_a / 4 + 1024);
         if (c.n_rare > rare_.n) rare_.alloc((size_t)c.n_rare + c.n_rare / 4 + 1024);
         if (c.n_tok > tok_.n) tok_.alloc((size_t)c.n_tok + c.n_tok / 4 + 1024);
         if (c.n_heavy > heavy_.n) heavy_.alloc((size_t)c.n_heavy + c.n_heavy / 4 + 1024);
@@ -541,8 +580,8 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     if (c.error & 4) throw HipError{"scan: a candidate is longer than 16 MiB (24-bit length field)"};
     const double t_counters = since();
     if (trace)
-        fprintf(stderr, "[matchy_amd] lines=%llu n_dom=%u n_rare=%u n_tok=%u n_heavy=%u n_cand=%u (true %u) n_hits=%u (true %u) n_ids=%u glob_work=%u final=%u\n",
-                c.lines, c.n_dom, c.n_rare, c.n_tok, c.n_heavy, c.n_cand, c.cand_true, c.n_hits, c.hits_true, c.n_ids, c.n_glob_work, c.n_final);
+        fprintf(stderr, "[matchy_amd] lines=%llu n_dom=%u n_rare=%u n_tok=%u n_heavy=%u n_cand=%u+%u (true %u) n_hits=%u (true %u) n_ids=%u glob_work=%u final=%u\n",
+                c.lines, c.n_dom, c.n_rare, c.n_tok, c.n_heavy, c.n_cand_a, c.n_cand, c.cand_true, c.n_hits, c.hits_true, c.n_ids, c.n_glob_work, c.n_final);
     out.lines = c.lines; out.n_cand = single_ ? c.n_cand : c.cand_true;
     out.n_hits = !last_lookup_ ? 0 : (single_ ? c.hits_true : c.n_final);
     if (profile_) {
@@ -598,9 +637,10 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         out.fin = (const FinalHit*)base; out.n_fin = c.n_final;
         out.fin_ids = (const uint32_t*)(base + hb); out.fin_offs = (const long long*)(base + hb + ib); out.n_fin_ids = c.n_final_ids;
     }
-    if (want_cands && c.n_cand) {
-        out.cands.resize(c.n_cand);
-        MXY_HIP(hipMemcpyAsync(out.cands.data(), cands_.p, (size_t)c.n_cand * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
+    if (want_cands && c.n_cand + c.n_cand_a) {   // k_anchor's IPv4 list, then the validation kernels' list
+        out.cands.resize((size_t)c.n_cand_a + c.n_cand);
+        if (c.n_cand_a) MXY_HIP(hipMemcpyAsync(out.cands.data(), cands_a_.p, (size_t)c.n_cand_a * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
+        if (c.n_cand) MXY_HIP(hipMemcpyAsync(out.cands.data() + c.n_cand_a, cands_.p, (size_t)c.n_cand * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
     }
     MXY_HIP(hipStreamSynchronize(stream));
     if (trace) fprintf(stderr, "[matchy_amd] fetch: counters after %.3f ms, records after %.3f ms\n", t_counters, since());

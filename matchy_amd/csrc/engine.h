@@ -19,6 +19,7 @@ void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t st
 void launch_validate(const TokParams& p, const DevDb& db, int grid, int n_cu, hipStream_t stream);
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_lookup(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream);
+void launch_lookup_ip(const LookupParams& p, const DevDb& db, int grid, bool dense, hipStream_t stream);
 
 struct HipError { std::string what; };
 #define MXY_HIP(expr)                                                                                   \
@@ -132,7 +133,11 @@ private:
     std::shared_ptr<DeviceDb> ddb_;
     hipStream_t host_stream_ = nullptr;   // scan_host: this scanner's own non-blocking stream
     uint32_t flags_, min_labels_;
-    DevBuf<Candidate> cands_;
+    DevBuf<Candidate> cands_, cands_a_;   // candidates of the validation kernels / IPv4 candidates of k_anchor
+    // the lookups of k_anchor's IPv4 candidates run on this stream beside the validation kernels (fork after k_anchor, join
+    // before the counters are read back)
+    hipStream_t aux_stream_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     DevBuf<RareAnchor> rare_, tok_, heavy_;
     DevBuf<FinalHit> final_;
     DevBuf<uint32_t> final_ids_;

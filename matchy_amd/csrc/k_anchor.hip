@@ -107,7 +107,7 @@ struct PendingV4 {
 __device__ __forceinline__ void commit_v4(PendingV4& pd, const WaveCtx& cx, CandWriter& cw) {
     const TokParams& p = *cx.p;
     const bool emit = pd.ok && ((pd.word >> ((pd.c.v4 >> 8) & 31)) & 1);
-    cw.append(emit, pd.c, p.cands, p.cand_cap, &p.counters->n_cand, Candidate{0u, 0xFFFFFFFFu, 0u, 0u});
+    cw.append(emit, pd.c, p.cands_a, p.cand_a_cap, &p.counters->n_cand_a, Candidate{0u, 0xFFFFFFFFu, 0u, 0u});
     pd.ok = false;
 }
 
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     cw_tok.flush(tok_out, p.tok_cap, &p.counters->n_tok);
     // mark the unused tail of every open chunk
     cw_dom.pad_rest(p.dom_list, p.dom_cap);
-    cw_cand.finish(p.cands, p.cand_cap, &p.counters->n_cand, Candidate{0u, 0xFFFFFFFFu, 0u, 0u});
+    cw_cand.finish(p.cands_a, p.cand_a_cap, &p.counters->n_cand_a, Candidate{0u, 0xFFFFFFFFu, 0u, 0u});
     {
         uint32_t nv = pend.n_valid;  // validated IPv4 candidates, listed or not
 #pragma unroll

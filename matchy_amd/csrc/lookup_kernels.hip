@@ -583,12 +583,13 @@ __device__ __forceinline__ void pack_record(const PackParams& pp, bool valid, co
 // that one counter — served one after the other — were 2/3 of the lookup kernel.
 constexpr uint32_t PEND_RECS = 8;
 struct PendRec { uint32_t start, len_type, a, kp; };   // kp: kind | prefix_len << 8
+template <uint32_t NREC = PEND_RECS>
 __device__ __forceinline__ void pack_pending(const PackParams& pp, uint32_t cnt, const PendRec* mine) {
     const uint32_t lane = lane_id();
     // literal hits count only if the literal has a data mapping (database.rs:911-981)
-    uint32_t lit_off[PEND_RECS], keep = 0, nids = 0;
+    uint32_t lit_off[NREC], keep = 0, nids = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < PEND_RECS; ++j) {
+    for (uint32_t j = 0; j < NREC; ++j) {
         lit_off[j] = 0xFFFFFFFFu;
         if (j < cnt) {
             const PendRec r = mine[j];
@@ -618,7 +619,7 @@ __device__ __forceinline__ void pack_pending(const PackParams& pp, uint32_t cnt,
     ids0 = __builtin_amdgcn_readfirstlane(ids0);
     uint32_t slot = slot0 + ((scan - own) & 0xFFFFu), w = ids0 + ((scan - own) >> 16);
 #pragma unroll
-    for (uint32_t j = 0; j < PEND_RECS; ++j) {
+    for (uint32_t j = 0; j < NREC; ++j) {
         if ((keep >> j) & 1u) {
             const PendRec r = mine[j];
             FinalHit f{};
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
     __shared__ uint32_t outq[GLOB ? 256 * GLOB_OUTQ : 1];
     const DfaView dv = dfa_stage<ROWS>(db, cls, rows);
     __syncthreads();
-    const uint32_t n = p.from_work ? min(p.counters->n_glob_work, p.glob_work_cap) : min(p.counters->n_cand, p.cand_cap);
+    const uint32_t n = p.from_work ? min(p.counters->n_glob_work, p.glob_work_cap) : min(p.n_in ? *p.n_in : p.counters->n_cand, p.cand_cap);
     uint32_t stride = gridDim.x * blockDim.x;
     ChunkWriter<Hit, HIT_CHUNK> cw;
     __shared__ uint32_t wb_work[4][64];
@@ -786,6 +787,33 @@ __global__ __launch_bounds__(SPILL_THREADS) void k_lookup_spill(LookupParams p, 
 }
 
 // ------------------------------------------------------------------------------------------------ launch wrapper
+// IPv4 candidates of k_anchor (LookupParams::cands / n_in name that list): trie lookups only. A kernel of its own because it
+// runs on a second stream BESIDE the validation kernels (engine.cpp) and must leave them their LDS and registers: no automaton
+// tables, NREC pending records per lane (2 -> 8 KiB per workgroup when the /24 bitmap has thinned the list, 8 when nearly every
+// candidate hits and the slot atomics would otherwise queue up: see pack_pending).
+template <uint32_t NREC>
+__global__ __launch_bounds__(256) void k_lookup_ip(LookupParams p, DevDb db) {
+    __shared__ __attribute__((aligned(16))) PendRec pend_lds[256 * NREC];
+    PendRec* pend = pend_lds + threadIdx.x * NREC;
+    uint32_t pn = 0;
+    const uint32_t n = min(*p.n_in, p.cand_cap);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {   // wave-uniform bound (pack_pending is a wave operation)
+        const uint32_t i = base + threadIdx.x;
+        Candidate c{0, 0xFFFFFFFFu, 0, 0};
+        if (i < n) c = p.cands[i];
+        if (c.len_type != 0xFFFFFFFFu && (c.len_type >> 24) == IT_IPV4) {
+            uint32_t off, pfx;
+            if (db.has_ip && trie_v4(db, c.v4, off, pfx)) { pend[pn] = PendRec{c.start, c.len_type, off, 2u | (pfx << 8)}; ++pn; }
+        }
+        if (__ballot(pn == NREC)) { pack_pending<NREC>(p.pk, pn, pend); pn = 0; }
+    }
+    pack_pending<NREC>(p.pk, pn, pend);
+}
+void launch_lookup_ip(const LookupParams& p, const DevDb& db, int grid, bool dense, hipStream_t stream) {
+    if (dense) hipLaunchKernelGGL(k_lookup_ip<8>, dim3(grid), dim3(256), 0, stream, p, db);
+    else hipLaunchKernelGGL(k_lookup_ip<2>, dim3(grid), dim3(256), 0, stream, p, db);
+}
 void launch_lookup(const LookupParams& p_in, const DevDb& db, int grid, hipStream_t stream) {
     LookupParams p = p_in;
     p.ac_filter = 0; p.from_work = 0;

@@ -53,6 +53,7 @@ struct DevDb {
     // IP tree, re-laid out as one uint2 {left,right} per node (records widened to 32 bit, host byte order)
     const uint2* ip_nodes;
     uint32_t ip_bm24_permille; // share of set bits in ip_bm24 (how much of the IPv4 space the /24 filter lets through)
+    uint32_t ip_bm24_any;      // 0: no bit of ip_bm24 is set (the database answers no IPv4 address: k_anchor lists no IPv4 candidate)
     const uint32_t* ip_bm24; // 2^24 bits: bit v set iff the first 24 IPv4 levels for prefix v do not end in "not found"
     const uint2* ip_l1;      // 65536 entries: outcome of the first 16 IPv4 levels (x = kind | prefix << 8, y = node / data offset)
     uint32_t node_count;
@@ -126,7 +127,9 @@ struct ScanCounters {
     uint32_t hits_true;
     uint32_t error;                  // bit0: a candidate matches more than 65535 glob patterns (16-bit id count of the hit record), bit2: candidate > 16 MiB (24-bit length)
     uint32_t reserved0;
-    alignas(128) uint32_t n_cand;    // candidates appended (may exceed capacity → overflow)
+    alignas(128) uint32_t n_cand;    // candidates appended by the validation kernels (may exceed capacity → overflow)
+    alignas(128) uint32_t n_cand_a;  // IPv4 candidates appended by k_anchor: a list of their own (TokParams::cands_a), so that their
+                                     // lookups can start when k_anchor ends, beside the validation kernels
     alignas(128) uint32_t n_dom;     // domain anchors (first byte of a label that follows a dot)
     alignas(128) uint32_t n_rare;    // IPv6 / e-mail anchors
     alignas(128) uint32_t n_tok;     // long-token anchors (hash / crypto candidates)
@@ -150,8 +153,10 @@ struct TokParams {
     uint32_t filter_ac;       // 1: ... unless their text reaches an output state of the glob automaton (databases with globs)
     uint32_t n_segs;
     uint32_t seg_bytes;       // bytes of log per wavefront work item: a multiple of SEG_ALIGN chosen from the batch length
-    Candidate* cands;
+    Candidate* cands;         // candidates of the validation kernels (domains, e-mail, IPv6, hashes, addresses)
     uint32_t cand_cap;
+    Candidate* cands_a;       // IPv4 candidates of k_anchor (ScanCounters::n_cand_a)
+    uint32_t cand_a_cap;
     uint32_t cand_chunk;      // slots k_anchor reserves per atomic for its IPv4 candidates (64: sparse list, 1024: one per line)
     RareAnchor* rare;         // IPv6 / e-mail anchors
     uint32_t rare_cap;
@@ -207,6 +212,7 @@ struct LookupParams {
     uint32_t len;
     const Candidate* cands;
     uint32_t cand_cap;
+    const uint32_t* n_in;     // number of entries of `cands` (device memory); null = counters->n_cand
     Hit* hits;
     uint32_t hit_cap;
     uint32_t* ids;
