@@ -451,6 +451,8 @@ def main():
             "candidates_per_step": agg["candidates"],
             "hits_per_step": agg["hits"],
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+            "kernel_ms_note": "HIP-event intervals on the scan's stream; the IPv4 lookup pass (k_lookup_ip) runs on a second stream beside "
+                              "k_validate_dom / k_validate / k_rare and is joined before `k_lookup` ends, so it is inside these intervals, not a term of its own",
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "peak_measured": peak_measured, "peak_measured_note": "device-to-device copy of 1 GiB in this run, read + write bytes / time",
                          "traffic": traffic, "kernel": dom_name, "algorithmic_bytes_per_launch": nbytes, "traffic_source": tr_note},
