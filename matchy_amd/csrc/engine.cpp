@@ -368,6 +368,8 @@ Scanner::Scanner(std::shared_ptr<const DbImage> img, std::shared_ptr<DeviceDb> d
     MXY_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     MXY_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     MXY_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
+    MXY_HIP(hipEventCreateWithFlags(&ev_join2_, hipEventDisableTiming));
+    MXY_HIP(hipStreamCreateWithFlags(&aux2_stream_, hipStreamNonBlocking));
 }
 
 Scanner::~Scanner() {
@@ -377,6 +379,8 @@ Scanner::~Scanner() {
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
+    if (ev_join2_) (void)hipEventDestroy(ev_join2_);
+    if (aux2_stream_) (void)hipStreamDestroy(aux2_stream_);
     if (host_stream_) (void)hipStreamDestroy(host_stream_);
 }
 
@@ -386,6 +390,7 @@ void Scanner::ensure_capacity(uint32_t len) {
     if (cands_.n < want_c) { cands_.alloc(want_c); hits_.alloc(std::max<size_t>(1024, want_c / 4)); ids_.alloc(std::max<size_t>(1024, want_c / 4)); }
     if (cands_a_.n < want_c) cands_a_.alloc(want_c);
     if (rare_.n < want_r) rare_.alloc(want_r);
+    if (rare_dom_.n < want_r) rare_dom_.alloc(want_r);
     if (tok_.n < want_r) tok_.alloc(want_r);
     if (heavy_.n < want_r) heavy_.alloc(want_r);
     if (final_.n < hits_.n) { final_.alloc(hits_.n); }
@@ -425,6 +430,8 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     // IPv4 candidates are listed sparsely when the /24 bitmap of the database filters most of the address space
     tp.cand_chunk = (lookup && ddb_->view.ip_bm24_permille <= 250) ? 64u : 1024u;
     tp.rare = rare_.p; tp.rare_cap = (uint32_t)rare_.n;
+    tp.rare_dom = rare_dom_.p; tp.rare_dom_cap = (uint32_t)rare_dom_.n;
+    tp.vmode = 3u;
     tp.tok = tok_.p; tp.tok_cap = (uint32_t)tok_.n;
     tp.heavy = heavy_.p; tp.heavy_cap = (uint32_t)heavy_.n;
     tp.dom_list = dom_list_.p; tp.dom_cap = (uint32_t)dom_slots_;
@@ -491,9 +498,14 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     if (profile_) MXY_HIP(hipEventRecord(ev_[0], stream));
     launch_anchor(tp, ddb_->view, grid_tok, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[1], stream));
-    // k_anchor's IPv4 candidates are complete now: their trie lookups (and the PCIe writes of their hit records, which is
-    // most of the result traffic of a log scan) go to a stream of their own and run beside the validation kernels; both
-    // lookup passes append to the same final arrays (atomic slot reservation). MATCHY_AMD_NO_FORK=1 keeps one stream.
+    // Fork. Everything k_anchor lists is complete now, and two parts of the rest do not depend on k_validate_dom:
+    //  * the trie lookups of the IPv4 candidates (and the PCIe writes of their hit records, which is most of the result traffic
+    //    of a log scan) -> k_lookup_ip on a stream of its own; both lookup passes append to the same final arrays (atomic slot
+    //    reservation);
+    //  * k_validate over the long tokens and k_anchor's IPv6 / e-mail anchors, and k_rare behind it -> a third stream.
+    // The scan's stream keeps k_validate_dom, k_validate over the domain anchors k_validate_dom left undecided, and the lookups
+    // of the validation kernels' candidates; it joins the third stream before those lookups and the second after them.
+    // MATCHY_AMD_NO_FORK=1 keeps everything on one stream.
     static const bool no_fork = getenv("MATCHY_AMD_NO_FORK") != nullptr;
     LookupParams la = lp;
     static const int ip_wgs = getenv("MATCHY_AMD_IPGRID") ? atoi(getenv("MATCHY_AMD_IPGRID")) : 0;
@@ -504,22 +516,41 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     const int ip_grid = ip_wgs > 0 ? ip_wgs : ip_dense ? n_cu_ * gm[2] : std::max(1, n_cu_ / 2);
     // a database without any IPv4 answer lists no IPv4 candidate (the /24 bitmap is empty): nothing to look up
     const bool ip_pass = lookup && (ddb_->view.ip_bm24_any || !tp.filter_v4);
+    const bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
+    static const int misc_wgs = getenv("MATCHY_AMD_MISC_GRID") ? atoi(getenv("MATCHY_AMD_MISC_GRID")) : 0;
     if (ip_pass) {
         la.cands = cands_a_.p; la.cand_cap = (uint32_t)cands_a_.n; la.n_in = &counters_.p->n_cand_a;
         la.glob_work = nullptr; la.glob_work_cap = 0;
-        if (!no_fork) {
-            hipEvent_t fork = profile_ ? ev_[1] : ev_fork_;
-            if (!profile_) MXY_HIP(hipEventRecord(ev_fork_, stream));
+    }
+    if (!no_fork) {
+        hipEvent_t fork = profile_ ? ev_[1] : ev_fork_;
+        if (!profile_) MXY_HIP(hipEventRecord(ev_fork_, stream));
+        if (ip_pass) {
             MXY_HIP(hipStreamWaitEvent(aux_stream_, fork, 0));
             launch_lookup_ip(la, ddb_->view, ip_grid, ip_dense, aux_stream_);
             MXY_HIP(hipEventRecord(ev_join_, aux_stream_));
         }
+        MXY_HIP(hipStreamWaitEvent(aux2_stream_, fork, 0));
+        TokParams t1 = tp;
+        t1.vmode = 1u;
+        // beside k_validate_dom: half the CUs, so that kernel keeps most of its resident waves
+        launch_validate_misc(t1, ddb_->view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);
+        if (rare_possible) launch_rare(tp, ddb_->view, n_cu_ * 4, aux2_stream_);   // one wave per SIMD (297 VGPRs)
+        MXY_HIP(hipEventRecord(ev_join2_, aux2_stream_));
+        launch_validate_dom(tp, ddb_->view, n_cu_ * gm[1], stream);
+        TokParams t2 = tp;
+        t2.vmode = 2u;
+        launch_validate_misc(t2, ddb_->view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
+        if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
+        MXY_HIP(hipStreamWaitEvent(stream, ev_join2_, 0));
+        if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
+    } else {
+        launch_validate_dom(tp, ddb_->view, n_cu_ * gm[1], stream);
+        launch_validate_misc(tp, ddb_->view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);   // vmode 3: every list
+        if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
+        if (rare_possible) launch_rare(tp, ddb_->view, n_cu_ * 4, stream);
+        if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
     }
-    launch_validate(tp, ddb_->view, n_cu_ * gm[1], n_cu_, stream);
-    if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
-    bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
-    if (rare_possible) launch_rare(tp, ddb_->view, n_cu_ * 4, stream);   // one wave per SIMD (297 VGPRs)
-    if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
     if (lookup) {
         if (ip_pass && no_fork) launch_lookup_ip(la, ddb_->view, ip_grid, ip_dense, stream);
         launch_lookup(lp, ddb_->view, n_cu_ * gm[2], stream);
@@ -548,7 +579,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
         MXY_HIP(hipStreamSynchronize(stream));
         const ScanCounters& c = host_counters_;
-        bool over = c.n_cand > cands_.n || c.n_cand_a > cands_a_.n || c.n_rare > rare_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_dom > dom_slots_ || (spill_.n && c.n_spill > spill_.n) ||
+        bool over = c.n_cand > cands_.n || c.n_cand_a > cands_a_.n || c.n_rare > rare_.n || c.n_rare_dom > rare_dom_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_dom > dom_slots_ || (spill_.n && c.n_spill > spill_.n) ||
                     c.n_final > final_.n || c.n_final_ids > final_ids_.n;
         if (!over) break;
         if (trace) fprintf(stderr, "[matchy_amd] work buffers overflow (attempt %d): regrow and rescan\n", attempt);
@@ -558,6 +589,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         if (c.n_cand > cands_.n) cands_.alloc((size_t)c.n_cand + c.n_cand / 4 + 1024);
         if (c.n_cand_a > cands_a_.n) cands_a_.alloc((size_t)c.n_cand_a + c.n_cand_a / 4 + 1024);
         if (c.n_rare > rare_.n) rare_.alloc((size_t)c.n_rare + c.n_rare / 4 + 1024);
+        if (c.n_rare_dom > rare_dom_.n) rare_dom_.alloc((size_t)c.n_rare_dom + c.n_rare_dom / 4 + 1024);
         if (c.n_tok > tok_.n) tok_.alloc((size_t)c.n_tok + c.n_tok / 4 + 1024);
         if (c.n_heavy > heavy_.n) heavy_.alloc((size_t)c.n_heavy + c.n_heavy / 4 + 1024);
         if (glob_work_.n && c.n_glob_work > glob_work_.n) glob_work_.alloc((size_t)c.n_glob_work + c.n_glob_work / 4 + 1024);
@@ -580,8 +612,8 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     if (c.error & 4) throw HipError{"scan: a candidate is longer than 16 MiB (24-bit length field)"};
     const double t_counters = since();
     if (trace)
-        fprintf(stderr, "[matchy_amd] lines=%llu n_dom=%u n_rare=%u n_tok=%u n_heavy=%u n_cand=%u+%u (true %u) n_hits=%u (true %u) n_ids=%u glob_work=%u final=%u\n",
-                c.lines, c.n_dom, c.n_rare, c.n_tok, c.n_heavy, c.n_cand_a, c.n_cand, c.cand_true, c.n_hits, c.hits_true, c.n_ids, c.n_glob_work, c.n_final);
+        fprintf(stderr, "[matchy_amd] lines=%llu n_dom=%u n_rare=%u+%u n_tok=%u n_heavy=%u n_cand=%u+%u (true %u) n_hits=%u (true %u) n_ids=%u glob_work=%u final=%u\n",
+                c.lines, c.n_dom, c.n_rare, c.n_rare_dom, c.n_tok, c.n_heavy, c.n_cand_a, c.n_cand, c.cand_true, c.n_hits, c.hits_true, c.n_ids, c.n_glob_work, c.n_final);
     out.lines = c.lines; out.n_cand = single_ ? c.n_cand : c.cand_true;
     out.n_hits = !last_lookup_ ? 0 : (single_ ? c.hits_true : c.n_final);
     if (profile_) {

@@ -16,7 +16,8 @@ namespace mxy {
 int anchor_blocks_per_cu();
 int validate_blocks_per_cu(bool ac);
 void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
-void launch_validate(const TokParams& p, const DevDb& db, int grid, int n_cu, hipStream_t stream);
+void launch_validate_dom(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
+void launch_validate_misc(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_lookup(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_lookup_ip(const LookupParams& p, const DevDb& db, int grid, bool dense, hipStream_t stream);
@@ -138,7 +139,10 @@ private:
     // before the counters are read back)
     hipStream_t aux_stream_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
-    DevBuf<RareAnchor> rare_, tok_, heavy_;
+    // a third stream: k_validate's part that does not depend on k_validate_dom (tokens, IPv6 / e-mail anchors) and k_rare behind it
+    hipStream_t aux2_stream_ = nullptr;
+    hipEvent_t ev_join2_ = nullptr;
+    DevBuf<RareAnchor> rare_, rare_dom_, tok_, heavy_;
     DevBuf<FinalHit> final_;
     DevBuf<uint32_t> final_ids_;
     DevBuf<long long> final_offs_;

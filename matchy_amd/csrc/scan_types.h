@@ -131,7 +131,9 @@ struct ScanCounters {
     alignas(128) uint32_t n_cand_a;  // IPv4 candidates appended by k_anchor: a list of their own (TokParams::cands_a), so that their
                                      // lookups can start when k_anchor ends, beside the validation kernels
     alignas(128) uint32_t n_dom;     // domain anchors (first byte of a label that follows a dot)
-    alignas(128) uint32_t n_rare;    // IPv6 / e-mail anchors
+    alignas(128) uint32_t n_rare;    // IPv6 / e-mail anchors (k_anchor)
+    alignas(128) uint32_t n_rare_dom;   // domain anchors k_validate_dom could not decide (general walk in k_validate): a list of their own,
+                                        // so that k_validate can take k_anchor's rare anchors and the tokens while k_validate_dom runs
     alignas(128) uint32_t n_tok;     // long-token anchors (hash / crypto candidates)
     alignas(128) uint32_t n_heavy;   // tokens that need a checksum validator (Base58Check, Bech32, EIP-55, Monero)
     alignas(128) uint32_t n_hits;
@@ -160,6 +162,9 @@ struct TokParams {
     uint32_t cand_chunk;      // slots k_anchor reserves per atomic for its IPv4 candidates (64: sparse list, 1024: one per line)
     RareAnchor* rare;         // IPv6 / e-mail anchors
     uint32_t rare_cap;
+    RareAnchor* rare_dom;     // undecided domain anchors (written by k_validate_dom)
+    uint32_t rare_dom_cap;
+    uint32_t vmode;           // k_validate: bit 0 = long tokens + the rare list, bit 1 = the rare_dom list
     RareAnchor* tok;          // long-token anchors
     uint32_t tok_cap;
     RareAnchor* heavy;        // tokens that passed the cheap prefilters of k_validate and need k_rare

@@ -877,14 +877,14 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
                 }
             }
         }
-        sw.append(slow, RareAnchor{cur.j & 0x7FFFFFFFu, (uint32_t)RARE_DOM}, p.rare, p.rare_cap, &p.counters->n_rare);
+        sw.append(slow, RareAnchor{cur.j & 0x7FFFFFFFu, (uint32_t)RARE_DOM}, p.rare_dom, p.rare_dom_cap, &p.counters->n_rare_dom);
         cur = nxt;
     }
     if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand);
     else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
     cw.flush(p.cands, p.cand_cap, &p.counters->n_cand);
     cw_dense.pad_rest(p.cands, p.cand_cap, SC);
-    sw.flush(p.rare, p.rare_cap, &p.counters->n_rare);
+    sw.flush(p.rare_dom, p.rare_dom_cap, &p.counters->n_rare_dom);
     // validated domain candidates, listed or not
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     // reference's from_utf8 precondition is implied by the per-symbol checks.
     __shared__ RareAnchor wb_heavy[4][64];
     BufferedWriter<RareAnchor> hw(wb_heavy[threadIdx.x >> 6]);
-    const uint32_t nt = min(p.counters->n_tok, p.tok_cap);
+    const uint32_t nt = (p.vmode & 1u) ? min(p.counters->n_tok, p.tok_cap) : 0u;
     for (uint32_t base = blockIdx.x * blockDim.x; base < nt; base += stride) {
         const uint32_t i = base + threadIdx.x;
         RareAnchor ra{0, 0xFF};
@@ -946,11 +946,16 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     // IPv6 ("::") and e-mail ('@') anchors from the rare list. The IPv6 parser reads its bytes many times: each lane
     // copies log[p2-40, p2+40) into its LDS window with five wide loads first.
     uint8_t* win = winbuf + threadIdx.x * 80;
-    const uint32_t nr = min(p.counters->n_rare, p.rare_cap);
+    // two lists through the same code: k_anchor's rare anchors (vmode bit 0) and the domain anchors k_validate_dom left (bit 1);
+    // the engine runs the first beside k_validate_dom on a stream of its own and the second behind it
+    for (uint32_t li = 0; li < 2; ++li) {
+    if (!((p.vmode >> li) & 1u)) continue;
+    const RareAnchor* rlist = li ? p.rare_dom : p.rare;
+    const uint32_t nr = li ? min(p.counters->n_rare_dom, p.rare_dom_cap) : min(p.counters->n_rare, p.rare_cap);
     for (uint32_t base = blockIdx.x * blockDim.x; base < nr; base += stride) {
         const uint32_t i = base + threadIdx.x;
         RareAnchor ra{0, 0xFF};
-        if (i < nr) ra = p.rare[i];
+        if (i < nr) ra = rlist[i];
         const uint32_t kind = ra.len_kind & 0xFF;
         Candidate c{0, 0, 0, 0};
         bool emit = false;
@@ -1019,6 +1024,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         }
         cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand);
     }
+    }
     cw.flush(p.cands, p.cand_cap, &p.counters->n_cand);
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
 }
@@ -1074,15 +1080,16 @@ int validate_blocks_per_cu(bool ac) {
     if (e != hipSuccess || n < 1) n = ac ? 3 : 4;
     return n;
 }
-// grid = workgroups of k_validate_dom; k_validate (rare anchors, tokens) has a fraction of the work and is latency-bound:
-// one workgroup per CU measured best (every workgroup stages the suffix tables first; 0.057 -> 0.049 ms on the headline batch)
-void launch_validate(const TokParams& p, const DevDb& db, int grid, int n_cu, hipStream_t stream) {
-    if (p.flags & EX_DOMAINS) {
-        if (p.filter_ac) hipLaunchKernelGGL(k_validate_dom<true>, dim3(grid), dim3(256), 0, stream, p, db);
-        else hipLaunchKernelGGL(k_validate_dom<false>, dim3(grid), dim3(256), 0, stream, p, db);
-    }
-    static const int misc_mult = getenv("MATCHY_AMD_MISC_GRID") ? atoi(getenv("MATCHY_AMD_MISC_GRID")) : 1;
-    hipLaunchKernelGGL(k_validate, dim3(n_cu * (misc_mult > 0 ? misc_mult : 1)), dim3(256), 0, stream, p, db);
+// grid = workgroups of k_validate_dom
+void launch_validate_dom(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
+    if (!(p.flags & EX_DOMAINS)) return;
+    if (p.filter_ac) hipLaunchKernelGGL(k_validate_dom<true>, dim3(grid), dim3(256), 0, stream, p, db);
+    else hipLaunchKernelGGL(k_validate_dom<false>, dim3(grid), dim3(256), 0, stream, p, db);
+}
+// k_validate (tokens, rare anchors, undecided domains: TokParams::vmode says which lists) has a fraction of the work and is
+// latency-bound: every workgroup stages the suffix tables first, so few workgroups (one per CU measured best for the whole job)
+void launch_validate_misc(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_validate, dim3(grid), dim3(256), 0, stream, p, db);
 }
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_rare, dim3(grid), dim3(64), 0, stream, p, db);
