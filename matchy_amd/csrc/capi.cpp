@@ -722,7 +722,7 @@ int32_t matchy_scanner_scan_device(matchy_scanner_t* s, const void* dptr, size_t
     try {
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         const bool sorted = (fetch_mode & 2) != 0;
-        h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st, (fetch_mode & 1) && !sorted);
+        h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st, (fetch_mode & 1) && !sorted, /*fork=*/true);
         ScanOutput so;
         h->sc->fetch(so, false, st, (fetch_mode & 1) ? HITS_FINAL : HITS_NONE, sorted);
         if (fetch_mode == MATCHY_SCAN_FETCH_DEVICE) { fill_device_result(*h->sc, so, len, out); return MATCHY_SUCCESS; }

@@ -408,12 +408,12 @@ void Scanner::ensure_mirror(uint32_t recs, uint32_t ids) {
     MXY_HIP(hipHostMalloc(&mirror_, bytes, hipHostMallocDefault));
 }
 
-void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror) {
+void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror, bool fork) {
     if (len >= 0x7FFF0000u) throw HipError{"scan_device: chunk too large (must be < 2^31 bytes)"};
     if (((uintptr_t)dptr & 15) != 0) throw HipError{"scan_device: device pointer must be 16-byte aligned"};
     MXY_HIP(hipSetDevice(ddb_->device));
     ensure_capacity(len);
-    last_ptr_ = dptr; last_len_ = len; last_lookup_ = lookup; last_mirror_ = host_mirror;
+    last_ptr_ = dptr; last_len_ = len; last_lookup_ = lookup; last_mirror_ = host_mirror; last_fork_ = fork;
     MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters), stream));
     TokParams tp{};
     tp.log = dptr; tp.len = len; tp.flags = flags_; tp.min_labels = min_labels_;
@@ -506,7 +506,8 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     // The scan's stream keeps k_validate_dom, k_validate over the domain anchors k_validate_dom left undecided, and the lookups
     // of the validation kernels' candidates; it joins the third stream before those lookups and the second after them.
     // MATCHY_AMD_NO_FORK=1 keeps everything on one stream.
-    static const bool no_fork = getenv("MATCHY_AMD_NO_FORK") != nullptr;
+    static const bool env_no_fork = getenv("MATCHY_AMD_NO_FORK") != nullptr;
+    const bool no_fork = env_no_fork || !fork;
     LookupParams la = lp;
     static const int ip_wgs = getenv("MATCHY_AMD_IPGRID") ? atoi(getenv("MATCHY_AMD_IPGRID")) : 0;
     // one workgroup on every other CU: enough lanes to keep the result traffic on the bus, and the validation kernels beside it
@@ -605,7 +606,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
             const size_t want = std::max<size_t>(hits_.n + ids_.n, (size_t)c.n_final_ids + c.n_final_ids / 4 + 1024);
             final_ids_.alloc(want); final_offs_.alloc(want);
         }
-        scan_device(last_ptr_, last_len_, last_lookup_, stream, last_mirror_);
+        scan_device(last_ptr_, last_len_, last_lookup_, stream, last_mirror_, last_fork_);
     }
     const ScanCounters& c = host_counters_;
     if (c.error & 1) throw HipError{"scan: a candidate matches more than 65535 glob patterns (the hit record counts pattern ids in 16 bits)"};

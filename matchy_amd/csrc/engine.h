@@ -106,7 +106,11 @@ public:
     // Scan `len` bytes already resident in device memory (16-byte aligned). len < 2^31.
     // lookup=false stops after extraction. Results stay on the device until fetch().
     // host_mirror: pack_record also writes the final records into pinned host memory (unsorted fetches then need no copy)
-    void scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror = false);
+    // fork: run the parts of the scan that do not depend on each other on the scanner's two extra streams (engine.cpp). For ONE
+    // batch at a time on device-resident input; callers that keep several batches in flight (submit / wait) or whose time is the
+    // host-to-device copy (scan_host) stay on one stream per scanner: the runtime multiplexes streams onto a few hardware queues,
+    // and three scanners with three streams each ran 25 % slower than with one each.
+    void scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror = false, bool fork = false);
     // Copies counters (and hits / candidates) back. Call after scan_device; synchronises the stream.
     // sorted: the final records are put into canonical order on the GPU (sort_hits.hip) before they are copied back
     void fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode = HITS_FINAL, bool sorted = false);
@@ -168,7 +172,7 @@ private:
     ScanCounters host_counters_{};
     uint32_t last_len_ = 0;
     const uint8_t* last_ptr_ = nullptr;
-    bool last_lookup_ = false;
+    bool last_lookup_ = false, last_fork_ = false;
     bool single_ = false;
     bool profile_ = false;
     hipEvent_t ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -120,7 +120,21 @@ def _scan_both(M, oracle, blob, text):
     got_hits = res.hits()
     got_lines = res.ndjson(text, source="t.log")
     got_stats = (res.lines, res.candidates)
-    res.close(); sc.close(); db.close()
+    res.close()
+    if text:
+        # the same bytes through the device-resident entry: that one runs the independent parts of a scan on three streams
+        # (the host-buffer entry above stays on one), and both must agree hit for hit
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        dptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(len(text) + 64)) == 0
+        assert hip.hipMemcpy(dptr, bytes(text), ctypes.c_size_t(len(text)), 1) == 0
+        rd = sc.scan_device(dptr.value, len(text), fetch_mode=3)
+        assert (rd.lines, rd.candidates) == got_stats
+        assert rd.hits() == got_hits
+        rd.close()
+        hip.hipFree(dptr)
+    sc.close(); db.close()
     odb = oracle.Database(blob)
     want_hits, want_lines, st = odb.scan(text, source="t.log")
     return got_hits, got_lines, got_stats, want_hits, want_lines, (st.lines, st.candidates)
