@@ -41,11 +41,28 @@ def check_extract(buf, what):
     return True
 
 
+import ctypes  # noqa: E402
+hip = ctypes.CDLL("libamdhip64.so")
+
+
 def check_scan(buf, what):
     res = sc.scan(buf)
     got = res.hits()
     gs = (res.lines, res.candidates)
     res.close()
+    if buf:   # the device-resident entry (independent parts of the scan on three streams) must agree with the host-buffer entry
+        dptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(len(buf) + 64)) == 0
+        assert hip.hipMemcpy(dptr, bytes(buf), ctypes.c_size_t(len(buf)), 1) == 0
+        rd = sc.scan_device(dptr.value, len(buf), fetch_mode=3)
+        same = rd.hits() == got and (rd.lines, rd.candidates) == gs
+        rd.close()
+        hip.hipFree(dptr)
+        if not same:
+            Path("gpurun_out").mkdir(exist_ok=True)
+            Path("gpurun_out/fuzz_fail.bin").write_bytes(buf)
+            print(f"MISMATCH device-resident vs host-buffer entry [{what}]", flush=True)
+            return False
     want, _, st = odb.scan(buf, want_json=False)
     if got != want or gs != (st.lines, st.candidates):
         Path("gpurun_out").mkdir(exist_ok=True)
