@@ -583,8 +583,11 @@ __device__ __forceinline__ void pack_record(const PackParams& pp, bool valid, co
 // that one counter — served one after the other — were 2/3 of the lookup kernel.
 constexpr uint32_t PEND_RECS = 8;
 struct PendRec { uint32_t start, len_type, a, kp; };   // kp: kind | prefix_len << 8
-template <uint32_t NREC = PEND_RECS>
-__device__ __forceinline__ void pack_pending(const PackParams& pp, uint32_t cnt, const PendRec* mine) {
+// WG = true: the call is made by every thread of a 256-thread workgroup (the flush at the end of a kernel); the four waves then
+// reserve their slots with ONE pair of atomics per workgroup through `wg` (6 words of LDS). All waves finish their lists at about
+// the same time, and 2048 waves queueing on the one counter line for their last flush were half of the string-lookup pass.
+template <uint32_t NREC = PEND_RECS, bool WG = false>
+__device__ __forceinline__ void pack_pending(const PackParams& pp, uint32_t cnt, const PendRec* mine, uint32_t* wg = nullptr) {
     const uint32_t lane = lane_id();
     // literal hits count only if the literal has a data mapping (database.rs:911-981)
     uint32_t lit_off[NREC], keep = 0, nids = 0;
@@ -609,14 +612,30 @@ __device__ __forceinline__ void pack_pending(const PackParams& pp, uint32_t cnt,
         if ((int)lane >= off) scan += t;
     }
     const uint32_t total = (uint32_t)__shfl((int)scan, 63);
-    if (total == 0) return;
     uint32_t slot0 = 0, ids0 = 0;
-    if (lane == 0) {
-        slot0 = atomicAdd(&pp.counters->n_final, total & 0xFFFFu);
-        if (total >> 16) ids0 = atomicAdd(&pp.counters->n_final_ids, total >> 16);
+    if constexpr (WG) {
+        const uint32_t wave = threadIdx.x >> 6;
+        if (lane == 0) wg[wave] = total;   // records | ids << 16: at most 4 * 64 * NREC of each per workgroup
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t k = 0; k < 4; ++k) { const uint32_t t = wg[k]; all += t; if (k < wave) before += t; }
+        if (threadIdx.x == 0 && all) {
+            wg[4] = atomicAdd(&pp.counters->n_final, all & 0xFFFFu);
+            wg[5] = (all >> 16) ? atomicAdd(&pp.counters->n_final_ids, all >> 16) : 0u;
+        }
+        __syncthreads();
+        if (total == 0) return;
+        slot0 = wg[4] + (before & 0xFFFFu);
+        ids0 = wg[5] + (before >> 16);
+    } else {
+        if (total == 0) return;
+        if (lane == 0) {
+            slot0 = atomicAdd(&pp.counters->n_final, total & 0xFFFFu);
+            if (total >> 16) ids0 = atomicAdd(&pp.counters->n_final_ids, total >> 16);
+        }
+        slot0 = __builtin_amdgcn_readfirstlane(slot0);
+        ids0 = __builtin_amdgcn_readfirstlane(ids0);
     }
-    slot0 = __builtin_amdgcn_readfirstlane(slot0);
-    ids0 = __builtin_amdgcn_readfirstlane(ids0);
     uint32_t slot = slot0 + ((scan - own) & 0xFFFFu), w = ids0 + ((scan - own) >> 16);
 #pragma unroll
     for (uint32_t j = 0; j < NREC; ++j) {
@@ -648,7 +667,11 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
     __shared__ uint8_t cls[256];  // byte -> DFA class
     // the glob pass sees texts that go deep into the automaton anyway: a small shallow part, more resident waves
     constexpr uint32_t ROWS = GLOB ? DFA_LDS_ENTRIES_GLOB : DFA_LDS_ENTRIES;
-    __shared__ uint32_t rows[ROWS];
+    // the transition rows of the lean pass are dynamic LDS: a database without a glob section has no automaton, and without the
+    // 32 KiB twice as many workgroups are resident (lookup_dyn_lds(); the string lookups are chains of dependent loads)
+    extern __shared__ __attribute__((aligned(16))) uint32_t rows_dyn[];
+    __shared__ uint32_t rows_glob[GLOB ? ROWS : 1];
+    uint32_t* rows = GLOB ? rows_glob : rows_dyn;
     __shared__ uint64_t twin[GLOB ? 256 * GLOB_WIN_WORDS : 1];   // per-lane text window of the glob pass
     __shared__ uint32_t outq[GLOB ? 256 * GLOB_OUTQ : 1];
     const DfaView dv = dfa_stage<ROWS>(db, cls, rows);
@@ -725,7 +748,8 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
             if (q < p.spill_cap) p.spill[q] = i;
         }
     }
-    if (p.direct && !GLOB) pack_pending(p.pk, pn, pend);
+    __shared__ uint32_t wg_slots[6];
+    if (p.direct && !GLOB) pack_pending<PEND_RECS, true>(p.pk, pn, pend, wg_slots);
     cw.pad_rest(p.hits, p.hit_cap, SH);
     if (!GLOB && p.ac_filter) ww.flush(p.glob_work, p.glob_work_cap, &p.counters->n_glob_work);
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->hits_true, cw.total);
@@ -808,7 +832,8 @@ __global__ __launch_bounds__(256) void k_lookup_ip(LookupParams p, DevDb db) {
         }
         if (__ballot(pn == NREC)) { pack_pending<NREC>(p.pk, pn, pend); pn = 0; }
     }
-    pack_pending<NREC>(p.pk, pn, pend);
+    __shared__ uint32_t wg_slots[6];
+    pack_pending<NREC, true>(p.pk, pn, pend, wg_slots);
 }
 void launch_lookup_ip(const LookupParams& p, const DevDb& db, int grid, bool dense, hipStream_t stream) {
     if (dense) hipLaunchKernelGGL(k_lookup_ip<8>, dim3(grid), dim3(256), 0, stream, p, db);
@@ -817,13 +842,14 @@ void launch_lookup_ip(const LookupParams& p, const DevDb& db, int grid, bool den
 void launch_lookup(const LookupParams& p_in, const DevDb& db, int grid, hipStream_t stream) {
     LookupParams p = p_in;
     p.ac_filter = 0; p.from_work = 0;
+    const size_t lean_lds = db.dfa ? (size_t)DFA_LDS_ENTRIES * 4 : 0;   // rows_dyn of k_lookup<false>
     if (!db.has_glob) {
-        hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(256), 0, stream, p, db);
+        hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(256), lean_lds, stream, p, db);
     } else if (db.dfa && db.wild_count == 0 && p.glob_work && grid > 1) {
         // two passes: lean lookup + AC prefilter for everything, the register-heavy glob matcher only for the few
         // candidates that reach an AC output state (without literal hits no glob can match: pure wildcards aside)
         p.ac_filter = 1;
-        hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(256), 0, stream, p, db);
+        hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(256), lean_lds, stream, p, db);
         p.ac_filter = 0; p.from_work = 1;
         hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(256), 0, stream, p, db);
     } else {
