@@ -90,9 +90,28 @@ MXY_HD uint64_t xxh64(const uint8_t* p, size_t len, uint64_t seed) {
         h = seed + P5;
     }
     h += (uint64_t)len;
-    while (q + 8 <= len) { h ^= round(0, rd64(q)); h = rotl64(h, 27) * P1 + P4; q += 8; }
-    if (q + 4 <= len) { h ^= rd32(q) * P1; h = rotl64(h, 23) * P2 + P3; q += 4; }
-    while (q < len) { h ^= (uint64_t)(FOLD ? ascii_lower1(p[q]) : (uint32_t)p[q]) * P5; h = rotl64(h, 11) * P1; ++q; }
+    if (len >= 8) {
+        // The last up to 7 bytes come out of ONE 8-byte load that ends at the end of the input (it overlaps bytes already hashed,
+        // which are shifted out), and for short inputs every load is issued before the chain of multiplies starts: on the GPU a
+        // key is a handful of dependent memory round trips otherwise (one per 8 / 4 / 1-byte step of the tail).
+        const uint64_t last = rd64(len - 8);
+        if (len < 32) {
+            const uint64_t w0 = rd64(0), w1 = rd64(len >= 16 ? 8 : len - 8), w2 = rd64(len >= 24 ? 16 : len - 8);
+            h ^= round(0, w0); h = rotl64(h, 27) * P1 + P4;
+            if (len >= 16) { h ^= round(0, w1); h = rotl64(h, 27) * P1 + P4; }
+            if (len >= 24) { h ^= round(0, w2); h = rotl64(h, 27) * P1 + P4; }
+            q = len & ~(size_t)7;
+        } else {
+            while (q + 8 <= len) { h ^= round(0, rd64(q)); h = rotl64(h, 27) * P1 + P4; q += 8; }
+        }
+        size_t r = len - q;                                   // 0..7 bytes left: the top r bytes of `last`
+        uint64_t tail = r ? last >> (8 * (8 - r)) : 0;
+        if (r >= 4) { h ^= (tail & 0xFFFFFFFFull) * P1; h = rotl64(h, 23) * P2 + P3; tail >>= 32; r -= 4; }
+        for (; r; --r) { h ^= (tail & 0xFF) * P5; h = rotl64(h, 11) * P1; tail >>= 8; }
+    } else {
+        if (q + 4 <= len) { h ^= rd32(q) * P1; h = rotl64(h, 23) * P2 + P3; q += 4; }
+        while (q < len) { h ^= (uint64_t)(FOLD ? ascii_lower1(p[q]) : (uint32_t)p[q]) * P5; h = rotl64(h, 11) * P1; ++q; }
+    }
     h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
     return h;
 }

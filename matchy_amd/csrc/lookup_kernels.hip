@@ -176,7 +176,9 @@ __device__ bool lit_lookup(const DevDb& db, const uint8_t* s0, uint32_t n0, uint
                     uint32_t b, k = 0;
                     while (ls.next(b)) { diff |= (uint64_t)(q[2 + k] ^ b); ++k; }
                 } else {
-                    // 8 bytes per step, no early exit: the loads are independent of each other
+                    // 8 bytes per step, no early exit: the loads are independent of each other; the last up to 7 bytes are
+                    // compared through one 8-byte pair that ends at the end of both strings (overlapping bytes compare equal
+                    // again) instead of a byte loop of dependent round trips
                     uint32_t k = 0;
                     for (; k + 8 <= n; k += 8) {
                         uint64_t x, y;
@@ -184,7 +186,16 @@ __device__ bool lit_lookup(const DevDb& db, const uint8_t* s0, uint32_t n0, uint
                         __builtin_memcpy(&y, s + k, 8);
                         diff |= x ^ (fold ? ascii_lower8(y) : y);
                     }
-                    for (; k < n; ++k) diff |= (uint64_t)(q[2 + k] ^ (fold ? ascii_lower1(s[k]) : (uint32_t)s[k]));
+                    if (k < n) {
+                        if (n >= 8) {
+                            uint64_t x, y;
+                            __builtin_memcpy(&x, q + 2 + n - 8, 8);
+                            __builtin_memcpy(&y, s + n - 8, 8);
+                            diff |= x ^ (fold ? ascii_lower8(y) : y);
+                        } else {
+                            for (; k < n; ++k) diff |= (uint64_t)(q[2 + k] ^ (fold ? ascii_lower1(s[k]) : (uint32_t)s[k]));
+                        }
+                    }
                 }
                 if (diff == 0) { pattern_id = e.pattern_id; return true; }
             }

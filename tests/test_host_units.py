@@ -40,3 +40,18 @@ def test_mutated_database_files_under_sanitizers(tmp_path):
     r = subprocess.run([str(exe), "4000", "7", *seeds], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.startswith("OK: 4000 mutated images")
+
+
+def test_xxh64_every_length_against_the_xxhash_module(tmp_path):
+    # hashes.h reads short keys and the last bytes of a key through overlapping 8-byte loads: every length 0..260, plain and with
+    # the ASCII case fold, against an implementation this repo did not write
+    import xxhash
+    out = _build_and_run("tests/cpp/dump_xxh64.cpp", tmp_path)
+    data = bytes((i * 131 + 7) & 0xFF for i in range(300))
+    lower = lambda x: bytes(c + 32 if 65 <= c <= 90 else c for c in x)
+    rows = [line.split() for line in out.splitlines()]
+    assert len(rows) == 261
+    for n, h, hf in rows:
+        n = int(n)
+        assert int(h, 16) == xxhash.xxh64(data[:n], seed=0).intdigest(), n
+        assert int(hf, 16) == xxhash.xxh64(lower(data[:n]), seed=0).intdigest(), n
