@@ -2,6 +2,7 @@
 path, and the BASELINE configs[1] workload at a size that exercises the > 1 GiB host path, checked against the oracle
 and through size-independent properties (idempotence, sharding invariance, additivity of the line count)."""
 import os
+from pathlib import Path
 
 import pytest
 
@@ -147,6 +148,41 @@ def test_headline_batch_as_one_launch(M, oracle, size):
     assert h1 + _rebased(h2, cut) == want
     sc.close(); db.close()
     hip.hipFree(dptr); hip.hipFree(d2)
+
+
+def test_single_stream_fallback_gives_the_same_records(M):
+    """MATCHY_AMD_NO_FORK=1 keeps the device-resident entry on the caller's stream (the scanner's two extra streams unused). The
+    switch is read once per process, so the single-stream scan runs in a child process (one at a time: the GPU box allows few
+    processes on the card) and hands back a digest of its records, as does a second child with the fork (test_scan_device_fetch_modes and the parity tests
+    hold the forked entry against the oracle)."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, hashlib, sys
+sys.path.insert(0, ".")
+import matchy_amd as M
+from tools import synth
+cfg = synth.config(sys.argv[1])
+db = M.Database(synth.build_db(cfg))
+log = synth.make_log(cfg, 0, 60000)
+sc = M.Scanner(db)
+hip = ctypes.CDLL("libamdhip64.so")
+d = ctypes.c_void_p()
+assert hip.hipMalloc(ctypes.byref(d), ctypes.c_size_t(len(log) + 64)) == 0
+assert hip.hipMemcpy(d, log, ctypes.c_size_t(len(log)), 1) == 0
+r = sc.scan_device(d.value, len(log), fetch_mode=3)
+print(hashlib.sha256(repr((r.lines, r.candidates, r.hits())).encode()).hexdigest())
+'''
+    root = Path(__file__).resolve().parent.parent
+    for cfgname in ("c2/10", "c4/10"):
+        digests = []
+        for env_extra in ({}, {"MATCHY_AMD_NO_FORK": "1"}):
+            env = {k: v for k, v in os.environ.items() if k != "MATCHY_AMD_NO_FORK"}
+            env.update(env_extra)
+            out = subprocess.run([sys.executable, "-c", code, cfgname], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0, out.stderr[-2000:]
+            digests.append(out.stdout.strip().splitlines()[-1])
+        assert digests[0] == digests[1]
 
 
 @pytest.mark.parametrize("cfgname,mirror", [("c4/10", "64"), ("c2/10", "64"), ("c2/10", "0")])
