@@ -436,16 +436,16 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.heavy = heavy_.p; tp.heavy_cap = (uint32_t)heavy_.n;
     tp.dom_list = dom_list_.p; tp.dom_cap = (uint32_t)dom_slots_;
     tp.counters = counters_.p;
-    // workgroups per CU for k_anchor / k_validate / k_lookup: what is resident at once (grid-stride kernels; a
+    // workgroups per CU for k_anchor / k_validate_dom / k_lookup: what is resident at once (grid-stride kernels; a
     // larger grid only adds a partially filled second round). MATCHY_AMD_GRID=a,v,l overrides for experiments.
-    // k_anchor: one full round of resident workgroups; k_validate: one; k_lookup: 2 per CU measured best (every wave
-    // pads its last hit chunk, and more waves in flight only add contention on the random table accesses).
+    // k_anchor: one full round of resident workgroups; k_validate_dom: one; k_lookup: 2 per CU measured best (the string
+    // lookups are chains of dependent loads: more waves in flight only add contention on the random table accesses).
     static const int occ_a = anchor_blocks_per_cu(), occ_v = validate_blocks_per_cu(false), occ_v_ac = validate_blocks_per_cu(true);
-    int gm[4] = {occ_a, tp.filter_ac ? occ_v_ac : occ_v, 2, 2};
+    int gm[3] = {occ_a, tp.filter_ac ? occ_v_ac : occ_v, 2};
     if (const char* g = getenv("MATCHY_AMD_GRID")) {   // 0 keeps the default of that kernel
-        int o[4] = {0, 0, 0, 0};
-        (void)sscanf(g, "%d,%d,%d,%d", &o[0], &o[1], &o[2], &o[3]);
-        for (int k = 0; k < 4; ++k) if (o[k] > 0) gm[k] = o[k];
+        int o[3] = {0, 0, 0};
+        (void)sscanf(g, "%d,%d,%d", &o[0], &o[1], &o[2]);
+        for (int k = 0; k < 3; ++k) if (o[k] > 0) gm[k] = o[k];
     }
     for (int& m : gm) m = std::max(1, std::min(m, 64));
     {
