@@ -144,8 +144,8 @@ def run_strong(args, rank, local_rank, world, rehearse, torch, dist, dev, coll_d
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)   # a step is ~1.2 ms: 50 of them keep one slow step (host jitter) out of the average
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--lines", type=int, default=10_000_000, help="log lines per GPU (BASELINE config: 10M)")
     ap.add_argument("--config", default="c2", help="indicator mix (tools/synth.py): c2 = 100K mixed IoCs")
     ap.add_argument("--cpu-lines", type=int, default=3_000_000, help="lines of the same log timed on the CPU oracle (rank 0, N=1)")
