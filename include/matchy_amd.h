@@ -280,7 +280,8 @@ void matchy_scan_result_free(matchy_scan_result_t *result);
 char *matchy_scan_hit_to_json(const matchy_scanner_t *scanner, const matchy_scan_result_t *result, size_t i,
                               const uint8_t *text, const char *source);
 /* Per-kernel HIP-event timing of the last scan (recorded on the scan's stream):
- * out[0..4] = k_anchor, k_validate_dom + k_validate, k_rare, k_lookup (incl. writing the hit records), total (milliseconds). */
+ * out[0..4] = k_anchor, k_validate_dom + k_validate, k_rare, k_lookup (incl. writing the hit records), total (milliseconds).
+ * matchy_scanner_scan_device runs the kernels behind k_anchor on three streams: then out[1] is that whole tail and out[2] = out[3] = 0. */
 void matchy_scanner_set_profile(matchy_scanner_t *scanner, bool enabled);
 void matchy_scanner_get_timing(const matchy_scanner_t *scanner, float out_ms[5]);
 /* Last error message of the calling thread ("" if none). */

@@ -414,6 +414,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     MXY_HIP(hipSetDevice(ddb_->device));
     ensure_capacity(len);
     last_ptr_ = dptr; last_len_ = len; last_lookup_ = lookup; last_mirror_ = host_mirror; last_fork_ = fork;
+    last_forked_ = false;
     MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters), stream));
     TokParams tp{};
     tp.log = dptr; tp.len = len; tp.flags = flags_; tp.min_labels = min_labels_;
@@ -508,6 +509,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     // MATCHY_AMD_NO_FORK=1 keeps everything on one stream.
     static const bool env_no_fork = getenv("MATCHY_AMD_NO_FORK") != nullptr;
     const bool no_fork = env_no_fork || !fork;
+    last_forked_ = !no_fork;
     LookupParams la = lp;
     static const int ip_wgs = getenv("MATCHY_AMD_IPGRID") ? atoi(getenv("MATCHY_AMD_IPGRID")) : 0;
     // one workgroup on every other CU: enough lanes to keep the result traffic on the bus, and the validation kernels beside it
@@ -542,9 +544,9 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         TokParams t2 = tp;
         t2.vmode = 2u;
         launch_validate_misc(t2, ddb_->view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
-        if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
+        // no timing events inside the forked tail: every packet between two kernels of the chain is ~6-8 us of it, and with
+        // kernels running side by side the intervals would not be kernel times anyway (ScanTiming: validate_ms = the whole tail)
         MXY_HIP(hipStreamWaitEvent(stream, ev_join2_, 0));
-        if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
     } else {
         launch_validate_dom(tp, ddb_->view, n_cu_ * gm[1], stream);
         launch_validate_misc(tp, ddb_->view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);   // vmode 3: every list
@@ -619,9 +621,14 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     out.n_hits = !last_lookup_ ? 0 : (single_ ? c.hits_true : c.n_final);
     if (profile_) {
         MXY_HIP(hipEventElapsedTime(&timing_.anchor_ms, ev_[0], ev_[1]));
-        MXY_HIP(hipEventElapsedTime(&timing_.validate_ms, ev_[1], ev_[2]));
-        MXY_HIP(hipEventElapsedTime(&timing_.rare_ms, ev_[2], ev_[3]));
-        MXY_HIP(hipEventElapsedTime(&timing_.lookup_ms, ev_[3], ev_[4]));
+        if (last_forked_) {   // one interval for everything behind k_anchor (kernels on three streams)
+            MXY_HIP(hipEventElapsedTime(&timing_.validate_ms, ev_[1], ev_[4]));
+            timing_.rare_ms = 0; timing_.lookup_ms = 0;
+        } else {
+            MXY_HIP(hipEventElapsedTime(&timing_.validate_ms, ev_[1], ev_[2]));
+            MXY_HIP(hipEventElapsedTime(&timing_.rare_ms, ev_[2], ev_[3]));
+            MXY_HIP(hipEventElapsedTime(&timing_.lookup_ms, ev_[3], ev_[4]));
+        }
         MXY_HIP(hipEventElapsedTime(&timing_.total_ms, ev_[0], ev_[4]));
     }
     out.hits.clear(); out.ids.clear(); out.cands.clear();

@@ -79,7 +79,9 @@ struct DeviceDb {
     void upload(const DbImage& img, int dev);
 };
 
-struct ScanTiming { float anchor_ms = 0, validate_ms = 0, rare_ms = 0, lookup_ms = 0, total_ms = 0; };  // lookup includes the record packing
+// HIP-event intervals of the last scan. One stream: k_anchor | k_validate_dom + k_validate | k_rare | lookups incl. record packing.
+// Forked scan (three streams): anchor_ms as before, validate_ms = everything behind k_anchor, rare_ms = lookup_ms = 0.
+struct ScanTiming { float anchor_ms = 0, validate_ms = 0, rare_ms = 0, lookup_ms = 0, total_ms = 0; };
 
 enum HitMode { HITS_NONE = 0, HITS_FINAL = 1, HITS_RAW = 2 };
 
@@ -172,7 +174,7 @@ private:
     ScanCounters host_counters_{};
     uint32_t last_len_ = 0;
     const uint8_t* last_ptr_ = nullptr;
-    bool last_lookup_ = false, last_fork_ = false;
+    bool last_lookup_ = false, last_fork_ = false, last_forked_ = false;
     bool single_ = false;
     bool profile_ = false;
     hipEvent_t ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
