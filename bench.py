@@ -141,6 +141,39 @@ def run_strong(args, rank, local_rank, world, rehearse, torch, dist, dev, coll_d
     scanner.close()
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a child (rendezvous on 127.0.0.1, a free port) and return its exit status. Rank 0's JSON line reaches stdout
+    through the inherited descriptors. Reference: the worker fan-out of crates/matchy/src/processing/parallel.rs:594-704."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd).returncode
+
+
+def dry_run(args, rank, world):
+    """BENCH_DRYRUN=1: the launch plumbing without a GPU (CPU test of `--gpus N`): rendezvous over gloo, the barrier and the
+    reduction bench.py uses, one JSON line from rank 0 with `value` null. Measures nothing."""
+    import torch
+    import torch.distributed as dist
+    from matchy_amd import sharding
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    sharding.barrier(dist, world)
+    blk = sharding.block_for_rank(rank, world, args.lines)
+    agg = sharding.aggregate(dist, world, torch.device("cpu"), 1.0, 0, blk.n_lines, 0, 0)
+    if rank == 0:
+        print(json.dumps({"metric": "log GB/s scanned (matchy match hot path, 100K IoCs)", "value": None, "unit": "GB/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "lines": agg["lines"]}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,7 +191,7 @@ def main():
     ap.add_argument("--extract-flags", type=int, default=0, help="diagnostics only: MATCHY_EXTRACT_* bit mask (0 = what the DB needs)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="strong: --lines is the size of ONE job that is cut across the GPUs "
                     "(default 100 M lines of --config c4 = BASELINE configs[3])")
-    ap.add_argument("--batch-lines", type=int, default=5_000_000, help="strong scaling: lines per batch (a batch must stay below 2 GiB)")
+    ap.add_argument("--batch-lines", type=int, default=10_000_000, help="strong scaling: lines per batch (a batch must stay below 2 GiB; the default is the weak line's batch)")
     ap.add_argument("--e2e-batches", type=int, default=4, help="strong scaling: batches per rank kept in pinned host memory for the end-to-end measurement")
     args = ap.parse_args()
     if args.scaling == "strong":
@@ -166,6 +199,17 @@ def main():
             args.lines = 100_000_000
         if "--config" not in " ".join(sys.argv):
             args.config = "c4"
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    # --gpus N is what runs. Started by torch.distributed.run (WORLD_SIZE set): the launcher's world must be N. Started
+    # directly with N > 1: this process becomes the launcher — one rank per GPU as a CHILD process tree, started before
+    # anything here has imported torch or touched HIP — and relays the ranks' output and exit status.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -177,9 +221,14 @@ def main():
         local_rank = 0
     os.environ["MATCHY_AMD_DEVICE"] = str(local_rank)
 
+    if os.environ.get("BENCH_DRYRUN") == "1":
+        return dry_run(args, rank, world)
+
     import torch
     import torch.distributed as dist
 
+    if not rehearse and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) are visible")
     if world > 1:
         if rehearse:
             dist.init_process_group(backend="gloo")

@@ -128,3 +128,27 @@ def test_world_size_2_gloo(oracle, tmp_path):
     assert agg["hits"] == whole["hits"] and agg["hits"] > 0
     assert agg["candidates"] == whole["candidates"]
     assert agg["elapsed_s"] >= rep["own_elapsed"] - 1e-9  # MAX over ranks
+
+
+def _bench(args, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env)
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_bench_gpus_flag_is_what_runs():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (child torch.distributed.run, gloo here) and
+    reports n_gpus = 2; a launcher whose world differs from --gpus is refused; without enough devices it fails loudly."""
+    r = _bench(["--gpus", "2", "--steps", "3", "--lines", "1000"], BENCH_DRYRUN="1", OMP_NUM_THREADS="1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["lines"] == 2000 and line["dry_run"] is True
+    r = _bench(["--gpus", "4"], WORLD_SIZE="2", RANK="0", BENCH_DRYRUN="1")
+    assert r.returncode != 0 and "--gpus 4" in r.stderr
+    # no GPU in the CPU container: the real path must refuse instead of printing a line for fewer devices than asked for
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = _bench(["--gpus", "2", "--steps", "1"], OMP_NUM_THREADS="1")
+        assert r.returncode != 0
+        assert "device(s) are visible" in r.stderr
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
