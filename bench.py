@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--pipelined", type=int, default=0, help="N > 1: after the timed steps, time the same K steps again with N batches in flight per GPU "
                     "(scanners on their own streams) and report it as the extra object `pipelined`. Off by default so that a profile "
                     "of the default command shows every kernel running alone")
+    ap.add_argument("--slices", type=int, default=0, help="matchy_scanner_set_slices: 0 = the library's default for the batch size, 1 = one launch of every "
+                    "kernel over the whole batch, n = n equal slices")
     ap.add_argument("--extract-flags", type=int, default=0, help="diagnostics only: MATCHY_EXTRACT_* bit mask (0 = what the DB needs)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="strong: --lines is the size of ONE job that is cut across the GPUs "
                     "(default 100 M lines of --config c4 = BASELINE configs[3])")
@@ -256,6 +258,8 @@ def main():
         cfg_note += " (case-insensitive database)"
     db = M.Database(blob)
     scanner = M.Scanner(db, extract_flags=args.extract_flags, device=local_rank, profile=True)
+    if args.slices:
+        scanner.set_slices(args.slices)
 
     # ---- synthetic batch: this rank's line block, generated on the host, uploaded once
     first_line = sharding.block_for_rank(rank, world, args.lines).first_line
@@ -332,6 +336,7 @@ def main():
             print(f"step {1e3 * (time.perf_counter() - ts0):.3f} ms", file=sys.stderr)
         t = scanner.timing_ms()
         tok_ms.append(t["anchor"]); look_ms.append(t["lookup"]); rare_ms.append(t["rare"]); val_ms.append(t["validate"])
+    scanner.last_slices_timed = scanner.last_slices()
     barrier()
     elapsed = time.perf_counter() - t0
     agg = sharding.aggregate(dist, world, coll_dev, elapsed, nbytes, counts[0], counts[2], counts[1])
@@ -346,7 +351,6 @@ def main():
     def step_dev():
         res = scanner.scan_device(dlog.data_ptr(), nbytes, stream=stream, fetch_mode=4)
         out = (res.lines, res.candidates, res.n_hits)
-        res._raw.hits = None
         res.close()
         return out
     for _ in range(2):
@@ -503,6 +507,7 @@ def main():
             "lines_per_s": round(total_lines / (elapsed / args.steps), 1),
             "candidates_per_step": agg["candidates"],
             "hits_per_step": agg["hits"],
+            "slices": scanner.last_slices_timed,
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "kernel_ms_note": "HIP-event intervals on the scan's stream: k_anchor alone, then everything behind it as one interval (three streams: "
                               "k_validate_dom -> k_validate -> k_lookup, with k_lookup_ip and k_validate / k_rare beside them); per-kernel durations are in "

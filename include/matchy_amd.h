@@ -275,6 +275,9 @@ int32_t matchy_scanner_submit_device(matchy_scanner_t *scanner, const void *devi
                                      uint32_t fetch_mode);
 int32_t matchy_scanner_wait(matchy_scanner_t *scanner, matchy_scan_result_t *out);
 void matchy_scan_result_free(matchy_scan_result_t *result);
+/* true for a result of fetch_mode MATCHY_SCAN_FETCH_DEVICE: hits / pattern_ids / data_offsets are DEVICE pointers and must not be
+ * dereferenced on the host (matchy_scan_hit_to_json returns NULL for such a result). */
+bool matchy_scan_result_on_device(const matchy_scan_result_t *result);
 /* The NDJSON record `matchy match` prints for hit i (match_processor/parallel.rs:297-369). `text` points at the
  * scanned bytes on the host. Returned string: matchy_free_string(). */
 char *matchy_scan_hit_to_json(const matchy_scanner_t *scanner, const matchy_scan_result_t *result, size_t i,
@@ -283,6 +286,11 @@ char *matchy_scan_hit_to_json(const matchy_scanner_t *scanner, const matchy_scan
  * out[0..4] = k_anchor, k_validate_dom + k_validate, k_rare, k_lookup (incl. writing the hit records), total (milliseconds).
  * matchy_scanner_scan_device runs the kernels behind k_anchor on three streams: then out[1] is that whole tail and out[2] = out[3] = 0. */
 void matchy_scanner_set_profile(matchy_scanner_t *scanner, bool enabled);
+/* matchy_scanner_scan_device cuts a large batch into slices and runs the kernels behind the streaming pass of one slice beside
+ * the streaming pass of the next (results do not depend on it: N4 of the design notes, positions stay absolute). 0 = default for
+ * the batch size, 1 = never cut, n = n equal slices (at most 8). matchy_scanner_last_slices: what the last scan used. */
+void matchy_scanner_set_slices(matchy_scanner_t *scanner, int32_t slices);
+int32_t matchy_scanner_last_slices(const matchy_scanner_t *scanner);
 void matchy_scanner_get_timing(const matchy_scanner_t *scanner, float out_ms[5]);
 /* Last error message of the calling thread ("" if none). */
 /* `matchy query DB QUERY` (bin/commands/query_cmd.rs:8-69) as one call: compact JSON array — one object per matching

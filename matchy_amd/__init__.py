@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "matchy_get_stats", "matchy_clear_cache", "matchy_has_pattern_data", "matchy_result_get_entry", "matchy_aget_value",
     "matchy_get_entry_data_list", "matchy_free_entry_data_list", "matchy_validate", "matchy_builder_set_schema",
     "matchy_amd_query_json", "matchy_amd_extractor_create", "matchy_amd_device_count", "matchy_scanner_submit_device",
-    "matchy_scanner_wait",
+    "matchy_scanner_wait", "matchy_scanner_set_slices", "matchy_scanner_last_slices", "matchy_scan_result_on_device",
 ]
 
 
@@ -147,6 +147,9 @@ def lib():
         "matchy_scan_result_free": (None, [C.POINTER(_ScanResult)]),
         "matchy_scan_hit_to_json": (vp, [vp, C.POINTER(_ScanResult), C.c_size_t, cp, cp]),
         "matchy_scanner_set_profile": (None, [vp, C.c_bool]),
+        "matchy_scanner_set_slices": (None, [vp, C.c_int32]),
+        "matchy_scanner_last_slices": (C.c_int32, [vp]),
+        "matchy_scan_result_on_device": (C.c_bool, [C.POINTER(_ScanResult)]),
         "matchy_scanner_get_timing": (None, [vp, C.POINTER(C.c_float)]),
         "matchy_amd_last_error": (cp, []),
         "matchy_get_stats": (None, [vp, C.POINTER(_Stats)]),
@@ -385,6 +388,7 @@ class ScanResult:
         self.candidates = raw.candidates
         self.bytes = raw.bytes
         self.n_hits = raw.n_hits
+        self.on_device = bool(lib().matchy_scan_result_on_device(C.byref(raw)))   # fetch_mode 4: device pointers
 
     def hits(self):
         """list of dict(start,end,type,kind,prefix_len,ip_data_offset,ids,offs) in canonical order."""
@@ -392,6 +396,8 @@ class ScanResult:
         out = []
         if not r.hits:
             return out
+        if self.on_device:
+            raise RuntimeError("the hit records of this result are in device memory (fetch_mode 4): read them on the GPU")
         for i in range(r.n_hits):
             h = r.hits[i]
             ids = [r.pattern_ids[h.value + k] for k in range(h.n_ids)] if h.kind == 3 else []
@@ -403,6 +409,8 @@ class ScanResult:
 
     def ndjson(self, text: bytes, source="-"):
         L = lib()
+        if self.on_device:
+            raise RuntimeError("the hit records of this result are in device memory (fetch_mode 4): read them on the GPU")
         return [_take_string(L.matchy_scan_hit_to_json(self._scanner._h, C.byref(self._raw), i, text, source.encode()))
                 for i in range(self._raw.n_hits)] if self._raw.hits else []
 
@@ -445,7 +453,9 @@ class Scanner:
         return ScanResult(self, raw)
 
     def scan_device(self, device_ptr: int, nbytes: int, stream: int = 0, fetch_mode=1) -> ScanResult:
-        """fetch_mode: 0 counters only, 1 hit records in device order, 3 hit records in canonical order."""
+        """fetch_mode: 0 counters only, 1 hit records in device order (borrowed from the scanner's pinned buffers), 3 hit records
+        in canonical order (owned copy), 4 the records stay in device memory (result.on_device: `_raw.hits` / `pattern_ids` /
+        `data_offsets` are device addresses; hits() raises)."""
         raw = _ScanResult()
         rc = lib().matchy_scanner_scan_device(self._h, device_ptr, nbytes, stream, fetch_mode, C.byref(raw))
         if rc != 0:
@@ -463,6 +473,13 @@ class Scanner:
         if rc != 0:
             raise RuntimeError(f"matchy_scanner_wait failed: rc={rc} {last_error()}")
         return ScanResult(self, raw)
+
+    def set_slices(self, n: int):
+        """scan_device cuts large batches into slices (tail of one slice beside the streaming pass of the next): 0 = default, 1 = never, n = n equal slices."""
+        lib().matchy_scanner_set_slices(self._h, n)
+
+    def last_slices(self) -> int:
+        return lib().matchy_scanner_last_slices(self._h)
 
     def timing_ms(self):
         out = (C.c_float * 5)()

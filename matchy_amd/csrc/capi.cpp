@@ -102,6 +102,7 @@ struct ScanResultInternal {
     std::vector<matchy_scan_hit_t> hits;
     std::vector<uint32_t> ids;
     std::vector<int64_t> offs;
+    bool on_device = false;   // MATCHY_SCAN_FETCH_DEVICE: the result's arrays are device pointers
 };
 
 int type_rank(uint32_t t) {  // chunk-path extractor order (matchy-extractor/src/lib.rs:449-485)
@@ -207,6 +208,9 @@ void fill_device_result(Scanner& sc, const ScanOutput& so, uint64_t bytes, match
     out->hits = reinterpret_cast<const matchy_scan_hit_t*>(sc.device_final());
     out->pattern_ids = sc.device_final_ids();
     out->data_offsets = reinterpret_cast<const int64_t*>(sc.device_final_offs());
+    auto* in = new ScanResultInternal();   // marks the residency: host-side readers of the result refuse device pointers
+    in->on_device = true;
+    out->_internal = in;
 }
 
 }  // namespace
@@ -694,6 +698,8 @@ matchy_scanner_t* matchy_scanner_create(const matchy_t* dbc, uint32_t extract_fl
 }
 void matchy_scanner_free(matchy_scanner_t* s) { delete reinterpret_cast<ScannerH*>(s); }
 void matchy_scanner_set_profile(matchy_scanner_t* s, bool on) { if (s) reinterpret_cast<ScannerH*>(s)->sc->set_profile(on); }
+void matchy_scanner_set_slices(matchy_scanner_t* s, int32_t n) { if (s) reinterpret_cast<ScannerH*>(s)->sc->set_slices(n); }
+int32_t matchy_scanner_last_slices(const matchy_scanner_t* s) { return s ? reinterpret_cast<const ScannerH*>(s)->sc->last_slice_count() : 0; }
 void matchy_scanner_get_timing(const matchy_scanner_t* s, float out[5]) {
     if (!s || !out) return;
     const ScanTiming& t = reinterpret_cast<const ScannerH*>(s)->sc->timing();
@@ -722,7 +728,7 @@ int32_t matchy_scanner_scan_device(matchy_scanner_t* s, const void* dptr, size_t
     try {
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         const bool sorted = (fetch_mode & 2) != 0;
-        h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st, (fetch_mode & 1) && !sorted, /*fork=*/true);
+        h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st, (fetch_mode & 1) && !sorted, /*fork=*/true, h->sc->slices());
         ScanOutput so;
         h->sc->fetch(so, false, st, (fetch_mode & 1) ? HITS_FINAL : HITS_NONE, sorted);
         if (fetch_mode == MATCHY_SCAN_FETCH_DEVICE) { fill_device_result(*h->sc, so, len, out); return MATCHY_SUCCESS; }
@@ -773,8 +779,13 @@ void matchy_scan_result_free(matchy_scan_result_t* r) {
     memset(r, 0, sizeof(*r));
 }
 
+bool matchy_scan_result_on_device(const matchy_scan_result_t* r) {
+    return r && r->_internal && reinterpret_cast<const ScanResultInternal*>(r->_internal)->on_device;
+}
+
 char* matchy_scan_hit_to_json(const matchy_scanner_t* s, const matchy_scan_result_t* r, size_t i, const uint8_t* text, const char* source) {
     if (!s || !r || !text || i >= r->n_hits || !r->hits) return nullptr;
+    if (matchy_scan_result_on_device(r)) { set_error("matchy_scan_hit_to_json: the records of this result are in device memory (MATCHY_SCAN_FETCH_DEVICE)"); return nullptr; }
     const DbImage& img = reinterpret_cast<const ScannerH*>(s)->sc->image();
     const matchy_scan_hit_t& h = r->hits[i];
     const uint32_t hlen = MATCHY_SCAN_HIT_LEN(h);

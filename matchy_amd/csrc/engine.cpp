@@ -15,6 +15,11 @@
 
 namespace mxy {
 
+void check_launch(const char* kernel) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw HipError{std::string("launch of ") + kernel + ": " + hipGetErrorString(e)};
+}
+
 // ------------------------------------------------------------------------------------------------ PSL
 namespace {
 
@@ -363,7 +368,8 @@ Scanner::Scanner(std::shared_ptr<const DbImage> img, std::shared_ptr<DeviceDb> d
     hipDeviceProp_t prop;
     MXY_HIP(hipGetDeviceProperties(&prop, ddb_->device));
     n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    counters_.alloc(1);
+    counters_.alloc(MAX_SLICES);
+    MXY_HIP(hipHostMalloc((void**)&host_slices_, sizeof(ScanCounters) * MAX_SLICES, hipHostMallocDefault));
     for (auto& e : ev_) MXY_HIP(hipEventCreate(&e));
     MXY_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     MXY_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
@@ -375,29 +381,46 @@ Scanner::Scanner(std::shared_ptr<const DbImage> img, std::shared_ptr<DeviceDb> d
 Scanner::~Scanner() {
     if (pinned_) (void)hipHostFree(pinned_);
     if (mirror_) (void)hipHostFree(mirror_);
+    if (host_slices_) (void)hipHostFree(host_slices_);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_anchor_) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_misc_) if (e) (void)hipEventDestroy(e);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
     if (ev_join2_) (void)hipEventDestroy(ev_join2_);
+    if (ev_join3_) (void)hipEventDestroy(ev_join3_);
     if (aux2_stream_) (void)hipStreamDestroy(aux2_stream_);
+    if (dom_stream_) (void)hipStreamDestroy(dom_stream_);
     if (host_stream_) (void)hipStreamDestroy(host_stream_);
 }
 
-void Scanner::ensure_capacity(uint32_t len) {
-    size_t want_c = std::max<size_t>(4096, (size_t)len / 24);
-    size_t want_r = std::max<size_t>(1024, (size_t)len / 256);
-    if (cands_.n < want_c) { cands_.alloc(want_c); hits_.alloc(std::max<size_t>(1024, want_c / 4)); ids_.alloc(std::max<size_t>(1024, want_c / 4)); }
-    if (cands_a_.n < want_c) cands_a_.alloc(want_c);
-    if (rare_.n < want_r) rare_.alloc(want_r);
-    if (rare_dom_.n < want_r) rare_dom_.alloc(want_r);
-    if (tok_.n < want_r) tok_.alloc(want_r);
-    if (heavy_.n < want_r) heavy_.alloc(want_r);
-    if (final_.n < hits_.n) { final_.alloc(hits_.n); }
-    if (final_ids_.n < hits_.n + ids_.n) { final_ids_.alloc(hits_.n + ids_.n); final_offs_.alloc(hits_.n + ids_.n); }
+// work lists of one slice for `len` bytes of log
+void Scanner::Work::ensure(uint32_t len) {
+    const size_t want_c = std::max<size_t>(4096, (size_t)len / 24);
+    const size_t want_r = std::max<size_t>(1024, (size_t)len / 256);
+    const size_t want_h = std::max<size_t>(1024, want_c / 4);
+    if (cands.n < want_c) cands.alloc(want_c);
+    if (hits.n < want_h) hits.alloc(want_h);
+    if (ids.n < want_h) ids.alloc(want_h);
+    if (cands_a.n < want_c) cands_a.alloc(want_c);
+    if (rare.n < want_r) rare.alloc(want_r);
+    if (rare_dom.n < want_r) rare_dom.alloc(want_r);
+    if (tok.n < want_r) tok.alloc(want_r);
+    if (heavy.n < want_r) heavy.alloc(want_r);
     // domain anchor list: slots of DOM_PLANES dwords, whole 1024-slot chunks (see TokParams::dom_list)
     const size_t want_d = ((std::max<size_t>(8192, (size_t)len / 96) + ANCHOR_CHUNK - 1) / ANCHOR_CHUNK) * ANCHOR_CHUNK;
-    if (dom_slots_ < want_d) { dom_list_.alloc(want_d * DOM_PLANES); dom_slots_ = want_d; }
+    if (dom_slots < want_d) { dom_list.alloc(want_d * DOM_PLANES); dom_slots = want_d; }
+}
+
+void Scanner::ensure_final(size_t recs, size_t ids) {
+    if (final_.n < recs) final_.alloc(recs);
+    if (final_ids_.n < recs + ids) { final_ids_.alloc(recs + ids); final_offs_.alloc(recs + ids); }
+}
+
+void Scanner::ensure_capacity(uint32_t len) {
+    work_[0].ensure(len);
+    ensure_final(work_[0].hits.n, work_[0].ids.n);
 }
 
 void Scanner::ensure_mirror(uint32_t recs, uint32_t ids) {
@@ -408,15 +431,31 @@ void Scanner::ensure_mirror(uint32_t recs, uint32_t ids) {
     MXY_HIP(hipHostMalloc(&mirror_, bytes, hipHostMallocDefault));
 }
 
-void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror, bool fork) {
-    if (len >= 0x7FFF0000u) throw HipError{"scan_device: chunk too large (must be < 2^31 bytes)"};
-    if (((uintptr_t)dptr & 15) != 0) throw HipError{"scan_device: device pointer must be 16-byte aligned"};
-    MXY_HIP(hipSetDevice(ddb_->device));
-    ensure_capacity(len);
-    last_ptr_ = dptr; last_len_ = len; last_lookup_ = lookup; last_mirror_ = host_mirror; last_fork_ = fork;
-    last_forked_ = false;
-    MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters), stream));
-    TokParams tp{};
+namespace {
+// grid multipliers (workgroups per CU) of k_anchor / k_validate_dom / k_lookup: what is resident at once (grid-stride kernels; a
+// larger grid only adds a partially filled second round). MATCHY_AMD_GRID=a,v,l overrides for experiments.
+// k_anchor: one full round of resident workgroups; k_validate_dom: one; k_lookup: 2 per CU measured best (the string
+// lookups are chains of dependent loads: more waves in flight only add contention on the random table accesses).
+void grid_multipliers(bool filter_ac, int (&gm)[3]) {
+    static const int occ_a = anchor_blocks_per_cu(), occ_v = validate_blocks_per_cu(false), occ_v_ac = validate_blocks_per_cu(true);
+    gm[0] = occ_a; gm[1] = filter_ac ? occ_v_ac : occ_v; gm[2] = 2;
+    if (const char* g = getenv("MATCHY_AMD_GRID")) {   // 0 keeps the default of that kernel
+        int o[3] = {0, 0, 0};
+        (void)sscanf(g, "%d,%d,%d", &o[0], &o[1], &o[2]);
+        for (int k = 0; k < 3; ++k) if (o[k] > 0) gm[k] = o[k];
+    }
+    for (int& m : gm) m = std::max(1, std::min(m, 64));
+}
+}  // namespace
+
+// Kernel parameters of slice `sl` for the byte range [lo, hi) of the batch (hi = len + 1 for the range that ends the batch).
+// The lists and counters are the slice's own; the final record arrays (and the counters that hand out their slots: slice 0's)
+// are shared by all slices.
+void Scanner::slice_params(int sl, const uint8_t* dptr, uint32_t len, uint32_t lo, uint32_t hi, bool lookup, bool host_mirror, SliceLaunch& L) {
+    Work& w = work_[sl];
+    ScanCounters* ctr = counters_.p + sl;
+    TokParams& tp = L.tp;
+    tp = TokParams{};
     tp.log = dptr; tp.len = len; tp.flags = flags_; tp.min_labels = min_labels_;
     tp.filter_v4 = lookup ? 1u : 0u;
     // without a glob section a string candidate can only hit through the literal table
@@ -426,78 +465,209 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     tp.filter_ac = (lookup && ac_ok) ? 1u : 0u;
     tp.filter_lit = (lookup && (!ddb_->view.has_glob || ac_ok)) ? 1u : 0u;
     if (const char* dbg = getenv("MATCHY_AMD_DEBUG")) tp.debug = (uint32_t)atoi(dbg);
-    tp.cands = cands_.p; tp.cand_cap = (uint32_t)cands_.n;
-    tp.cands_a = cands_a_.p; tp.cand_a_cap = (uint32_t)cands_a_.n;
+    tp.cands = w.cands.p; tp.cand_cap = (uint32_t)w.cands.n;
+    tp.cands_a = w.cands_a.p; tp.cand_a_cap = (uint32_t)w.cands_a.n;
     // IPv4 candidates are listed sparsely when the /24 bitmap of the database filters most of the address space
     tp.cand_chunk = (lookup && ddb_->view.ip_bm24_permille <= 250) ? 64u : 1024u;
-    tp.rare = rare_.p; tp.rare_cap = (uint32_t)rare_.n;
-    tp.rare_dom = rare_dom_.p; tp.rare_dom_cap = (uint32_t)rare_dom_.n;
+    tp.rare = w.rare.p; tp.rare_cap = (uint32_t)w.rare.n;
+    tp.rare_dom = w.rare_dom.p; tp.rare_dom_cap = (uint32_t)w.rare_dom.n;
     tp.vmode = 3u;
-    tp.tok = tok_.p; tp.tok_cap = (uint32_t)tok_.n;
-    tp.heavy = heavy_.p; tp.heavy_cap = (uint32_t)heavy_.n;
-    tp.dom_list = dom_list_.p; tp.dom_cap = (uint32_t)dom_slots_;
-    tp.counters = counters_.p;
-    // workgroups per CU for k_anchor / k_validate_dom / k_lookup: what is resident at once (grid-stride kernels; a
-    // larger grid only adds a partially filled second round). MATCHY_AMD_GRID=a,v,l overrides for experiments.
-    // k_anchor: one full round of resident workgroups; k_validate_dom: one; k_lookup: 2 per CU measured best (the string
-    // lookups are chains of dependent loads: more waves in flight only add contention on the random table accesses).
-    static const int occ_a = anchor_blocks_per_cu(), occ_v = validate_blocks_per_cu(false), occ_v_ac = validate_blocks_per_cu(true);
-    int gm[3] = {occ_a, tp.filter_ac ? occ_v_ac : occ_v, 2};
-    if (const char* g = getenv("MATCHY_AMD_GRID")) {   // 0 keeps the default of that kernel
-        int o[3] = {0, 0, 0};
-        (void)sscanf(g, "%d,%d,%d", &o[0], &o[1], &o[2]);
-        for (int k = 0; k < 3; ++k) if (o[k] > 0) gm[k] = o[k];
-    }
-    for (int& m : gm) m = std::max(1, std::min(m, 64));
+    tp.tok = w.tok.p; tp.tok_cap = (uint32_t)w.tok.n;
+    tp.heavy = w.heavy.p; tp.heavy_cap = (uint32_t)w.heavy.n;
+    tp.dom_list = w.dom_list.p; tp.dom_cap = (uint32_t)w.dom_slots;
+    tp.counters = ctr;
+    grid_multipliers(tp.filter_ac != 0, L.gm);
     {
         // k_anchor: one round of resident workgroups and ONE segment per wave, all of the same size — the segments are
         // handed out statically, so anything else leaves some waves with one segment more than the others (with three or
         // four segments per wave that was 19 % of the kernel), and every segment end flushes the wave's anchor rings.
-        // Short batches get SEG_MIN segments and fewer waves.
-        const uint64_t waves = (uint64_t)n_cu_ * gm[0] * 4;
-        uint64_t sb = (((uint64_t)len + 1 + waves - 1) / waves + SEG_ALIGN - 1) / SEG_ALIGN * SEG_ALIGN;
+        // Short ranges get SEG_MIN segments and fewer waves.
+        const uint64_t waves = (uint64_t)n_cu_ * L.gm[0] * 4;
+        const uint64_t span = (uint64_t)hi - lo;
+        uint64_t sb = ((span + waves - 1) / waves + SEG_ALIGN - 1) / SEG_ALIGN * SEG_ALIGN;
         if (const char* e = getenv("MATCHY_AMD_SEG_KB")) sb = (uint64_t)atoi(e) * 1024 / SEG_ALIGN * SEG_ALIGN;
         tp.seg_bytes = (uint32_t)std::min<uint64_t>(SEG_MAX, std::max<uint64_t>(SEG_MIN, sb));
-        tp.n_segs = (uint32_t)(((uint64_t)len + 1 + tp.seg_bytes - 1) / tp.seg_bytes);
+        tp.n_segs = (uint32_t)((span + tp.seg_bytes - 1) / tp.seg_bytes);
+        tp.seg_base = lo; tp.scan_end = hi;
     }
-    int grid_tok = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * gm[0]);
-    if (grid_tok < 1) grid_tok = 1;
-    // lookup parameters first: what they may allocate (mirror, glob work list) must not sit between the launches
-    LookupParams lp{};
+    L.grid_anchor = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * L.gm[0]);
+    if (L.grid_anchor < 1) L.grid_anchor = 1;
+    LookupParams& lp = L.lp;
+    lp = LookupParams{};
     if (lookup) {
-        lp.log = dptr; lp.len = len; lp.cands = cands_.p; lp.cand_cap = (uint32_t)cands_.n;
-        lp.hits = hits_.p; lp.hit_cap = (uint32_t)hits_.n; lp.ids = ids_.p; lp.ids_cap = (uint32_t)ids_.n;
+        lp.log = dptr; lp.len = len; lp.cands = w.cands.p; lp.cand_cap = (uint32_t)w.cands.n;
+        lp.hits = w.hits.p; lp.hit_cap = (uint32_t)w.hits.n; lp.ids = w.ids.p; lp.ids_cap = (uint32_t)w.ids.n;
         if (ddb_->view.has_glob) {
-            if (glob_work_.n < cands_.n / 8) glob_work_.alloc(cands_.n / 8);
-            lp.glob_work = glob_work_.p; lp.glob_work_cap = (uint32_t)glob_work_.n;
-            setup_spill(lp);
+            if (w.glob_work.n < w.cands.n / 8) w.glob_work.alloc(w.cands.n / 8);
+            lp.glob_work = w.glob_work.p; lp.glob_work_cap = (uint32_t)w.glob_work.n;
+            setup_spill(sl, lp);
         }
-        lp.counters = counters_.p;
+        lp.counters = ctr;
         PackParams pp{};
-        pp.hits = hits_.p; pp.hit_cap = (uint32_t)hits_.n; pp.ids = ids_.p; pp.ids_cap = (uint32_t)ids_.n;
+        pp.hits = w.hits.p; pp.hit_cap = (uint32_t)w.hits.n; pp.ids = w.ids.p; pp.ids_cap = (uint32_t)w.ids.n;
         pp.lit_offsets = ddb_->lit_offsets.p; pp.n_lit = ddb_->n_lit_offsets;
         pp.glob_offsets = ddb_->glob_offsets.p; pp.n_glob = ddb_->n_glob_offsets;
         pp.out = final_.p; pp.out_cap = (uint32_t)final_.n;
         pp.out_ids = final_ids_.p; pp.out_offs = final_offs_.p; pp.out_ids_cap = (uint32_t)final_ids_.n;
-        mirror_used_ = false;
         if (host_mirror) {
-            static const uint32_t mirror0 = getenv("MATCHY_AMD_MIRROR_RECS") ? (uint32_t)atoi(getenv("MATCHY_AMD_MIRROR_RECS")) : (1u << 20);
-            ensure_mirror(std::max(mirror0, 16u), std::max(mirror0 / 16, 16u));
             uint8_t* mb = (uint8_t*)mirror_;
             pp.host_out = (FinalHit*)mb; pp.host_cap = mirror_cap_;
             pp.host_ids = (uint32_t*)(mb + (size_t)mirror_cap_ * sizeof(FinalHit));
             pp.host_offs = (long long*)(mb + (size_t)mirror_cap_ * sizeof(FinalHit) + (((size_t)mirror_ids_cap_ * 4 + 7) & ~(size_t)7));
             pp.host_ids_cap = mirror_ids_cap_;
-            mirror_used_ = true;
         }
-        pp.counters = counters_.p;
+        pp.counters = counters_.p;   // n_final / n_final_ids of slice 0 hand out the slots of the shared record arrays
         // k_lookup writes the final records itself (the PCIe writes of the mirror overlap the lookups); only the
         // single-query path (lookup_one) reads the raw hit list
         lp.direct = 1u;
         lp.pk = pp;
     }
+    // a database without any IPv4 answer lists no IPv4 candidate (the /24 bitmap is empty): nothing to look up
+    L.ip_pass = lookup && (ddb_->view.ip_bm24_any || !tp.filter_v4);
+    L.la = lp;
+    if (L.ip_pass) {
+        L.la.cands = w.cands_a.p; L.la.cand_cap = (uint32_t)w.cands_a.n; L.la.n_in = &ctr->n_cand_a;
+        L.la.glob_work = nullptr; L.la.glob_work_cap = 0;
+    }
+    // one workgroup on every other CU: enough lanes to keep the result traffic on the bus, and the validation kernels beside it
+    // keep nearly all of their resident waves (128 / 256 / 512 workgroups measured 1.199 / 1.213 / 1.241 ms per headline batch)
+    // (dense lists — a database that answers most addresses, C5 — are latency-bound trie walks for every line: full grid)
+    static const int ip_wgs = getenv("MATCHY_AMD_IPGRID") ? atoi(getenv("MATCHY_AMD_IPGRID")) : 0;
+    L.ip_dense = tp.cand_chunk != 64u;
+    L.ip_grid = ip_wgs > 0 ? ip_wgs : L.ip_dense ? n_cu_ * L.gm[2] : std::max(1, n_cu_ / 2);
+}
+
+// How a device-resident batch of `len` bytes is cut into slices: cuts[0] = 0 < cuts[1] < ... < cuts[n] = len + 1, inner cuts on
+// multiples of one full round of k_anchor segments (waves x SEG_ALIGN bytes), so that every wave of a slice gets a segment of
+// the same size. MATCHY_AMD_SLICES = "n" (equal slices) or "a,b,c,..." (relative sizes) overrides the default.
+int Scanner::plan_slices(uint32_t len, int want, uint32_t (&cuts)[MAX_SLICES + 1]) {
+    int gm[3];
+    grid_multipliers(false, gm);
+    // an explicit slice count (matchy_scanner_set_slices: tests, experiments) is honoured down to SEG_ALIGN-sized slices
+    const uint64_t unit = want > 0 ? (uint64_t)SEG_ALIGN : (uint64_t)n_cu_ * gm[0] * 4 * SEG_ALIGN;
+    double share[MAX_SLICES];
+    int n = 0;
+    static const char* env = getenv("MATCHY_AMD_SLICES");
+    if (want > 0) {
+        n = std::min(want, (int)MAX_SLICES);
+        for (int k = 0; k < n; ++k) share[k] = 1.0;
+    } else if (env && *env) {
+        const char* q = env;
+        while (*q && n < MAX_SLICES) {
+            char* e = nullptr;
+            const double v = strtod(q, &e);
+            if (e == q) break;
+            share[n++] = v > 0 ? v : 1.0;
+            q = *e == ',' ? e + 1 : e;
+        }
+        if (n == 1) { n = std::max(1, std::min((int)share[0], (int)MAX_SLICES)); for (int k = 0; k < n; ++k) share[k] = 1.0; }
+    } else {
+        // default: later slices are smaller — only the tail of the LAST slice is not hidden by a following k_anchor
+        static const double dflt[4] = {4, 3, 2, 1};
+        n = (uint64_t)len >= 24 * unit ? 4 : 1;
+        for (int k = 0; k < n; ++k) share[k] = dflt[k];
+    }
+    // a slice wants at least two rounds of segments (an explicitly requested one: one segment)
+    n = (int)std::min<uint64_t>((uint64_t)std::max(n, 1), std::max<uint64_t>(1, ((uint64_t)len + 1) / (want > 0 ? unit : 2 * unit)));
+    double total = 0;
+    for (int k = 0; k < n; ++k) total += share[k];
+    cuts[0] = 0;
+    double acc = 0;
+    for (int k = 1; k < n; ++k) {
+        acc += share[k - 1];
+        uint64_t c = (uint64_t)((double)len * acc / total) / unit * unit;
+        c = std::max<uint64_t>(c, (uint64_t)cuts[k - 1] + unit);
+        cuts[k] = (uint32_t)c;
+    }
+    cuts[n] = len + 1;
+    for (int k = 1; k <= n; ++k) if (cuts[k] <= cuts[k - 1]) return (cuts[1] = len + 1, 1);   // degenerate: one slice
+    return n;
+}
+
+void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror, bool fork, int slices) {
+    if (len >= 0x7FFF0000u) throw HipError{"scan_device: chunk too large (must be < 2^31 bytes)"};
+    if (((uintptr_t)dptr & 15) != 0) throw HipError{"scan_device: device pointer must be 16-byte aligned"};
+    MXY_HIP(hipSetDevice(ddb_->device));
+    last_ptr_ = dptr; last_len_ = len; last_lookup_ = lookup; last_mirror_ = host_mirror; last_fork_ = fork; last_slices_ = slices;
+    last_forked_ = false;
+    spill_done_ = false;
+    // MATCHY_AMD_NO_FORK=1 keeps everything on one stream.
+    static const bool env_no_fork = getenv("MATCHY_AMD_NO_FORK") != nullptr;
+    const bool no_fork = env_no_fork || !fork;
+    uint32_t cuts[MAX_SLICES + 1] = {0, len + 1};
+    const int ns = (no_fork || !lookup) ? 1 : plan_slices(len, slices, cuts);
+    n_slices_ = ns;
+    // buffers first: what they may allocate (lists, mirror, glob work list) must not sit between the launches
+    if (ns == 1) ensure_capacity(len);
+    else {
+        size_t recs = 0, ids = 0;
+        for (int k = 0; k < ns; ++k) { work_[k].ensure(cuts[k + 1] - cuts[k]); recs += work_[k].hits.n; ids += work_[k].ids.n; }
+        ensure_final(recs, ids);
+    }
+    mirror_used_ = false;
+    if (lookup && host_mirror) {
+        static const uint32_t mirror0 = getenv("MATCHY_AMD_MIRROR_RECS") ? (uint32_t)atoi(getenv("MATCHY_AMD_MIRROR_RECS")) : (1u << 20);
+        ensure_mirror(std::max(mirror0, 16u), std::max(mirror0 / 16, 16u));
+        mirror_used_ = true;
+    }
+    for (int k = 0; k < ns; ++k) slice_params(k, dptr, len, cuts[k], cuts[k + 1], lookup, host_mirror, launch_[k]);
+    MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters) * ns, stream));
+    const bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
+    static const int misc_wgs = getenv("MATCHY_AMD_MISC_GRID") ? atoi(getenv("MATCHY_AMD_MISC_GRID")) : 0;
+    const DevDb& view = ddb_->view;
+    if (ns > 1) {
+        // Sliced scan. The scan's stream carries the k_anchor launches, slice after slice. Behind k_anchor of slice i three
+        // side streams take over, as in the one-slice fork below: dom_stream_ k_validate_dom -> k_validate (undecided
+        // domains) -> k_lookup; aux_stream_ k_lookup_ip; aux2_stream_ k_validate (tokens, IPv6 / e-mail) -> k_rare. They
+        // run BESIDE k_anchor of slice i + 1 (whose workgroups leave the CUs one by one), the slices of one side stream in
+        // stream order. Only the tail of the last slice is not covered by a k_anchor.
+        last_forked_ = true;
+        if (!dom_stream_) {
+            MXY_HIP(hipStreamCreateWithFlags(&dom_stream_, hipStreamNonBlocking));
+            MXY_HIP(hipEventCreateWithFlags(&ev_join3_, hipEventDisableTiming));
+            for (auto& e : ev_anchor_) MXY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto& e : ev_misc_) MXY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        if (profile_) MXY_HIP(hipEventRecord(ev_[0], stream));
+        for (int k = 0; k < ns; ++k) {
+            SliceLaunch& L = launch_[k];
+            launch_anchor(L.tp, view, L.grid_anchor, stream);
+            hipEvent_t done = ev_anchor_[k];
+            if (profile_ && k == ns - 1) { MXY_HIP(hipEventRecord(ev_[1], stream)); done = ev_[1]; }
+            else MXY_HIP(hipEventRecord(done, stream));
+            if (L.ip_pass) {
+                MXY_HIP(hipStreamWaitEvent(aux_stream_, done, 0));
+                launch_lookup_ip(L.la, view, L.ip_grid, L.ip_dense, aux_stream_);
+            }
+            MXY_HIP(hipStreamWaitEvent(aux2_stream_, done, 0));
+            TokParams t1 = L.tp;
+            t1.vmode = 1u;
+            launch_validate_misc(t1, view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);
+            if (rare_possible) launch_rare(L.tp, view, n_cu_ * 4, aux2_stream_);
+            MXY_HIP(hipEventRecord(ev_misc_[k], aux2_stream_));
+            MXY_HIP(hipStreamWaitEvent(dom_stream_, done, 0));
+            launch_validate_dom(L.tp, view, n_cu_ * L.gm[1], dom_stream_);
+            TokParams t2 = L.tp;
+            t2.vmode = 2u;
+            launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, dom_stream_);
+            MXY_HIP(hipStreamWaitEvent(dom_stream_, ev_misc_[k], 0));
+            launch_lookup(L.lp, view, n_cu_ * L.gm[2], dom_stream_);
+        }
+        MXY_HIP(hipEventRecord(ev_join3_, dom_stream_));
+        MXY_HIP(hipStreamWaitEvent(stream, ev_join3_, 0));
+        bool any_ip = false;
+        for (int k = 0; k < ns; ++k) any_ip |= launch_[k].ip_pass;
+        if (any_ip) {
+            MXY_HIP(hipEventRecord(ev_join_, aux_stream_));
+            MXY_HIP(hipStreamWaitEvent(stream, ev_join_, 0));
+        }
+        if (profile_) MXY_HIP(hipEventRecord(ev_[4], stream));
+        return;
+    }
+    SliceLaunch& L = launch_[0];
+    const TokParams& tp = L.tp;
     if (profile_) MXY_HIP(hipEventRecord(ev_[0], stream));
-    launch_anchor(tp, ddb_->view, grid_tok, stream);
+    launch_anchor(tp, view, L.grid_anchor, stream);
     if (profile_) MXY_HIP(hipEventRecord(ev_[1], stream));
     // Fork. Everything k_anchor lists is complete now, and two parts of the rest do not depend on k_validate_dom:
     //  * the trie lookups of the IPv4 candidates (and the PCIe writes of their hit records, which is most of the result traffic
@@ -506,58 +676,40 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     //  * k_validate over the long tokens and k_anchor's IPv6 / e-mail anchors, and k_rare behind it -> a third stream.
     // The scan's stream keeps k_validate_dom, k_validate over the domain anchors k_validate_dom left undecided, and the lookups
     // of the validation kernels' candidates; it joins the third stream before those lookups and the second after them.
-    // MATCHY_AMD_NO_FORK=1 keeps everything on one stream.
-    static const bool env_no_fork = getenv("MATCHY_AMD_NO_FORK") != nullptr;
-    const bool no_fork = env_no_fork || !fork;
     last_forked_ = !no_fork;
-    LookupParams la = lp;
-    static const int ip_wgs = getenv("MATCHY_AMD_IPGRID") ? atoi(getenv("MATCHY_AMD_IPGRID")) : 0;
-    // one workgroup on every other CU: enough lanes to keep the result traffic on the bus, and the validation kernels beside it
-    // keep nearly all of their resident waves (128 / 256 / 512 workgroups measured 1.199 / 1.213 / 1.241 ms per headline batch)
-    // (dense lists — a database that answers most addresses, C5 — are latency-bound trie walks for every line: full grid)
-    const bool ip_dense = tp.cand_chunk != 64u;
-    const int ip_grid = ip_wgs > 0 ? ip_wgs : ip_dense ? n_cu_ * gm[2] : std::max(1, n_cu_ / 2);
-    // a database without any IPv4 answer lists no IPv4 candidate (the /24 bitmap is empty): nothing to look up
-    const bool ip_pass = lookup && (ddb_->view.ip_bm24_any || !tp.filter_v4);
-    const bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
-    static const int misc_wgs = getenv("MATCHY_AMD_MISC_GRID") ? atoi(getenv("MATCHY_AMD_MISC_GRID")) : 0;
-    if (ip_pass) {
-        la.cands = cands_a_.p; la.cand_cap = (uint32_t)cands_a_.n; la.n_in = &counters_.p->n_cand_a;
-        la.glob_work = nullptr; la.glob_work_cap = 0;
-    }
     if (!no_fork) {
         hipEvent_t fork = profile_ ? ev_[1] : ev_fork_;
         if (!profile_) MXY_HIP(hipEventRecord(ev_fork_, stream));
-        if (ip_pass) {
+        if (L.ip_pass) {
             MXY_HIP(hipStreamWaitEvent(aux_stream_, fork, 0));
-            launch_lookup_ip(la, ddb_->view, ip_grid, ip_dense, aux_stream_);
+            launch_lookup_ip(L.la, view, L.ip_grid, L.ip_dense, aux_stream_);
             MXY_HIP(hipEventRecord(ev_join_, aux_stream_));
         }
         MXY_HIP(hipStreamWaitEvent(aux2_stream_, fork, 0));
         TokParams t1 = tp;
         t1.vmode = 1u;
         // beside k_validate_dom: half the CUs, so that kernel keeps most of its resident waves
-        launch_validate_misc(t1, ddb_->view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);
-        if (rare_possible) launch_rare(tp, ddb_->view, n_cu_ * 4, aux2_stream_);   // one wave per SIMD (297 VGPRs)
+        launch_validate_misc(t1, view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);
+        if (rare_possible) launch_rare(tp, view, n_cu_ * 4, aux2_stream_);   // one wave per SIMD (297 VGPRs)
         MXY_HIP(hipEventRecord(ev_join2_, aux2_stream_));
-        launch_validate_dom(tp, ddb_->view, n_cu_ * gm[1], stream);
+        launch_validate_dom(tp, view, n_cu_ * L.gm[1], stream);
         TokParams t2 = tp;
         t2.vmode = 2u;
-        launch_validate_misc(t2, ddb_->view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
+        launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
         // no timing events inside the forked tail: every packet between two kernels of the chain is ~6-8 us of it, and with
         // kernels running side by side the intervals would not be kernel times anyway (ScanTiming: validate_ms = the whole tail)
         MXY_HIP(hipStreamWaitEvent(stream, ev_join2_, 0));
     } else {
-        launch_validate_dom(tp, ddb_->view, n_cu_ * gm[1], stream);
-        launch_validate_misc(tp, ddb_->view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);   // vmode 3: every list
+        launch_validate_dom(tp, view, n_cu_ * L.gm[1], stream);
+        launch_validate_misc(tp, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);   // vmode 3: every list
         if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
-        if (rare_possible) launch_rare(tp, ddb_->view, n_cu_ * 4, stream);
+        if (rare_possible) launch_rare(tp, view, n_cu_ * 4, stream);
         if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
     }
     if (lookup) {
-        if (ip_pass && no_fork) launch_lookup_ip(la, ddb_->view, ip_grid, ip_dense, stream);
-        launch_lookup(lp, ddb_->view, n_cu_ * gm[2], stream);
-        if (ip_pass && !no_fork) MXY_HIP(hipStreamWaitEvent(stream, ev_join_, 0));
+        if (L.ip_pass && no_fork) launch_lookup_ip(L.la, view, L.ip_grid, L.ip_dense, stream);
+        launch_lookup(L.lp, view, n_cu_ * L.gm[2], stream);
+        if (L.ip_pass && !no_fork) MXY_HIP(hipStreamWaitEvent(stream, ev_join_, 0));
     }
     if (profile_) MXY_HIP(hipEventRecord(ev_[4], stream));
 }
@@ -578,45 +730,91 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     MXY_HIP(hipSetDevice(ddb_->device));   // regrown buffers must land on this scanner's device whatever thread calls
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-    for (int attempt = 0; attempt < 6; ++attempt) {
-        MXY_HIP(hipMemcpyAsync(&host_counters_, counters_.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, stream));
+    const int ns = n_slices_;
+    for (int attempt = 0;; ++attempt) {
+        MXY_HIP(hipMemcpyAsync(host_slices_, counters_.p, sizeof(ScanCounters) * ns, hipMemcpyDeviceToHost, stream));
         MXY_HIP(hipStreamSynchronize(stream));
-        const ScanCounters& c = host_counters_;
-        bool over = c.n_cand > cands_.n || c.n_cand_a > cands_a_.n || c.n_rare > rare_.n || c.n_rare_dom > rare_dom_.n || c.n_tok > tok_.n || c.n_heavy > heavy_.n || (glob_work_.n && c.n_glob_work > glob_work_.n) || c.n_hits > hits_.n || c.n_ids > ids_.n || c.n_dom > dom_slots_ || (spill_.n && c.n_spill > spill_.n) ||
-                    c.n_final > final_.n || c.n_final_ids > final_ids_.n;
-        if (!over) break;
+        // slice 0 holds n_final / n_final_ids of all slices; statistics are summed
+        ScanCounters& c = host_counters_;
+        c = host_slices_[0];
+        for (int k = 1; k < ns; ++k) {
+            const ScanCounters& s = host_slices_[k];
+            c.lines += s.lines; c.cand_true += s.cand_true; c.hits_true += s.hits_true; c.error |= s.error;
+        }
+        bool over = c.n_final > final_.n || c.n_final_ids > final_ids_.n;
+        for (int k = 0; k < ns; ++k) {
+            const ScanCounters& s = host_slices_[k];
+            const Work& w = work_[k];
+            over = over || s.n_cand > w.cands.n || s.n_cand_a > w.cands_a.n || s.n_rare > w.rare.n || s.n_rare_dom > w.rare_dom.n || s.n_tok > w.tok.n ||
+                   s.n_heavy > w.heavy.n || (w.glob_work.n && s.n_glob_work > w.glob_work.n) || s.n_hits > w.hits.n || s.n_ids > w.ids.n ||
+                   s.n_dom > w.dom_slots || (w.spill.n && s.n_spill > w.spill.n);
+        }
+        if (!over) {
+            // candidates the glob pass could not hold (more results / deeper star nesting than a lane stores): normally none.
+            // If there are, the spill pass runs now — its scratch (one bit per pattern id per thread) is allocated only here — and
+            // appends their records to the same arrays; the counters are read again afterwards.
+            uint32_t n_spill = 0;
+            for (int k = 0; k < ns; ++k) n_spill += work_[k].spill.n ? host_slices_[k].n_spill : 0u;
+            if (n_spill == 0 || spill_done_ || !last_lookup_) break;
+            const uint32_t threads = spill_threads();
+            const size_t words = launch_[0].lp.spill_words;
+            if (spill_scratch_.n < words * SPILL_BLOCKS * threads) spill_scratch_.alloc(words * SPILL_BLOCKS * threads);
+            for (int k = 0; k < ns; ++k) {
+                if (!work_[k].spill.n || !host_slices_[k].n_spill) continue;
+                LookupParams lp = launch_[k].lp;
+                lp.spill_scratch = spill_scratch_.p;
+                launch_lookup_spill(lp, ddb_->view, stream);
+            }
+            spill_done_ = true;
+            if (trace) fprintf(stderr, "[matchy_amd] %u candidates to the spill pass\n", n_spill);
+            continue;
+        }
         if (trace) fprintf(stderr, "[matchy_amd] work buffers overflow (attempt %d): regrow and rescan\n", attempt);
         if (single_) throw HipError{"lookup_one: work buffers overflow"};
-        if (attempt == 5) throw HipError{"scan: work buffers still overflow after regrowing"};
+        if (attempt >= 5) throw HipError{"scan: work buffers still overflow after regrowing"};
         // grow and run again: the kernels count past the capacity without writing, so the counts are exact demands
-        if (c.n_cand > cands_.n) cands_.alloc((size_t)c.n_cand + c.n_cand / 4 + 1024);
-        if (c.n_cand_a > cands_a_.n) cands_a_.alloc((size_t)c.n_cand_a + c.n_cand_a / 4 + 1024);
-        if (c.n_rare > rare_.n) rare_.alloc((size_t)c.n_rare + c.n_rare / 4 + 1024);
-        if (c.n_rare_dom > rare_dom_.n) rare_dom_.alloc((size_t)c.n_rare_dom + c.n_rare_dom / 4 + 1024);
-        if (c.n_tok > tok_.n) tok_.alloc((size_t)c.n_tok + c.n_tok / 4 + 1024);
-        if (c.n_heavy > heavy_.n) heavy_.alloc((size_t)c.n_heavy + c.n_heavy / 4 + 1024);
-        if (glob_work_.n && c.n_glob_work > glob_work_.n) glob_work_.alloc((size_t)c.n_glob_work + c.n_glob_work / 4 + 1024);
-        if (spill_.n && c.n_spill > spill_.n) spill_.alloc((size_t)c.n_spill + c.n_spill / 4 + 1024);
-        if (c.n_dom > dom_slots_) {
-            dom_slots_ = (((size_t)c.n_dom + c.n_dom / 4 + ANCHOR_CHUNK) / ANCHOR_CHUNK) * ANCHOR_CHUNK;
-            dom_list_.alloc(dom_slots_ * DOM_PLANES);
+        auto grown = [](uint32_t n) { return (size_t)n + n / 4 + 1024; };
+        size_t recs = 0, ids = 0;
+        for (int k = 0; k < ns; ++k) {
+            const ScanCounters& s = host_slices_[k];
+            Work& w = work_[k];
+            if (s.n_cand > w.cands.n) w.cands.alloc(grown(s.n_cand));
+            if (s.n_cand_a > w.cands_a.n) w.cands_a.alloc(grown(s.n_cand_a));
+            if (s.n_rare > w.rare.n) w.rare.alloc(grown(s.n_rare));
+            if (s.n_rare_dom > w.rare_dom.n) w.rare_dom.alloc(grown(s.n_rare_dom));
+            if (s.n_tok > w.tok.n) w.tok.alloc(grown(s.n_tok));
+            if (s.n_heavy > w.heavy.n) w.heavy.alloc(grown(s.n_heavy));
+            if (w.glob_work.n && s.n_glob_work > w.glob_work.n) w.glob_work.alloc(grown(s.n_glob_work));
+            if (w.spill.n && s.n_spill > w.spill.n) w.spill.alloc(grown(s.n_spill));
+            if (s.n_dom > w.dom_slots) {
+                w.dom_slots = (((size_t)s.n_dom + s.n_dom / 4 + ANCHOR_CHUNK) / ANCHOR_CHUNK) * ANCHOR_CHUNK;
+                w.dom_list.alloc(w.dom_slots * DOM_PLANES);
+            }
+            if (s.n_hits > w.hits.n || w.hits.n < w.cands.n / 4) w.hits.alloc(std::max<size_t>(grown(s.n_hits), w.cands.n / 4));
+            if (s.n_ids > w.ids.n) w.ids.alloc(grown(s.n_ids));
+            recs += w.hits.n; ids += w.ids.n;
         }
-        if (c.n_hits > hits_.n || hits_.n < cands_.n / 4) hits_.alloc(std::max<size_t>((size_t)c.n_hits + c.n_hits / 4 + 1024, cands_.n / 4));
-        if (c.n_ids > ids_.n) ids_.alloc((size_t)c.n_ids + c.n_ids / 4 + 1024);
-        if (final_.n < hits_.n || c.n_final > final_.n) final_.alloc(std::max<size_t>(hits_.n, (size_t)c.n_final + c.n_final / 4 + 1024));
-        if (final_ids_.n < hits_.n + ids_.n || c.n_final_ids > final_ids_.n) {
-            const size_t want = std::max<size_t>(hits_.n + ids_.n, (size_t)c.n_final_ids + c.n_final_ids / 4 + 1024);
+        if (final_.n < recs || c.n_final > final_.n) final_.alloc(std::max<size_t>(recs, grown(c.n_final)));
+        if (final_ids_.n < recs + ids || c.n_final_ids > final_ids_.n) {
+            const size_t want = std::max<size_t>(recs + ids, grown(c.n_final_ids));
             final_ids_.alloc(want); final_offs_.alloc(want);
         }
-        scan_device(last_ptr_, last_len_, last_lookup_, stream, last_mirror_, last_fork_);
+        scan_device(last_ptr_, last_len_, last_lookup_, stream, last_mirror_, last_fork_, last_slices_);
     }
     const ScanCounters& c = host_counters_;
     if (c.error & 1) throw HipError{"scan: a candidate matches more than 65535 glob patterns (the hit record counts pattern ids in 16 bits)"};
     if (c.error & 4) throw HipError{"scan: a candidate is longer than 16 MiB (24-bit length field)"};
     const double t_counters = since();
-    if (trace)
-        fprintf(stderr, "[matchy_amd] lines=%llu n_dom=%u n_rare=%u+%u n_tok=%u n_heavy=%u n_cand=%u+%u (true %u) n_hits=%u (true %u) n_ids=%u glob_work=%u final=%u\n",
-                c.lines, c.n_dom, c.n_rare, c.n_rare_dom, c.n_tok, c.n_heavy, c.n_cand_a, c.n_cand, c.cand_true, c.n_hits, c.hits_true, c.n_ids, c.n_glob_work, c.n_final);
+    if (trace) {
+        ScanCounters t = host_slices_[0];
+        for (int k = 1; k < ns; ++k) {
+            const ScanCounters& s = host_slices_[k];
+            t.n_dom += s.n_dom; t.n_rare += s.n_rare; t.n_rare_dom += s.n_rare_dom; t.n_tok += s.n_tok; t.n_heavy += s.n_heavy; t.n_cand_a += s.n_cand_a;
+            t.n_cand += s.n_cand; t.n_hits += s.n_hits; t.n_ids += s.n_ids; t.n_glob_work += s.n_glob_work;
+        }
+        fprintf(stderr, "[matchy_amd] slices=%d lines=%llu n_dom=%u n_rare=%u+%u n_tok=%u n_heavy=%u n_cand=%u+%u (true %u) n_hits=%u (true %u) n_ids=%u glob_work=%u final=%u\n",
+                ns, c.lines, t.n_dom, t.n_rare, t.n_rare_dom, t.n_tok, t.n_heavy, t.n_cand_a, t.n_cand, c.cand_true, t.n_hits, c.hits_true, t.n_ids, t.n_glob_work, c.n_final);
+    }
     out.lines = c.lines; out.n_cand = single_ ? c.n_cand : c.cand_true;
     out.n_hits = !last_lookup_ ? 0 : (single_ ? c.hits_true : c.n_final);
     if (profile_) {
@@ -630,18 +828,21 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
             MXY_HIP(hipEventElapsedTime(&timing_.lookup_ms, ev_[3], ev_[4]));
         }
         MXY_HIP(hipEventElapsedTime(&timing_.total_ms, ev_[0], ev_[4]));
+        timing_.slices = ns;
     }
     out.hits.clear(); out.ids.clear(); out.cands.clear();
     out.fin = nullptr; out.fin_ids = nullptr; out.fin_offs = nullptr; out.n_fin = 0; out.n_fin_ids = 0;
+    Work& w0 = work_[0];   // raw hits and candidate lists are read by one-slice scans only (single queries, extraction)
     const bool get_raw = last_lookup_ && hit_mode == HITS_RAW && c.n_hits;
     const bool get_fin = last_lookup_ && hit_mode == HITS_FINAL && c.n_final;
+    if ((get_raw || want_cands) && ns != 1) throw HipError{"fetch: raw hits / candidates of a sliced scan"};
     // D2H into pinned memory (pageable destinations run at a fraction of the PCIe rate)
     if (get_raw) {
         ensure_pinned((size_t)c.n_hits * sizeof(Hit));
-        MXY_HIP(hipMemcpyAsync(pinned_, hits_.p, (size_t)c.n_hits * sizeof(Hit), hipMemcpyDeviceToHost, stream));
+        MXY_HIP(hipMemcpyAsync(pinned_, w0.hits.p, (size_t)c.n_hits * sizeof(Hit), hipMemcpyDeviceToHost, stream));
         if (c.n_ids) {
             out.ids.resize(c.n_ids);
-            MXY_HIP(hipMemcpyAsync(out.ids.data(), ids_.p, (size_t)c.n_ids * 4, hipMemcpyDeviceToHost, stream));
+            MXY_HIP(hipMemcpyAsync(out.ids.data(), w0.ids.p, (size_t)c.n_ids * 4, hipMemcpyDeviceToHost, stream));
         }
     }
     if (get_fin && !sorted && mirror_used_ && c.n_final <= mirror_cap_ && c.n_final_ids <= mirror_ids_cap_) {
@@ -679,8 +880,8 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     }
     if (want_cands && c.n_cand + c.n_cand_a) {   // k_anchor's IPv4 list, then the validation kernels' list
         out.cands.resize((size_t)c.n_cand_a + c.n_cand);
-        if (c.n_cand_a) MXY_HIP(hipMemcpyAsync(out.cands.data(), cands_a_.p, (size_t)c.n_cand_a * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
-        if (c.n_cand) MXY_HIP(hipMemcpyAsync(out.cands.data() + c.n_cand_a, cands_.p, (size_t)c.n_cand * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
+        if (c.n_cand_a) MXY_HIP(hipMemcpyAsync(out.cands.data(), w0.cands_a.p, (size_t)c.n_cand_a * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
+        if (c.n_cand) MXY_HIP(hipMemcpyAsync(out.cands.data() + c.n_cand_a, w0.cands.p, (size_t)c.n_cand * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
     }
     MXY_HIP(hipStreamSynchronize(stream));
     if (trace) fprintf(stderr, "[matchy_amd] fetch: counters after %.3f ms, records after %.3f ms\n", t_counters, since());
@@ -699,35 +900,38 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     if (want_cands) for (const Candidate& cd : out.cands) { uint32_t ty = cd.len_type >> 24; if (ty < IT_COUNT) out.by_type[ty]++; }
 }
 
-// Spill pass of the glob lookup (k_lookup_spill): list of candidate indices + per-thread scratch (one bit per pattern id and a
-// star stack as deep as the longest pattern).
-void Scanner::setup_spill(LookupParams& lp) {
+// Spill pass of the glob lookup (k_lookup_spill): list of candidate indices per slice; the per-thread scratch (one bit per
+// pattern id and a star stack as deep as the longest pattern: ~128 MB for a million patterns) is allocated by fetch() when a
+// scan has actually spilled.
+void Scanner::setup_spill(int sl, LookupParams& lp) {
     if (!ddb_->view.has_glob) return;
-    constexpr uint32_t SPILL_BLOCKS = 16, SPILL_THREADS = 64;
+    Work& w = work_[sl];
     const size_t words = (ddb_->view.pattern_count + 31) / 32 + 2 * ((size_t)ddb_->view.glob_max_segs + 1);
-    const size_t want = std::max<size_t>(1024, cands_.n / 256);
-    if (spill_.n < want) spill_.alloc(want);
-    if (spill_scratch_.n < words * SPILL_BLOCKS * SPILL_THREADS) spill_scratch_.alloc(words * SPILL_BLOCKS * SPILL_THREADS);
-    lp.spill = spill_.p; lp.spill_cap = (uint32_t)spill_.n;
-    lp.spill_scratch = spill_scratch_.p; lp.spill_words = (uint32_t)words; lp.spill_blocks = SPILL_BLOCKS;
+    const size_t want = std::max<size_t>(1024, w.cands.n / 256);
+    if (w.spill.n < want) w.spill.alloc(want);
+    lp.spill = w.spill.p; lp.spill_cap = (uint32_t)w.spill.n;
+    lp.spill_scratch = nullptr; lp.spill_words = (uint32_t)words; lp.spill_blocks = SPILL_BLOCKS;
 }
 
 void Scanner::lookup_one(const std::string& text, Candidate c, ScanOutput& out) {
     MXY_HIP(hipSetDevice(ddb_->device));
     ensure_capacity(4096);
+    Work& w = work_[0];
     if (staging_.n < text.size() + 16) staging_.alloc(text.size() + 4096);
     if (!text.empty()) MXY_HIP(hipMemcpy(staging_.p, text.data(), text.size(), hipMemcpyHostToDevice));
     c.start = 0;
-    MXY_HIP(hipMemcpy(cands_.p, &c, sizeof(c), hipMemcpyHostToDevice));
+    MXY_HIP(hipMemcpy(w.cands.p, &c, sizeof(c), hipMemcpyHostToDevice));
     ScanCounters z{};
     z.n_cand = 1;
     MXY_HIP(hipMemcpy(counters_.p, &z, sizeof(z), hipMemcpyHostToDevice));
     LookupParams lp{};
-    lp.log = staging_.p; lp.len = (uint32_t)text.size(); lp.cands = cands_.p; lp.cand_cap = (uint32_t)cands_.n;
-    lp.hits = hits_.p; lp.hit_cap = (uint32_t)hits_.n; lp.ids = ids_.p; lp.ids_cap = (uint32_t)ids_.n;
+    lp.log = staging_.p; lp.len = (uint32_t)text.size(); lp.cands = w.cands.p; lp.cand_cap = (uint32_t)w.cands.n;
+    lp.hits = w.hits.p; lp.hit_cap = (uint32_t)w.hits.n; lp.ids = w.ids.p; lp.ids_cap = (uint32_t)w.ids.n;
     lp.counters = counters_.p;
-    setup_spill(lp);
+    setup_spill(0, lp);
     launch_lookup(lp, ddb_->view, 1, nullptr);
+    launch_[0].lp = lp;   // fetch() launches the spill pass from here if the candidate spilled
+    n_slices_ = 1; spill_done_ = false;
     last_lookup_ = true; last_ptr_ = staging_.p; last_len_ = (uint32_t)text.size();
     bool prof = profile_;
     profile_ = false;

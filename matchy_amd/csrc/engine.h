@@ -21,6 +21,9 @@ void launch_validate_misc(const TokParams& p, const DevDb& db, int grid, hipStre
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_lookup(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_lookup_ip(const LookupParams& p, const DevDb& db, int grid, bool dense, hipStream_t stream);
+// k_lookup_spill over p.spill (launched by Scanner::fetch when a scan has spilled candidates); threads = spill_threads() per block
+void launch_lookup_spill(const LookupParams& p, const DevDb& db, hipStream_t stream);
+uint32_t spill_threads();
 
 struct HipError { std::string what; };
 #define MXY_HIP(expr)                                                                                   \
@@ -81,7 +84,9 @@ struct DeviceDb {
 
 // HIP-event intervals of the last scan. One stream: k_anchor | k_validate_dom + k_validate | k_rare | lookups incl. record packing.
 // Forked scan (three streams): anchor_ms as before, validate_ms = everything behind k_anchor, rare_ms = lookup_ms = 0.
-struct ScanTiming { float anchor_ms = 0, validate_ms = 0, rare_ms = 0, lookup_ms = 0, total_ms = 0; };
+// Sliced scan: anchor_ms = first k_anchor launch to the end of the last (the other slices' tails run beside), validate_ms = what is
+// left behind the last k_anchor.
+struct ScanTiming { float anchor_ms = 0, validate_ms = 0, rare_ms = 0, lookup_ms = 0, total_ms = 0; int slices = 1; };
 
 enum HitMode { HITS_NONE = 0, HITS_FINAL = 1, HITS_RAW = 2 };
 
@@ -112,12 +117,12 @@ public:
     // batch at a time on device-resident input; callers that keep several batches in flight (submit / wait) or whose time is the
     // host-to-device copy (scan_host) stay on one stream per scanner: the runtime multiplexes streams onto a few hardware queues,
     // and three scanners with three streams each ran 25 % slower than with one each.
-    void scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror = false, bool fork = false);
+    // slices > 1 (with fork): cut the batch into that many slices (see MAX_SLICES); 0 = the scanner's default for the batch size
+    void scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror = false, bool fork = false, int slices = 0);
     // Copies counters (and hits / candidates) back. Call after scan_device; synchronises the stream.
     // sorted: the final records are put into canonical order on the GPU (sort_hits.hip) before they are copied back
     void fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode = HITS_FINAL, bool sorted = false);
     // One synthetic candidate (single-query API): `text` is uploaded, only the lookup kernel runs.
-    void setup_spill(LookupParams& lp);
     // the dense hit records of the last lookup scan as the kernel left them in device memory (MATCHY_SCAN_FETCH_DEVICE)
     const FinalHit* device_final() const { return final_.p; }
     const uint32_t* device_final_ids() const { return final_ids_.p; }
@@ -129,18 +134,58 @@ public:
     void scan_host(const uint8_t* data, size_t len, bool lookup, bool want_cands, ScanOutput& out, std::vector<uint64_t>* cand_bases,
                    std::vector<FinalHit>* fin, std::vector<uint32_t>* fin_ids, std::vector<long long>* fin_offs);
     void set_profile(bool on) { profile_ = on; }
+    // slices of the forked scan_device: 0 = default for the batch size (MATCHY_AMD_SLICES overrides), 1 = never cut, n = n equal slices
+    void set_slices(int n) { slices_ = n < 0 ? 0 : n; }
+    int slices() const { return slices_; }
+    int last_slice_count() const { return n_slices_; }
     const ScanTiming& timing() const { return timing_; }
     uint32_t flags() const { return flags_; }
     int device() const { return ddb_->device; }
     const DbImage& image() const { return *img_; }
 
+    // A device-resident batch of one synchronous scan is cut into up to MAX_SLICES slices (byte ranges on SEG_ALIGN boundaries, no
+    // newline alignment needed: positions stay absolute and k_anchor looks across the cuts): k_anchor runs slice after slice on the
+    // scan's stream, and everything behind it (validation, lookups, result traffic) runs per slice on three side streams, i.e.
+    // BESIDE k_anchor of the following slices. Every slice has its own work lists and counters; the final records of all slices
+    // go to the same arrays (slots reserved with atomics on the counters of slice 0).
+    static constexpr int MAX_SLICES = 8;
+    static constexpr uint32_t SPILL_BLOCKS = 16;
+
 private:
-    void ensure_capacity(uint32_t len);
+    // work lists of one slice (grown on demand, reused between scans)
+    struct Work {
+        DevBuf<Candidate> cands, cands_a;   // candidates of the validation kernels / IPv4 candidates of k_anchor
+        DevBuf<RareAnchor> rare, rare_dom, tok, heavy;
+        DevBuf<uint32_t> dom_list;
+        size_t dom_slots = 0;
+        DevBuf<Hit> hits;                   // single-query path and the spill pass only
+        DevBuf<uint32_t> ids, glob_work;
+        DevBuf<uint32_t> spill;             // glob candidates beyond the per-lane storage of the glob pass (k_lookup_spill)
+        void ensure(uint32_t len);
+    };
+    Work work_[MAX_SLICES];
+    int n_slices_ = 1;                      // slices of the last scan_device
+    int slices_ = 0;                        // set_slices()
+    void ensure_capacity(uint32_t len);     // slice 0 + the final arrays, for a scan of `len` bytes in one slice
+    void ensure_final(size_t recs, size_t ids);
+    // kernel parameters and grids of one slice of the last scan_device (kept: the spill pass is launched from fetch())
+    struct SliceLaunch {
+        TokParams tp;
+        LookupParams lp, la;       // lookups of the validation kernels' candidates / of k_anchor's IPv4 candidates
+        int gm[3] = {1, 1, 1};
+        int grid_anchor = 1, ip_grid = 1;
+        bool ip_pass = false, ip_dense = false;
+    };
+    SliceLaunch launch_[MAX_SLICES];
+    void slice_params(int sl, const uint8_t* dptr, uint32_t len, uint32_t lo, uint32_t hi, bool lookup, bool host_mirror, SliceLaunch& L);
+    int plan_slices(uint32_t len, int want, uint32_t (&cuts)[MAX_SLICES + 1]);
+    void setup_spill(int sl, LookupParams& lp);
+    bool spill_done_ = false;
+    int last_slices_ = 0;
     std::shared_ptr<const DbImage> img_;
     std::shared_ptr<DeviceDb> ddb_;
     hipStream_t host_stream_ = nullptr;   // scan_host: this scanner's own non-blocking stream
     uint32_t flags_, min_labels_;
-    DevBuf<Candidate> cands_, cands_a_;   // candidates of the validation kernels / IPv4 candidates of k_anchor
     // the lookups of k_anchor's IPv4 candidates run on this stream beside the validation kernels (fork after k_anchor, join
     // before the counters are read back)
     hipStream_t aux_stream_ = nullptr;
@@ -148,20 +193,21 @@ private:
     // a third stream: k_validate's part that does not depend on k_validate_dom (tokens, IPv6 / e-mail anchors) and k_rare behind it
     hipStream_t aux2_stream_ = nullptr;
     hipEvent_t ev_join2_ = nullptr;
-    DevBuf<RareAnchor> rare_, rare_dom_, tok_, heavy_;
+    // sliced scans: the k_validate_dom -> k_validate -> k_lookup chain of every slice runs on a stream of its own too (the scan's
+    // stream only carries the k_anchor launches), one "k_anchor of slice i is done" and one "misc stream of slice i is done" event
+    // per slice
+    hipStream_t dom_stream_ = nullptr;
+    hipEvent_t ev_anchor_[MAX_SLICES] = {}, ev_misc_[MAX_SLICES] = {};
+    hipEvent_t ev_join3_ = nullptr;
     DevBuf<FinalHit> final_;
     DevBuf<uint32_t> final_ids_;
     DevBuf<long long> final_offs_;
-    DevBuf<uint32_t> dom_list_;
-    size_t dom_slots_ = 0;
-    DevBuf<Hit> hits_;
-    DevBuf<uint32_t> ids_, glob_work_;
     DevBuf<unsigned long long> sort_keys_;
     DevBuf<uint32_t> sort_vals_;
     DevBuf<uint8_t> sort_tmp_;
     DevBuf<FinalHit> final_sorted_;
-    DevBuf<ScanCounters> counters_;
-    DevBuf<uint32_t> spill_, spill_scratch_;   // glob candidates beyond the per-lane storage of the glob pass (k_lookup_spill)
+    DevBuf<ScanCounters> counters_;            // MAX_SLICES entries
+    DevBuf<uint32_t> spill_scratch_;           // per-thread scratch of k_lookup_spill (allocated when a scan first spills)
     DevBuf<uint8_t> staging_;  // scan_host only
     // pinned mirror of the final records written by the lookup kernels themselves: FinalHit[mirror_cap_] | u32 ids[mirror_ids_cap_] | i64 offs[..]
     void* mirror_ = nullptr;
@@ -171,7 +217,8 @@ private:
     void* pinned_ = nullptr;   // one pinned block: FinalHit[n] | u32 ids[m] | i64 offs[m]  (or Hit[n] for HITS_RAW)
     size_t pinned_bytes_ = 0;
     void ensure_pinned(size_t bytes);
-    ScanCounters host_counters_{};
+    ScanCounters host_counters_{};             // the slices' counters summed (list counters: of slice 0 for one-slice scans)
+    ScanCounters* host_slices_ = nullptr;      // pinned: MAX_SLICES counter blocks as read back
     uint32_t last_len_ = 0;
     const uint8_t* last_ptr_ = nullptr;
     bool last_lookup_ = false, last_fork_ = false, last_forked_ = false;

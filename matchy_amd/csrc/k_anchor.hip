@@ -376,9 +376,10 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     };
 
     for (uint32_t seg = gw; seg < p.n_segs; seg += nw) {
-        const uint32_t seg_start = seg * p.seg_bytes;
-        // positions 0..len are scanned: position `len` (padding, class "boundary") closes a trailing token
-        const uint32_t seg_end = min(seg_start + p.seg_bytes, len + 1);
+        const uint32_t seg_start = p.seg_base + seg * p.seg_bytes;
+        // positions 0..len are scanned: position `len` (padding, class "boundary") closes a trailing token (scan_end = len + 1
+        // for the launch that covers the end of the batch)
+        const uint32_t seg_end = min(seg_start + p.seg_bytes, p.scan_end);
         // Plane carries = the word a lane 63 of a block in front of the segment would hold; only its row-7 bits (8 b + 7 =
         // class of byte seg_start - 4 + b) are ever used. In front of the buffer: boundary.
         uint32_t cB = 0x80808080u, cX = 0;   // cX: carry of the packed word X = [C.b2, C.b3, D.b3, T.b3] (see the block loop)
@@ -614,6 +615,7 @@ int anchor_blocks_per_cu() {
 void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
     if ((p.flags & EX_ALL) == EX_ALL && !anchor_tl_wide(db)) hipLaunchKernelGGL(k_anchor<true>, dim3(grid), dim3(AW * 64), 0, stream, p, db);
     else hipLaunchKernelGGL(k_anchor<false>, dim3(grid), dim3(AW * 64), 0, stream, p, db);
+    check_launch("launch_anchor");
 }
 
 }  // namespace mxy

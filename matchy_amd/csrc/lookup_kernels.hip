@@ -594,6 +594,10 @@ __device__ __forceinline__ void pack_record(const PackParams& pp, bool valid, co
 // that one counter — served one after the other — were 2/3 of the lookup kernel.
 constexpr uint32_t PEND_RECS = 8;
 struct PendRec { uint32_t start, len_type, a, kp; };   // kp: kind | prefix_len << 8
+// LDS budget of k_lookup<false> with an automaton: 32 KiB of pending records + 1 KiB work-list stage (static) + 32 KiB of
+// transition rows (dynamic) — more than the 64 KiB a workgroup gets on earlier CDNA parts; gfx950 has 160 KiB per CU, and the
+// launch wrappers check the launch status (check_launch) so that a rejected launch is an error, not a scan without hits.
+static_assert(256 * PEND_RECS * sizeof(PendRec) + 4 * 64 * 4 + DFA_LDS_ENTRIES * 4 + 1024 <= 160 * 1024, "k_lookup<false>: LDS of one gfx950 CU");
 // WG = true: the call is made by every thread of a 256-thread workgroup (the flush at the end of a kernel); the four waves then
 // reserve their slots with ONE pair of atomics per workgroup through `wg` (6 words of LDS). All waves finish their lists at about
 // the same time, and 2048 waves queueing on the one counter line for their last flush were half of the string-lookup pass.
@@ -849,6 +853,7 @@ __global__ __launch_bounds__(256) void k_lookup_ip(LookupParams p, DevDb db) {
 void launch_lookup_ip(const LookupParams& p, const DevDb& db, int grid, bool dense, hipStream_t stream) {
     if (dense) hipLaunchKernelGGL(k_lookup_ip<8>, dim3(grid), dim3(256), 0, stream, p, db);
     else hipLaunchKernelGGL(k_lookup_ip<2>, dim3(grid), dim3(256), 0, stream, p, db);
+    check_launch("launch_lookup_ip");
 }
 void launch_lookup(const LookupParams& p_in, const DevDb& db, int grid, hipStream_t stream) {
     LookupParams p = p_in;
@@ -866,8 +871,14 @@ void launch_lookup(const LookupParams& p_in, const DevDb& db, int grid, hipStrea
     } else {
         hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(256), 0, stream, p, db);
     }
-    // candidates beyond the glob pass's per-lane storage (normally none: the kernel reads the counter and returns)
-    if (db.has_glob && p.spill_scratch) hipLaunchKernelGGL(k_lookup_spill, dim3(p.spill_blocks), dim3(SPILL_THREADS), 0, stream, p, db);
+    // candidates beyond the glob pass's per-lane storage are listed in p.spill: Scanner::fetch launches k_lookup_spill when the
+    // counters show that there are any (normally none)
+    check_launch("launch_lookup");
 }
+void launch_lookup_spill(const LookupParams& p, const DevDb& db, hipStream_t stream) {
+    hipLaunchKernelGGL(k_lookup_spill, dim3(p.spill_blocks), dim3(SPILL_THREADS), 0, stream, p, db);
+    check_launch("launch_lookup_spill");
+}
+uint32_t spill_threads() { return SPILL_THREADS; }
 
 }  // namespace mxy

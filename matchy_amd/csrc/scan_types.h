@@ -155,6 +155,12 @@ struct TokParams {
     uint32_t filter_ac;       // 1: ... unless their text reaches an output state of the glob automaton (databases with globs)
     uint32_t n_segs;
     uint32_t seg_bytes;       // bytes of log per wavefront work item: a multiple of SEG_ALIGN chosen from the batch length
+    // One launch of k_anchor covers the byte range [seg_base, scan_end) of the batch: segment s starts at seg_base + s * seg_bytes.
+    // A whole batch is seg_base = 0, scan_end = len + 1 (position `len` closes a trailing token). A scan that is cut into slices
+    // (Scanner::scan_device: the tail of one slice runs beside k_anchor of the next) launches k_anchor once per slice; seg_base
+    // is a multiple of SEG_ALIGN, positions stay absolute, look-back and look-ahead across a cut read the neighbouring bytes.
+    uint32_t seg_base;
+    uint32_t scan_end;
     Candidate* cands;         // candidates of the validation kernels (domains, e-mail, IPv6, hashes, addresses)
     uint32_t cand_cap;
     Candidate* cands_a;       // IPv4 candidates of k_anchor (ScanCounters::n_cand_a)
@@ -177,6 +183,10 @@ struct TokParams {
     uint32_t dom_cap;
     ScanCounters* counters;
 };
+
+// Called by every launch wrapper right after its hipLaunchKernelGGL: a launch the runtime rejects (LDS or register budget of
+// another target, bad grid) would otherwise show up as a scan without hits. Throws mxy::HipError (engine.cpp).
+void check_launch(const char* kernel);
 
 // Final hit record, bit-identical to matchy_scan_hit_t in include/matchy_amd.h (checked by static_assert in capi.cpp).
 struct FinalHit {

@@ -1085,14 +1085,17 @@ void launch_validate_dom(const TokParams& p, const DevDb& db, int grid, hipStrea
     if (!(p.flags & EX_DOMAINS)) return;
     if (p.filter_ac) hipLaunchKernelGGL(k_validate_dom<true>, dim3(grid), dim3(256), 0, stream, p, db);
     else hipLaunchKernelGGL(k_validate_dom<false>, dim3(grid), dim3(256), 0, stream, p, db);
+    check_launch("launch_validate_dom");
 }
 // k_validate (tokens, rare anchors, undecided domains: TokParams::vmode says which lists) has a fraction of the work and is
 // latency-bound: every workgroup stages the suffix tables first, so few workgroups (one per CU measured best for the whole job)
 void launch_validate_misc(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_validate, dim3(grid), dim3(256), 0, stream, p, db);
+    check_launch("launch_validate_misc");
 }
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_rare, dim3(grid), dim3(64), 0, stream, p, db);
+    check_launch("launch_rare");
 }
 
 }  // namespace mxy

@@ -133,6 +133,17 @@ def _scan_both(M, oracle, blob, text):
         assert (rd.lines, rd.candidates) == got_stats
         assert rd.hits() == got_hits
         rd.close()
+        # ... and cut into slices (the tail of one slice beside the streaming pass of the next; cuts on 8 KiB multiples, not
+        # on newlines): same counters, same records
+        for ns in (2, 5):
+            if len(text) >= ns * 8192:
+                sc.set_slices(ns)
+                rs = sc.scan_device(dptr.value, len(text), fetch_mode=3)
+                assert sc.last_slices() == ns
+                assert (rs.lines, rs.candidates) == got_stats
+                assert rs.hits() == got_hits
+                rs.close()
+        sc.set_slices(0)
         hip.hipFree(dptr)
     sc.close(); db.close()
     odb = oracle.Database(blob)

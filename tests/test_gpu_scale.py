@@ -132,6 +132,18 @@ def test_headline_batch_as_one_launch(M, oracle, size):
     assert (r.lines, r.candidates, r.n_hits) == (st.lines, st.candidates, len(want))
     r.close()
     assert got == want
+    if lines >= 10_000_000:
+        assert sc.last_slices() > 1   # a batch of this size is cut into slices by default (tails beside the next slice's k_anchor)
+    # one slice (every kernel launched once over the whole batch) and eight: the same records
+    for ns in (1, 8):
+        sc.set_slices(ns)
+        r = sc.scan_device(dptr.value, len(log), fetch_mode=1)
+        assert sc.last_slices() == ns
+        assert (r.lines, r.candidates, r.n_hits) == (st.lines, st.candidates, len(want))
+        key = lambda h: (h["start"], h["end"], h["type"])
+        assert sorted(r.hits(), key=key) == sorted(want, key=key)
+        r.close()
+    sc.set_slices(0)
     # halves: 16-byte aligned start of the second one (the entry requires it), so the cut is moved to a newline that
     # is followed by an aligned offset by scanning the second half from a copy
     cut = log.rfind(b"\n", 0, len(log) // 2) + 1
@@ -230,8 +242,24 @@ def test_scan_device_fetch_modes(M, oracle, cfgname, mirror, monkeypatch):
         src = ctypes.cast(r4._raw.hits, ctypes.c_void_p)
         assert hip.hipMemcpy(buf, src, ctypes.c_size_t(16 * r4.n_hits), 2) == 0
         recs4 = sorted((b.start, b.start + (b.len_type & 0xFFFFFF), M.ITEM_TYPE_NAMES[b.len_type >> 24], b.kind, b.prefix_len, b.n_ids) for b in buf)
-        r4._raw.hits = None   # device pointers: nothing for the host-side accessors to read
+        # device pointers: the host-side accessors refuse them
+        assert r4.on_device
+        with pytest.raises(RuntimeError):
+            r4.hits()
+        with pytest.raises(RuntimeError):
+            r4.ndjson(log)
         r4.close()
+        # sliced scans through every fetch mode (60 000 lines = 11 MB: explicit slice counts are honoured down to 8 KiB slices)
+        for ns in (3, 8):
+            sc.set_slices(ns)
+            r1 = sc.scan_device(d.data_ptr(), len(log), fetch_mode=1)
+            assert sc.last_slices() == ns
+            assert sorted(r1.hits(), key=key) == sorted(want, key=key)
+            r1.close()
+            r0 = sc.scan_device(d.data_ptr(), len(log), fetch_mode=0)
+            assert (r0.lines, r0.candidates, r0.n_hits) == (st.lines, st.candidates, len(want))
+            r0.close()
+        sc.set_slices(0)
         assert recs4 == sorted((h["start"], h["end"], h["type"], 2 if h["kind"] == "ip" else 3, h["prefix_len"], len(h["ids"])) for h in want)
     sc.close(); db.close()
     hip.hipFree(dptr)
