@@ -562,10 +562,12 @@ int Scanner::plan_slices(uint32_t len, int want, uint32_t (&cuts)[MAX_SLICES + 1
         }
         if (n == 1) { n = std::max(1, std::min((int)share[0], (int)MAX_SLICES)); for (int k = 0; k < n; ++k) share[k] = 1.0; }
     } else {
-        // default: later slices are smaller — only the tail of the LAST slice is not hidden by a following k_anchor
-        static const double dflt[4] = {4, 3, 2, 1};
-        n = (uint64_t)len >= 24 * unit ? 4 : 1;
-        for (int k = 0; k < n; ++k) share[k] = dflt[k];
+        // default: ONE slice. Measured on the headline batch (profiles/r03_slices_sweep.txt): with k_anchor's segments handed out
+        // statically — one per resident wave — the tail kernels of slice i take wave slots that k_anchor of slice i + 1 needs at
+        // its start, the workgroups that start late finish late, and the whole scan gets slower (2 slices 1.32 ms, 4 slices 1.53 ms
+        // against 1.16 ms for one). The mechanism stays available (matchy_scanner_set_slices, MATCHY_AMD_SLICES).
+        n = 1;
+        share[0] = 1.0;
     }
     // a slice wants at least two rounds of segments (an explicitly requested one: one segment)
     n = (int)std::min<uint64_t>((uint64_t)std::max(n, 1), std::max<uint64_t>(1, ((uint64_t)len + 1) / (want > 0 ? unit : 2 * unit)));

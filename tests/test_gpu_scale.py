@@ -132,10 +132,9 @@ def test_headline_batch_as_one_launch(M, oracle, size):
     assert (r.lines, r.candidates, r.n_hits) == (st.lines, st.candidates, len(want))
     r.close()
     assert got == want
-    if lines >= 10_000_000:
-        assert sc.last_slices() > 1   # a batch of this size is cut into slices by default (tails beside the next slice's k_anchor)
-    # one slice (every kernel launched once over the whole batch) and eight: the same records
-    for ns in (1, 8):
+    assert sc.last_slices() == 1   # the default: every kernel launched once over the whole batch
+    # cut into three and eight slices (tails beside the next slice's k_anchor): the same records
+    for ns in (3, 8):
         sc.set_slices(ns)
         r = sc.scan_device(dptr.value, len(log), fetch_mode=1)
         assert sc.last_slices() == ns
