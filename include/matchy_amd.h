@@ -301,6 +301,9 @@ char *matchy_amd_query_json(const matchy_t *db, const char *query, int32_t *foun
  * `matchy extract --min-labels`); 0 = the default of 2. */
 matchy_extractor_t *matchy_amd_extractor_create(uint32_t flags, uint32_t min_domain_labels);
 const char *matchy_amd_last_error(void);
+/* Diagnostics: states of the flattened Aho-Corasick automaton on the handle's default device; 0 = the database has no glob
+ * section or its automaton is walked node by node (flattened table above MATCHY_AMD_DFA_MAX_MB, default 8192), -1 = error. */
+int32_t matchy_amd_ac_dfa_states(const matchy_t *db);
 /* HIP devices visible to the process (0 when there is none); `matchy match --devices all` */
 int32_t matchy_amd_device_count(void);
 /* Deterministic builds for tests: fixes the build_epoch metadata value. */

@@ -78,8 +78,10 @@ def lib():
         L.orc_scan_ndjson.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
         L.orc_scan_ndjson.restype = C.c_void_p
         L.orc_scan_free.argtypes = [C.c_void_p]
-        if L.orc_init(str(PSL).encode()) != 0:
-            raise RuntimeError(f"oracle: cannot load PSL container {PSL}")
+        # MATCHY_AMD_PSL: the same override the product honours (tests with a public-suffix list of their own)
+        psl = os.environ.get("MATCHY_AMD_PSL") or str(PSL)
+        if L.orc_init(psl.encode()) != 0:
+            raise RuntimeError(f"oracle: cannot load PSL container {psl}")
         _lib = L
     return _lib
 

@@ -1,6 +1,7 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI (libmatchy_amd.so), against the CPU oracle on the
 same inputs. Integer/byte work: every comparison is exact."""
 import json
+import os
 import random
 from pathlib import Path
 
@@ -908,3 +909,133 @@ def test_case_insensitive_special_casing_from_the_unicode_standard(M, oracle):
     log = "".join(f"GET http://{up}/x http://{low}/y\n" for up, low in pairs).encode()
     gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, log)
     assert gs == ws and gh == wh and gl == wl and len(wh) == 2 * len(pairs)
+
+
+def test_ac_node_walk_without_the_flattened_automaton(M, oracle, monkeypatch):
+    """MATCHY_AMD_DFA_MAX_MB=0 at open: the database is uploaded WITHOUT the dense DFA, the AC prefilters are off and
+    glob_find_all walks the stored ACNodeHot records — goto over ONE / SPARSE / DENSE nodes, failure links until the root
+    (paraglob_offset.rs:1186-1353) — which is the path of a database whose flattened automaton does not fit (10 M globs).
+    Scans (both entries, sliced too) and single queries against the oracle: glob fuzz cases, a case-insensitive database
+    (text ASCII-folded while it is walked), the handmade file with all four node kinds, results beyond the lane storage."""
+    monkeypatch.setenv("MATCHY_AMD_DFA_MAX_MB", "0")
+    for seed in (11, 14):
+        pats, log = _glob_fuzz_case(seed)
+        b = M.DatabaseBuilder(build_epoch=6)
+        for pt, i in pats.items():
+            b.add_entry(pt, {"g": i})
+        b.add_entry("literal:" + log.split()[0].decode(), {"lit": True})
+        blob = b.build()
+        db = M.Database(blob)
+        assert M.lib().matchy_amd_ac_dfa_states(db.handle) == 0    # the node walk really is what runs
+        db.close()
+        gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, log)
+        assert gs == ws and gh == wh and gl == wl
+        assert len(gh) > 100
+    entries, log, names = _ci_case(23)
+    b = M.DatabaseBuilder(build_epoch=7, case_insensitive=True)
+    for k, v in entries:
+        b.add_entry(k, v)
+    blob = b.build()
+    b.close()
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, log)
+    assert gs == ws and gh == wh and gl == wl
+    assert len(gh) > 60
+    db = M.Database(blob)
+    assert M.lib().matchy_amd_ac_dfa_states(db.handle) == 0
+    odb = oracle.Database(blob)
+    rng = random.Random(23)
+    for nm in names[:150]:
+        q = "".join(ch.upper() if rng.random() < 0.5 else ch.lower() for ch in nm)
+        want, got = odb.lookup(q), db.lookup(q)
+        if want["kind"] == "pattern" and want["data"] and want["data"][0] is not None:
+            assert got == {"found": True, "prefix_len": 0, "data": want["data"][0]}, q
+        elif want["kind"] != "pattern":
+            assert got is None, (q, got)
+    db.close()
+    # handmade automaton (EMPTY / ONE / SPARSE / DENSE nodes, built by the textbook algorithm, not by this repository's builder)
+    exp = json.loads((GOLD / "handmade_expect.json").read_text())
+    for name in ("24", "v6"):
+        blob = (GOLD / f"handmade_{name}.mxy").read_bytes()
+        db = M.Database(blob)
+        assert M.lib().matchy_amd_ac_dfa_states(db.handle) == 0
+        for q in exp[name]["queries"]:
+            got, want = db.lookup(q["query"]), q["expect"]
+            if want["kind"] == "ip":
+                assert got == {"found": True, "prefix_len": want["prefix_len"], "data": want["data"]}, (name, q, got)
+            elif want["kind"] == "pattern":
+                assert got == {"found": True, "prefix_len": 0, "data": want["data"][0]}, (name, q, got)
+            else:
+                assert got is None, (name, q, got)
+        db.close()
+        log = b"".join(b"GET http://" + q["query"].encode() + b"/x HTTP/1.1\" \"ref=" + q["query"].encode() + b"\n" for q in exp[name]["queries"])
+        gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, log)
+        assert gs == ws and gh == wh and gl == wl
+    # with the automaton back (default limit) the same database reports its states
+    monkeypatch.delenv("MATCHY_AMD_DFA_MAX_MB")
+    db = M.Database((GOLD / "handmade_24.mxy").read_bytes())
+    assert M.lib().matchy_amd_ac_dfa_states(db.handle) > 0
+    db.close()
+
+
+def test_wide_label_start_class_with_another_public_suffix_list(M, tmp_path):
+    """k_anchor<false> with tl_wide: the shipped public-suffix list only has last labels that start with a-z or a byte >= 0x80, so
+    the streaming pass uses that narrow first-byte class; a list with a last label that starts with a digit (MATCHY_AMD_PSL)
+    switches it to "any label byte or '-'" (k_anchor.hip anchor_tl_wide). The list is loaded once per process, so the comparison
+    with the oracle (same list) runs in a child process: extractor fuzz + a scan."""
+    import subprocess
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from tools import gen_psl
+    base = Path(__file__).resolve().parent.parent / "matchy_amd" / "data" / "psl.bin"
+    # decode the shipped container and add suffixes whose last label starts with a digit / is all digits
+    raw = base.read_bytes()
+    count = int.from_bytes(raw[8:12], "little")
+    sufs, prev, p = [], b"", 16
+    for _ in range(count):
+        shared, rest = raw[p], raw[p + 1]
+        s = prev[:shared] + raw[p + 2:p + 2 + rest]
+        p += 2 + rest
+        sufs.append(s)
+        prev = s
+    sufs = sorted(set(sufs + [b"4u", b"co.4u", b"7z", b"123", b"0x0"]))
+    pslp = tmp_path / "psl_wide.bin"
+    pslp.write_bytes(gen_psl.encode(sufs))
+    code = r"""
+import random, sys
+sys.path.insert(0, ".")
+import matchy_amd as M
+from oracle import oracle
+from tools import synth
+ex = M.Extractor()
+rng = random.Random(77)
+cases = [b"shop.4u", b"a.co.4u x", b"file.7z\n", b"v1.2.123 ", b"x.0x0", b"host.4u.", b"1.2.3.4", b"a.4u-b", b"www.shop.4u/p", b"q.7zz", b"9.123", b"a.b.7z c.d.e.4u"]
+alphas = [b"ab.47uz0x-", b"0123456789.", b"a1.:@ /-\n7z4u", b"comnetorg.uk.co.4u7z"]
+for it in range(300):
+    alpha = rng.choice(alphas)
+    n = rng.choice([5, 17, 64, 129, 1000, 1025, 5000])
+    cases.append(bytes(rng.choice(alpha) for _ in range(n)))
+seen = 0
+for buf in cases:
+    got = [(t, s, e, v) for (t, s, e, v) in ex.extract_from_chunk(buf)]
+    want = [(t, s, e, v) for (t, s, e, v) in oracle.extract(buf)]
+    assert got == want, buf
+    seen += sum(1 for (t, s, e, v) in got if t == "Domain" and v.rsplit(".", 1)[-1][:1].isdigit())
+assert seen > 10, seen
+cfg = synth.config("c2/50")
+blob = synth.build_db(cfg)
+log = synth.make_log(cfg, 0, 3000) + b"GET http://shop.4u/ x.co.4u y.7z 8.8.8.8.123\n" * 50
+db = M.Database(blob)
+sc = M.Scanner(db)
+r = sc.scan(log)
+hits, stats = r.hits(), (r.lines, r.candidates)
+r.close()
+want, _, st = oracle.Database(blob).scan(log, want_json=False)
+assert stats == (st.lines, st.candidates), (stats, st.lines, st.candidates)
+assert hits == want
+print("WIDE-OK", seen, len(hits))
+"""
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, MATCHY_AMD_PSL=str(pslp))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "WIDE-OK" in out.stdout
