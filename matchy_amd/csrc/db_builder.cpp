@@ -319,13 +319,19 @@ struct ParaglobBuilder {
         std::vector<uint8_t> aclh;
         if (!ac_lits.empty()) {
             size_t n = ac_lits.size();
-            // The table is written completely FULL (table_size = number of literals). The reference reader probes from
-            // FxHasher(literal_id) % table_size for at most table_size steps and gives up at the first empty slot
-            // (literal_hash.rs:263-299); rustc-hash 2.1.1's FxHasher cannot be verified in this image, and
-            // with no empty slot every probe sequence reaches every entry whatever the function really is. The slots are
-            // still assigned from the believed function, so if it is right the reference finds an entry after a few steps.
-            // This repository's readers do not use the slot function at all (they enumerate the table once at open).
-            size_t table_size = n;
+            // Sized and filled like ACLiteralHashBuilder::build (literal_hash.rs:120-160): max(ceil(1.25 n), 16) slots, entries
+            // placed by linear probing from FxHasher(literal_id) % table_size. rustc-hash 2.1.1's FxHasher cannot be verified in
+            // this image (believed: (id * 0xf1357aea2e62a9c5).rotate_left(26), hashes.h fx_u32), and the reference
+            // reader gives up at the first EMPTY slot (literal_hash.rs:263-299) — so the slots the reference would leave empty
+            // carry FILLER entries here: a literal id no automaton ever reports (0x80000000 | slot; real ids are dense from 0),
+            // no patterns. With the believed function right, every real id is found exactly as in a reference-built table (its
+            // probe path only crosses real entries: fillers are placed last, into slots no insertion used); with it wrong, the
+            // probe still reaches the entry because nothing stops it (bounded by table_size, literal_hash.rs:272). Lookups of
+            // ids that are absent never happen (paraglob_offset.rs:1070-1073 looks up ids the automaton reported). The
+            // reference's validator skips nothing but 0xFFFFFFFF and accepts entries without patterns (validation.rs:231-283).
+            // This repository's readers do not use the slot function at all (they enumerate the table once at open) and skip
+            // entries without patterns.
+            size_t table_size = std::max<size_t>((n * 5 + 3) / 4, 16);
             std::vector<uint8_t> lists;
             std::vector<uint32_t> offs(n);
             for (size_t l = 0; l < n; ++l) { offs[l] = (uint32_t)lists.size(); for (uint32_t pid : lit_pats[l]) put32(lists, pid); }
@@ -343,7 +349,7 @@ struct ParaglobBuilder {
             put32(aclh, (uint32_t)lists.size());
             for (size_t s = 0; s < table_size; ++s) {
                 uint32_t l = slot_lit[s];
-                if (l == 0xFFFFFFFFu) { put32(aclh, 0xFFFFFFFFu); put32(aclh, 0); put32(aclh, 0); put32(aclh, 0); }
+                if (l == 0xFFFFFFFFu) { put32(aclh, 0x80000000u | (uint32_t)s); put32(aclh, 0); put32(aclh, 0); put32(aclh, 0); }   // filler
                 else { put32(aclh, l); put32(aclh, offs[l]); put32(aclh, (uint32_t)lit_pats[l].size()); put32(aclh, 0); }
             }
             aclh.insert(aclh.end(), lists.begin(), lists.end());

@@ -172,6 +172,7 @@ bool DbImage::check_structure(std::string& err) const {
             for (uint64_t s2 = 0; s2 < table_size; ++s2) {
                 const uint8_t* e = a + 24 + s2 * 16;
                 if (rd32(e) == 0xFFFFFFFFu) continue;
+                if (rd32(e + 8) == 0) continue;   // an entry without patterns maps nothing (db_builder.cpp writes such fillers)
                 // literal ids are dense (paraglob_offset.rs:587: enumerate() over the AC literals), so the table has at least as
                 // many slots as the largest id + 1; the host tables indexed by literal id are sized from the largest id
                 if (rd32(e) >= table_size) { err = "AC literal map names an implausible literal id"; return false; }
@@ -327,6 +328,7 @@ void DbImage::build_lit2pat(std::vector<uint32_t>& off, std::vector<uint32_t>& i
         uint32_t lit = rd32(e);
         if (lit == 0xFFFFFFFFu) continue;
         uint32_t po = rd32(e + 4), pc = rd32(e + 8);
+        if (pc == 0) continue;   // filler / literal without patterns
         if ((size_t)pstart + po + (size_t)pc * 4 > alen) continue;
         ents.push_back({lit, {po, pc}});
         if (lit + 1 > max_lit) max_lit = lit + 1;

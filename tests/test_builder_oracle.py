@@ -274,8 +274,16 @@ def test_lowercase_table_matches_the_interpreter(oracle):
     for s in ["HELLO", "ÉCOLE.Example.COM", "İstanbul", "ǅ", "ẞ", "K", "ΣΑΣ", "ΑΣ", "Σ", "ΑΣ.Β", "ΑΣ́", "́Σ", "aΣb", "ὈΔΥΣΣΕΎΣ", "A.Σ", "Σ.A", "",
               "mixed ÀÉÎÕÜ ΑΒΓ АБВ ԱԲԳ ᏣᎳᎩ \U00010400\U00010401 🌍"]:
         assert oracle.to_lowercase(s) == s.lower(), s
-    bad = [cp for cp in range(0x80, 0x30000) if not 0xD800 <= cp <= 0xDFFF and oracle.to_lowercase(chr(cp) + "x") != (chr(cp) + "x").lower()]
+    # ... except the capitals Unicode 14.0 / 16.0 added, which the table carries by hand (tools/gen_lowercase.py) and this
+    # interpreter's Unicode 13 tables map to themselves
+    from tools import gen_lowercase
+    added = dict(gen_lowercase.added_pairs())
+    bad = [cp for cp in range(0x80, 0x30000) if not 0xD800 <= cp <= 0xDFFF and cp not in added and oracle.to_lowercase(chr(cp) + "x") != (chr(cp) + "x").lower()]
     assert not bad, [hex(c) for c in bad[:10]]
+    assert len(added) == 5 + 5 + 11 + 15 + 7 + 2 + 22
+    for up, lo in added.items():
+        assert oracle.to_lowercase(chr(up) + "x") == chr(lo) + "x", hex(up)
+        assert oracle.to_lowercase("a" + chr(lo)) == "a" + chr(lo)
 
 
 def test_case_insensitive_reference_vectors(oracle):
@@ -428,3 +436,68 @@ def test_handmade_files_pass_structural_validation():
     for name in HANDMADE:
         msg = C.c_void_p()
         assert M.lib().matchy_validate(str(gold / f"handmade_{name}.mxy").encode(), 0, C.byref(msg)) == 0
+
+
+def test_ac_literal_map_layout_for_the_reference_reader():
+    """The AC literal map (ACLH) this repository writes: sized like ACLiteralHashBuilder::build (literal_hash.rs:120-160:
+    max(ceil(1.25 n), 16) slots), real entries reachable from FxHasher(id) % table_size by linear probing WITHOUT crossing a
+    filler (what the reference reader does when the believed hash is right), and no EMPTY slot anywhere (so the reference's probe,
+    which gives up at the first empty slot, reaches every entry even if the believed hash were wrong: literal_hash.rs:263-299)."""
+    import struct
+    import matchy_amd as M
+    for n_globs in (3, 40, 1000):
+        b = M.DatabaseBuilder(build_epoch=3)
+        for i in range(n_globs):
+            b.add_entry(f"*.host{i}.example{i % 7}.com", {"i": i})
+        blob = b.build()
+        b.close()
+        p = blob.index(b"MMDB_PATTERN\0\0\0\0") + 16
+        pg = blob[p + 8:]
+        assert pg[:8] == b"PARAGLOB"
+        map_off, map_cnt = struct.unpack_from("<II", pg, 96)
+        a = pg[map_off:]
+        magic, ver, n, table_size, pstart, psize = struct.unpack_from("<4sIIIII", a, 0)
+        assert magic == b"ACLH" and ver == 1 and n == map_cnt
+        assert table_size == max((n * 5 + 3) // 4, 16)
+        ents = [struct.unpack_from("<IIII", a, 24 + 16 * s) for s in range(table_size)]
+        assert all(e[0] != 0xFFFFFFFF for e in ents)
+        real = {e[0] for e in ents if e[2] > 0}
+        assert real == set(range(n))
+        assert all(e[0] >= 0x80000000 and e[1] == 0 for e in ents if e[2] == 0)
+
+        def fx(v):
+            h = (v * 0xf1357aea2e62a9c5) & 0xFFFFFFFFFFFFFFFF
+            return ((h << 26) | (h >> 38)) & 0xFFFFFFFFFFFFFFFF
+        worst = 0
+        for lid in range(n):
+            s, steps = fx(lid) % table_size, 0
+            while ents[s][0] != lid:
+                assert ents[s][2] > 0, "a filler sits on the probe path of a real entry"
+                s = (s + 1) % table_size
+                steps += 1
+            worst = max(worst, steps)
+        assert worst < 64
+
+
+def test_lowercase_table_covers_case_pairs_added_after_unicode_13(oracle):
+    """matchy_amd/data/lowercase.bin is generated from this interpreter's Unicode 13 tables plus the hand-listed additions of Unicode
+    14.0 / 16.0 (tools/gen_lowercase.py); the oracle (same data file) must answer the capital spelling from a case-insensitive
+    database keyed by the lower-case one. The same pairs run on the GPU in test_case_insensitive_special_casing_from_the_unicode_standard."""
+    import matchy_amd as M
+    pairs = [("Ⱟx.example.com", "ⱟx.example.com"), ("ꟀꟘ.example.com", "ꟁꟙ.example.com"),
+             ("\U00010570\U00010595.example.com", "\U00010597\U000105BC.example.com"), ("Ᲊa.example.com", "ᲊa.example.com"),
+             ("ꟋaꟜ.example.com", "ɤaƛ.example.com"), ("\U00010D50\U00010D65.example.com", "\U00010D70\U00010D85.example.com")]
+    b = M.DatabaseBuilder(build_epoch=7, case_insensitive=True)
+    for i, (_, low) in enumerate(pairs):
+        b.add_entry(low, {"k": i})
+    blob = b.build()
+    b.close()
+    odb = oracle.Database(blob)
+    for i, (up, low) in enumerate(pairs):
+        for q in (up, low):
+            assert odb.lookup(q)["data"] == [{"k": i}], q
+    # a key given in capitals is stored lower-cased by the builder (matchy-literal-hash/src/lib.rs:158-167)
+    b = M.DatabaseBuilder(build_epoch=7, case_insensitive=True)
+    b.add_entry(pairs[4][0], {"k": 1})
+    assert oracle.Database(b.build()).lookup(pairs[4][1])["data"] == [{"k": 1}]
+    b.close()

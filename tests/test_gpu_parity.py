@@ -893,6 +893,14 @@ def test_case_insensitive_special_casing_from_the_unicode_standard(M, oracle):
         ("ÀÉÎÕÜ.example.com", "àéîõü.example.com"),
         ("ΆΈΉΊΌΎΏ.example.com", "άέήίόύώ.example.com"),
         ("ЖЁЛТЫЙ.example.com", "жёлтый.example.com"),
+        # case pairs added after Unicode 13 (hand-listed from UnicodeData.txt of Unicode 14.0 / 16.0; the interpreter here knows neither)
+        ("\u2C2Fx.example.com", "\u2C5Fx.example.com"),                 # 14.0 GLAGOLITIC CAUDATE CHU
+        ("\uA7C0\uA7D0\uA7D6\uA7D8.example.com", "\uA7C1\uA7D1\uA7D7\uA7D9.example.com"),   # 14.0 Latin Extended-D
+        ("\U00010570\U0001057A\U0001057C\U00010595.example.com", "\U00010597\U000105A1\U000105A3\U000105BC.example.com"),   # 14.0 Vithkuqi
+        ("\u1C89a.example.com", "\u1C8Aa.example.com"),                 # 16.0 CYRILLIC TJE
+        ("\uA7CBa\uA7DC.example.com", "\u0264a\u019B.example.com"),    # 16.0 RAMS HORN -> U+0264, LAMBDA WITH STROKE -> U+019B
+        ("\uA7CC\uA7DA.example.com", "\uA7CD\uA7DB.example.com"),      # 16.0
+        ("\U00010D50\U00010D65.example.com", "\U00010D70\U00010D85.example.com"),   # 16.0 Garay
     ]
     b = M.DatabaseBuilder(build_epoch=7, case_insensitive=True)
     for i, (_, low) in enumerate(pairs):
