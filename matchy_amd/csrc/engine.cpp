@@ -216,6 +216,89 @@ void DeviceDb::upload(const DbImage& img, int dev) {
                 }
             }
         }
+        // First 24 levels as a direct table (2^24 entries, 128 MB of the 288 GB): a lookup is one load plus at most 8 dependent
+        // node loads instead of 1 + 16. Built when the tree is big enough for the walks to matter (MATCHY_AMD_L24=0 / 1 forces).
+        {
+            bool want = img.node_count >= 4096;
+            if (const char* e = getenv("MATCHY_AMD_L24")) want = atoi(e) != 0 && img.node_count > 0;
+            if (want) {
+                std::vector<uint2> l24((size_t)1 << 24, make_uint2(1u, 0u));
+                struct Frame { uint32_t node, prefix, depth; };
+                std::vector<Frame> st;
+                for (uint32_t v = 0; v < 65536; ++v) {
+                    const uint2 e = l1[v];
+                    if ((e.x & 0xFF) != 0) {   // decided within 16 levels: the 256 entries below repeat it
+                        if ((e.x & 0xFF) == 2) for (uint32_t k = 0; k < 256; ++k) l24[((size_t)v << 8) | k] = e;
+                        continue;
+                    }
+                    st.push_back({e.y, v << 8, 16u});
+                    while (!st.empty()) {
+                        const Frame f = st.back();
+                        st.pop_back();
+                        const uint2 nd = nodes[f.node];
+                        for (uint32_t bit = 0; bit < 2; ++bit) {
+                            const uint32_t rec = bit ? nd.y : nd.x;
+                            const uint32_t depth = f.depth + 1;
+                            const uint32_t prefix = f.prefix | (bit << (24 - depth));
+                            const uint32_t span = 1u << (24 - depth);
+                            if (rec == img.node_count) continue;
+                            if (rec < img.node_count) {
+                                if (depth == 24) l24[prefix] = make_uint2(0u, rec);
+                                else st.push_back({rec, prefix, depth});
+                            } else if (rec - img.node_count >= 16) {
+                                const uint2 found = make_uint2(2u | (depth << 8), rec - img.node_count - 16);
+                                for (uint32_t k = 0; k < span; ++k) l24[prefix + k] = found;
+                            }
+                        }
+                    }
+                }
+                // ... and below a /24 that is not decided yet: a LEAF table with the outcome for each of its 256 addresses (2 KB per
+                // such /24: 40 K host addresses are 80 MB, 900 K are 1.8 GB — what 288 GB of HBM are for), so that every IPv4
+                // lookup is exactly two dependent loads. Entry kind 3 in the /24 table: y = leaf index. Capped at 16 GB; /24s
+                // beyond the cap keep kind 0 (continue at node y: the reference's walk).
+                {
+                    size_t n_leaf = 0;
+                    for (const uint2& e : l24) n_leaf += (e.x & 0xFF) == 0;
+                    size_t cap_leaf = ((size_t)16 << 30) / (256 * sizeof(uint2));
+                    if (const char* e = getenv("MATCHY_AMD_LEAF_MB")) cap_leaf = ((size_t)atoll(e) << 20) / (256 * sizeof(uint2));
+                    n_leaf = std::min(n_leaf, cap_leaf);
+                    if (n_leaf) {
+                        std::vector<uint2> leaf(n_leaf * 256, make_uint2(1u, 0u));
+                        size_t next = 0;
+                        for (size_t v = 0; v < l24.size() && next < n_leaf; ++v) {
+                            if ((l24[v].x & 0xFF) != 0) continue;
+                            uint2* out = leaf.data() + next * 256;
+                            st.push_back({l24[v].y, 0u, 24u});
+                            while (!st.empty()) {
+                                const Frame f = st.back();
+                                st.pop_back();
+                                const uint2 nd = nodes[f.node];
+                                for (uint32_t bit = 0; bit < 2; ++bit) {
+                                    const uint32_t rec = bit ? nd.y : nd.x;
+                                    const uint32_t depth = f.depth + 1;                       // 25..32
+                                    const uint32_t prefix = f.prefix | (bit << (32 - depth));  // low 8 address bits, left-aligned
+                                    if (rec == img.node_count) continue;
+                                    if (rec < img.node_count) {
+                                        if (depth < 32) st.push_back({rec, prefix, depth});   // a node below bit 32 answers nothing (tree.rs:46-90)
+                                    } else if (rec - img.node_count >= 16) {
+                                        const uint2 found = make_uint2(2u | (depth << 8), rec - img.node_count - 16);
+                                        for (uint32_t k = 0, span = 1u << (32 - depth); k < span; ++k) out[prefix + k] = found;
+                                    }
+                                }
+                            }
+                            l24[v] = make_uint2(3u, (uint32_t)next);
+                            ++next;
+                        }
+                        ip_leaf.upload(leaf);
+                        view.ip_leaf = ip_leaf.p;
+                        bytes_uploaded += leaf.size() * sizeof(uint2);
+                    }
+                }
+                ip_l24.upload(l24);
+                view.ip_l24 = ip_l24.p;
+                bytes_uploaded += l24.size() * sizeof(uint2);
+            }
+        }
         ip_bm24.upload(bm);
         view.ip_bm24 = ip_bm24.p;
         {
@@ -369,6 +452,8 @@ Scanner::Scanner(std::shared_ptr<const DbImage> img, std::shared_ptr<DeviceDb> d
     MXY_HIP(hipGetDeviceProperties(&prop, ddb_->device));
     n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     counters_.alloc(MAX_SLICES);
+    MXY_HIP(hipMemset(counters_.p, 0, sizeof(ScanCounters) * MAX_SLICES));
+    counters_clean_ = true;
     MXY_HIP(hipHostMalloc((void**)&host_slices_, sizeof(ScanCounters) * MAX_SLICES, hipHostMallocDefault));
     for (auto& e : ev_) MXY_HIP(hipEventCreate(&e));
     MXY_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
@@ -390,6 +475,7 @@ Scanner::~Scanner() {
     if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
     if (ev_join2_) (void)hipEventDestroy(ev_join2_);
     if (ev_join3_) (void)hipEventDestroy(ev_join3_);
+    if (ev_dom_) (void)hipEventDestroy(ev_dom_);
     if (aux2_stream_) (void)hipStreamDestroy(aux2_stream_);
     if (dom_stream_) (void)hipStreamDestroy(dom_stream_);
     if (host_stream_) (void)hipStreamDestroy(host_stream_);
@@ -404,6 +490,9 @@ void Scanner::Work::ensure(uint32_t len) {
     if (hits.n < want_h) hits.alloc(want_h);
     if (ids.n < want_h) ids.alloc(want_h);
     if (cands_a.n < want_c) cands_a.alloc(want_c);
+    if (cands_m.n < want_c / 8) cands_m.alloc(want_c / 8);
+    if (cands_r.n < want_r) cands_r.alloc(want_r);
+    if (cands_d.n < want_r) cands_d.alloc(want_r);
     if (rare.n < want_r) rare.alloc(want_r);
     if (rare_dom.n < want_r) rare_dom.alloc(want_r);
     if (tok.n < want_r) tok.alloc(want_r);
@@ -438,7 +527,10 @@ namespace {
 // lookups are chains of dependent loads: more waves in flight only add contention on the random table accesses).
 void grid_multipliers(bool filter_ac, int (&gm)[3]) {
     static const int occ_a = anchor_blocks_per_cu(), occ_v = validate_blocks_per_cu(false), occ_v_ac = validate_blocks_per_cu(true);
-    gm[0] = occ_a; gm[1] = filter_ac ? occ_v_ac : occ_v; gm[2] = 2;
+    // k_validate_dom: at most 4 workgroups per CU — the fifth that registers and LDS would allow leaves no LDS for the kernels
+    // that run beside it (k_validate over tokens / IPv6 / e-mail anchors: 26 KB per workgroup), which then start when
+    // k_validate_dom's workgroups retire (measured: tail 0.250 -> 0.232 ms)
+    gm[0] = occ_a; gm[1] = std::min(filter_ac ? occ_v_ac : occ_v, 4); gm[2] = 2;
     if (const char* g = getenv("MATCHY_AMD_GRID")) {   // 0 keeps the default of that kernel
         int o[3] = {0, 0, 0};
         (void)sscanf(g, "%d,%d,%d", &o[0], &o[1], &o[2]);
@@ -465,7 +557,7 @@ void Scanner::slice_params(int sl, const uint8_t* dptr, uint32_t len, uint32_t l
     tp.filter_ac = (lookup && ac_ok) ? 1u : 0u;
     tp.filter_lit = (lookup && (!ddb_->view.has_glob || ac_ok)) ? 1u : 0u;
     if (const char* dbg = getenv("MATCHY_AMD_DEBUG")) tp.debug = (uint32_t)atoi(dbg);
-    tp.cands = w.cands.p; tp.cand_cap = (uint32_t)w.cands.n;
+    tp.cands = w.cands.p; tp.cand_cap = (uint32_t)w.cands.n; tp.n_cand = &ctr->n_cand;
     tp.cands_a = w.cands_a.p; tp.cand_a_cap = (uint32_t)w.cands_a.n;
     // IPv4 candidates are listed sparsely when the /24 bitmap of the database filters most of the address space
     tp.cand_chunk = (lookup && ddb_->view.ip_bm24_permille <= 250) ? 64u : 1024u;
@@ -521,13 +613,33 @@ void Scanner::slice_params(int sl, const uint8_t* dptr, uint32_t len, uint32_t l
         // single-query path (lookup_one) reads the raw hit list
         lp.direct = 1u;
         lp.pk = pp;
+        // sparse IPv4 candidates (the /24 bitmap lets a few per cent through): k_anchor looks them up itself while it streams
+        // (k_anchor.hip v4_lookup_flush) — their hit records, most of the result traffic of a log scan, then cross the bus under
+        // the streaming pass instead of behind it. Dense lists (a database that answers most addresses) keep the lookup kernel:
+        // there the walks are the work, and a kernel of lanes that do nothing else hides their latency better.
+        static const bool env_no_inline = getenv("MATCHY_AMD_INLINE_V4") && atoi(getenv("MATCHY_AMD_INLINE_V4")) == 0;
+        tp.inline_v4 = (!env_no_inline && tp.filter_v4 && tp.cand_chunk == 64u) ? 1u : 0u;
+        tp.pk = pp;
     }
     // a database without any IPv4 answer lists no IPv4 candidate (the /24 bitmap is empty): nothing to look up
-    L.ip_pass = lookup && (ddb_->view.ip_bm24_any || !tp.filter_v4);
+    L.ip_pass = lookup && !tp.inline_v4 && (ddb_->view.ip_bm24_any || !tp.filter_v4);
     L.la = lp;
     if (L.ip_pass) {
         L.la.cands = w.cands_a.p; L.la.cand_cap = (uint32_t)w.cands_a.n; L.la.n_in = &ctr->n_cand_a;
         L.la.glob_work = nullptr; L.la.glob_work_cap = 0;
+    }
+    // Forked scans of a database without globs: the third stream (tokens, IPv6 / e-mail anchors, k_rare) gets a candidate list and a
+    // lookup pass of its own, so the scan's stream does not have to join it in front of its lookups (an event wait between two
+    // kernels costs ~20 us of the chain even when the event is long done). With a glob section the lookups share the glob work
+    // list and its counter: one list, joined as before.
+    L.split_misc = lookup && !ddb_->view.has_glob;
+    L.lm = lp;
+    L.lr = lp;
+    L.ld = lp;
+    if (L.split_misc) {
+        L.ld.cands = w.cands_d.p; L.ld.cand_cap = (uint32_t)w.cands_d.n; L.ld.n_in = &ctr->n_cand_d;
+        L.lm.cands = w.cands_m.p; L.lm.cand_cap = (uint32_t)w.cands_m.n; L.lm.n_in = &ctr->n_cand_m;
+        L.lr.cands = w.cands_r.p; L.lr.cand_cap = (uint32_t)w.cands_r.n; L.lr.n_in = &ctr->n_cand_r;
     }
     // one workgroup on every other CU: enough lanes to keep the result traffic on the bus, and the validation kernels beside it
     // keep nearly all of their resident waves (128 / 256 / 512 workgroups measured 1.199 / 1.213 / 1.241 ms per headline batch)
@@ -613,7 +725,9 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         mirror_used_ = true;
     }
     for (int k = 0; k < ns; ++k) slice_params(k, dptr, len, cuts[k], cuts[k + 1], lookup, host_mirror, launch_[k]);
-    MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters) * ns, stream));
+    // the counter blocks are zero already when the last scan ended with fetch() (k_finish copies them out and clears them)
+    if (!counters_clean_) MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters) * MAX_SLICES, stream));
+    counters_clean_ = false;
     const bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
     static const int misc_wgs = getenv("MATCHY_AMD_MISC_GRID") ? atoi(getenv("MATCHY_AMD_MISC_GRID")) : 0;
     const DevDb& view = ddb_->view;
@@ -627,6 +741,9 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         if (!dom_stream_) {
             MXY_HIP(hipStreamCreateWithFlags(&dom_stream_, hipStreamNonBlocking));
             MXY_HIP(hipEventCreateWithFlags(&ev_join3_, hipEventDisableTiming));
+            MXY_HIP(hipEventCreateWithFlags(&ev_dom_, hipEventDisableTiming));
+        }
+        if (!ev_anchor_[0]) {
             for (auto& e : ev_anchor_) MXY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             for (auto& e : ev_misc_) MXY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
@@ -644,19 +761,28 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
             MXY_HIP(hipStreamWaitEvent(aux2_stream_, done, 0));
             TokParams t1 = L.tp;
             t1.vmode = 1u;
+            if (L.split_misc) { t1.cands = work_[k].cands_m.p; t1.cand_cap = (uint32_t)work_[k].cands_m.n; t1.n_cand = &(counters_.p + k)->n_cand_m; }
             launch_validate_misc(t1, view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);
-            if (rare_possible) launch_rare(L.tp, view, n_cu_ * 4, aux2_stream_);
+            if (L.split_misc) launch_lookup(L.lm, view, std::max(1, n_cu_ / 2), aux2_stream_);
+            if (rare_possible) {
+                TokParams tr = t1;
+                tr.vmode = L.tp.vmode;
+                if (L.split_misc) { tr.cands = work_[k].cands_r.p; tr.cand_cap = (uint32_t)work_[k].cands_r.n; tr.n_cand = &(counters_.p + k)->n_cand_r; }
+                launch_rare(tr, view, n_cu_ * 4, aux2_stream_);
+                if (L.split_misc) launch_lookup(L.lr, view, std::max(1, n_cu_ / 8), aux2_stream_);
+            }
             MXY_HIP(hipEventRecord(ev_misc_[k], aux2_stream_));
             MXY_HIP(hipStreamWaitEvent(dom_stream_, done, 0));
             launch_validate_dom(L.tp, view, n_cu_ * L.gm[1], dom_stream_);
             TokParams t2 = L.tp;
             t2.vmode = 2u;
             launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, dom_stream_);
-            MXY_HIP(hipStreamWaitEvent(dom_stream_, ev_misc_[k], 0));
+            if (!L.split_misc) MXY_HIP(hipStreamWaitEvent(dom_stream_, ev_misc_[k], 0));
             launch_lookup(L.lp, view, n_cu_ * L.gm[2], dom_stream_);
         }
         MXY_HIP(hipEventRecord(ev_join3_, dom_stream_));
         MXY_HIP(hipStreamWaitEvent(stream, ev_join3_, 0));
+        if (launch_[0].split_misc) MXY_HIP(hipStreamWaitEvent(stream, ev_misc_[ns - 1], 0));
         bool any_ip = false;
         for (int k = 0; k < ns; ++k) any_ip |= launch_[k].ip_pass;
         if (any_ip) {
@@ -690,17 +816,46 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         MXY_HIP(hipStreamWaitEvent(aux2_stream_, fork, 0));
         TokParams t1 = tp;
         t1.vmode = 1u;
+        if (L.split_misc) { t1.cands = work_[0].cands_m.p; t1.cand_cap = (uint32_t)work_[0].cands_m.n; t1.n_cand = &counters_.p->n_cand_m; }
         // beside k_validate_dom: half the CUs, so that kernel keeps most of its resident waves
         launch_validate_misc(t1, view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);
-        if (rare_possible) launch_rare(tp, view, n_cu_ * 4, aux2_stream_);   // one wave per SIMD (297 VGPRs)
+        // split lists: the lookups of k_validate's candidates do not wait for k_rare (checksum validators: a chain of their own,
+        // almost always over next to nothing), whose few candidates get a list and a lookup launch behind it
+        if (L.split_misc) launch_lookup(L.lm, view, std::max(1, n_cu_ / 2), aux2_stream_);
+        if (rare_possible) {   // one wave per SIMD (297 VGPRs)
+            TokParams tr = t1;
+            tr.vmode = tp.vmode;
+            if (L.split_misc) { tr.cands = work_[0].cands_r.p; tr.cand_cap = (uint32_t)work_[0].cands_r.n; tr.n_cand = &counters_.p->n_cand_r; }
+            launch_rare(tr, view, n_cu_ * 4, aux2_stream_);
+            if (L.split_misc) launch_lookup(L.lr, view, std::max(1, n_cu_ / 8), aux2_stream_);
+        }
         MXY_HIP(hipEventRecord(ev_join2_, aux2_stream_));
         launch_validate_dom(tp, view, n_cu_ * L.gm[1], stream);
         TokParams t2 = tp;
         t2.vmode = 2u;
-        launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
-        // no timing events inside the forked tail: every packet between two kernels of the chain is ~6-8 us of it, and with
-        // kernels running side by side the intervals would not be kernel times anyway (ScanTiming: validate_ms = the whole tail)
-        MXY_HIP(hipStreamWaitEvent(stream, ev_join2_, 0));
+        if (L.split_misc) {
+            // the few domain anchors k_validate_dom left undecided: general walk + lookups of ITS candidates (a list of their own)
+            // on a fourth stream, beside the lookups of k_validate_dom's candidates instead of in front of them
+            if (!dom_stream_) {
+                MXY_HIP(hipStreamCreateWithFlags(&dom_stream_, hipStreamNonBlocking));
+                MXY_HIP(hipEventCreateWithFlags(&ev_join3_, hipEventDisableTiming));
+                MXY_HIP(hipEventCreateWithFlags(&ev_dom_, hipEventDisableTiming));
+            }
+            MXY_HIP(hipEventRecord(ev_dom_, stream));
+            MXY_HIP(hipStreamWaitEvent(dom_stream_, ev_dom_, 0));
+            t2.cands = work_[0].cands_d.p; t2.cand_cap = (uint32_t)work_[0].cands_d.n; t2.n_cand = &counters_.p->n_cand_d;
+            launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, dom_stream_);
+            launch_lookup(L.ld, view, std::max(1, n_cu_ / 8), dom_stream_);
+            // one join for the scan's stream: this chain takes the third stream's end in (every event wait on the scan's stream
+            // is ~10 us between its last kernel and k_finish)
+            MXY_HIP(hipStreamWaitEvent(dom_stream_, ev_join2_, 0));
+            MXY_HIP(hipEventRecord(ev_join3_, dom_stream_));
+        } else {
+            launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
+            // no timing events inside the forked tail: every packet between two kernels of the chain is ~6-8 us of it, and with
+            // kernels running side by side the intervals would not be kernel times anyway (ScanTiming: validate_ms = the whole tail)
+            MXY_HIP(hipStreamWaitEvent(stream, ev_join2_, 0));
+        }
     } else {
         launch_validate_dom(tp, view, n_cu_ * L.gm[1], stream);
         launch_validate_misc(tp, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);   // vmode 3: every list
@@ -712,6 +867,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         if (L.ip_pass && no_fork) launch_lookup_ip(L.la, view, L.ip_grid, L.ip_dense, stream);
         launch_lookup(L.lp, view, n_cu_ * L.gm[2], stream);
         if (L.ip_pass && !no_fork) MXY_HIP(hipStreamWaitEvent(stream, ev_join_, 0));
+        if (L.split_misc && !no_fork) MXY_HIP(hipStreamWaitEvent(stream, ev_join3_, 0));
     }
     if (profile_) MXY_HIP(hipEventRecord(ev_[4], stream));
 }
@@ -734,8 +890,10 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     const int ns = n_slices_;
     for (int attempt = 0;; ++attempt) {
-        MXY_HIP(hipMemcpyAsync(host_slices_, counters_.p, sizeof(ScanCounters) * ns, hipMemcpyDeviceToHost, stream));
+        // k_finish: the counter blocks go to pinned host memory and are cleared on the device for the next scan
+        launch_finish(counters_.p, host_slices_, ns, stream);
         MXY_HIP(hipStreamSynchronize(stream));
+        counters_clean_ = true;
         // slice 0 holds n_final / n_final_ids of all slices; statistics are summed
         ScanCounters& c = host_counters_;
         c = host_slices_[0];
@@ -747,7 +905,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         for (int k = 0; k < ns; ++k) {
             const ScanCounters& s = host_slices_[k];
             const Work& w = work_[k];
-            over = over || s.n_cand > w.cands.n || s.n_cand_a > w.cands_a.n || s.n_rare > w.rare.n || s.n_rare_dom > w.rare_dom.n || s.n_tok > w.tok.n ||
+            over = over || s.n_cand > w.cands.n || s.n_cand_a > w.cands_a.n || s.n_cand_m > w.cands_m.n || s.n_cand_r > w.cands_r.n || s.n_cand_d > w.cands_d.n || s.n_rare > w.rare.n || s.n_rare_dom > w.rare_dom.n || s.n_tok > w.tok.n ||
                    s.n_heavy > w.heavy.n || (w.glob_work.n && s.n_glob_work > w.glob_work.n) || s.n_hits > w.hits.n || s.n_ids > w.ids.n ||
                    s.n_dom > w.dom_slots || (w.spill.n && s.n_spill > w.spill.n);
         }
@@ -761,6 +919,9 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
             const uint32_t threads = spill_threads();
             const size_t words = launch_[0].lp.spill_words;
             if (spill_scratch_.n < words * SPILL_BLOCKS * threads) spill_scratch_.alloc(words * SPILL_BLOCKS * threads);
+            // the spill pass appends to the lists the counters describe: put them back (k_finish cleared them)
+            MXY_HIP(hipMemcpyAsync(counters_.p, host_slices_, sizeof(ScanCounters) * ns, hipMemcpyHostToDevice, stream));
+            counters_clean_ = false;
             for (int k = 0; k < ns; ++k) {
                 if (!work_[k].spill.n || !host_slices_[k].n_spill) continue;
                 LookupParams lp = launch_[k].lp;
@@ -782,6 +943,9 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
             Work& w = work_[k];
             if (s.n_cand > w.cands.n) w.cands.alloc(grown(s.n_cand));
             if (s.n_cand_a > w.cands_a.n) w.cands_a.alloc(grown(s.n_cand_a));
+            if (s.n_cand_m > w.cands_m.n) w.cands_m.alloc(grown(s.n_cand_m));
+            if (s.n_cand_r > w.cands_r.n) w.cands_r.alloc(grown(s.n_cand_r));
+            if (s.n_cand_d > w.cands_d.n) w.cands_d.alloc(grown(s.n_cand_d));
             if (s.n_rare > w.rare.n) w.rare.alloc(grown(s.n_rare));
             if (s.n_rare_dom > w.rare_dom.n) w.rare_dom.alloc(grown(s.n_rare_dom));
             if (s.n_tok > w.tok.n) w.tok.alloc(grown(s.n_tok));
@@ -926,6 +1090,7 @@ void Scanner::lookup_one(const std::string& text, Candidate c, ScanOutput& out) 
     ScanCounters z{};
     z.n_cand = 1;
     MXY_HIP(hipMemcpy(counters_.p, &z, sizeof(z), hipMemcpyHostToDevice));
+    counters_clean_ = false;
     LookupParams lp{};
     lp.log = staging_.p; lp.len = (uint32_t)text.size(); lp.cands = w.cands.p; lp.cand_cap = (uint32_t)w.cands.n;
     lp.hits = w.hits.p; lp.hit_cap = (uint32_t)w.hits.n; lp.ids = w.ids.p; lp.ids_cap = (uint32_t)w.ids.n;

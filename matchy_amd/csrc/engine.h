@@ -65,7 +65,7 @@ struct DevBuf {
 struct DeviceDb {
     int device = 0;
     DevDb view{};
-    DevBuf<uint2> ip_nodes, ip_l1;
+    DevBuf<uint2> ip_nodes, ip_l1, ip_l24, ip_leaf;
     DevBuf<uint32_t> ip_bm24, lit_bm;
     DevBuf<uint2> tld_tab;
     DevBuf<uint32_t> dfa, dfa_node;
@@ -155,6 +155,7 @@ private:
     // work lists of one slice (grown on demand, reused between scans)
     struct Work {
         DevBuf<Candidate> cands, cands_a;   // candidates of the validation kernels / IPv4 candidates of k_anchor
+        DevBuf<Candidate> cands_m, cands_r, cands_d; // forked scans of databases without globs: candidates of the third stream (tokens, IPv6, e-mail) / of k_rare
         DevBuf<RareAnchor> rare, rare_dom, tok, heavy;
         DevBuf<uint32_t> dom_list;
         size_t dom_slots = 0;
@@ -171,7 +172,8 @@ private:
     // kernel parameters and grids of one slice of the last scan_device (kept: the spill pass is launched from fetch())
     struct SliceLaunch {
         TokParams tp;
-        LookupParams lp, la;       // lookups of the validation kernels' candidates / of k_anchor's IPv4 candidates
+        LookupParams lp, la, lm, lr, ld;   // lookups of the validation kernels' candidates / of k_anchor's IPv4 candidates / of the third stream's lists
+        bool split_misc = false;   // the third stream has a candidate list and a lookup pass of its own
         int gm[3] = {1, 1, 1};
         int grid_anchor = 1, ip_grid = 1;
         bool ip_pass = false, ip_dense = false;
@@ -181,6 +183,7 @@ private:
     int plan_slices(uint32_t len, int want, uint32_t (&cuts)[MAX_SLICES + 1]);
     void setup_spill(int sl, LookupParams& lp);
     bool spill_done_ = false;
+    bool counters_clean_ = false;   // the device counter blocks are zero (k_finish of the last fetch left them so)
     int last_slices_ = 0;
     std::shared_ptr<const DbImage> img_;
     std::shared_ptr<DeviceDb> ddb_;
@@ -198,7 +201,7 @@ private:
     // per slice
     hipStream_t dom_stream_ = nullptr;
     hipEvent_t ev_anchor_[MAX_SLICES] = {}, ev_misc_[MAX_SLICES] = {};
-    hipEvent_t ev_join3_ = nullptr;
+    hipEvent_t ev_join3_ = nullptr, ev_dom_ = nullptr;
     DevBuf<FinalHit> final_;
     DevBuf<uint32_t> final_ids_;
     DevBuf<long long> final_offs_;

@@ -34,7 +34,7 @@
 //   e-mail  '@' at j                                                                 (ext:1182-1196)
 //   token   boundary at j closing a token of length 26..62, 64, 90..110 or 128       (ext:1212-1409)
 #include "anchor_planes.h"
-#include "device_common.h"
+#include "device_shared.h"
 
 namespace mxy {
 
@@ -104,10 +104,74 @@ struct PendingV4 {
     uint32_t n_valid = 0;  // per-lane count of validated candidates (reduced into ScanCounters::cand_true at the end)
 };
 
-__device__ __forceinline__ void commit_v4(PendingV4& pd, const WaveCtx& cx, CandWriter& cw) {
+// TokParams::inline_v4: the wave looks its IPv4 candidates up itself. Candidates that pass the /24 bitmap collect as {start, address}
+// in the LDS stage the candidate writer would use (V4_STAGE entries of 8 bytes in the same 256 bytes); when the stage is full —
+// and at the end of the wave's work — one lane per entry walks the trie (trie_v4: first-levels table + at most 8 / 16 dependent
+// node loads) and the hits leave as final records: one atomic on the record counter per flush, device array + pinned host mirror
+// like pack_pending in lookup_kernels.hip. A few flushes per wave and batch; the other waves of the SIMD cover the load latency.
+constexpr uint32_t V4_STAGE = CAND_STAGE * sizeof(Candidate) / sizeof(uint2);
+struct V4Lookup {
+    uint2* stage;        // V4_STAGE entries of LDS owned by this wave (the CandWriter's buffer)
+    uint32_t cnt = 0;    // wave-uniform
+    const DevDb* db;
+};
+// length of the canonical dotted-quad text of an address (what the extractor accepted: no leading zeros)
+__device__ __forceinline__ uint32_t v4_text_len(uint32_t a) {
+    uint32_t n = 7;   // four digits and three dots
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint32_t o = (a >> (8 * k)) & 0xFF; n += (o > 9) + (o > 99); }
+    return n;
+}
+__device__ __forceinline__ void v4_lookup_flush(V4Lookup& vl, const TokParams& p) {
+    if (vl.cnt == 0) return;
+    const uint32_t lane = lane_id();
+    __builtin_amdgcn_wave_barrier();
+    const bool have = lane < vl.cnt;
+    uint2 e = make_uint2(0u, 0u);
+    if (have) e = vl.stage[lane];
+    uint32_t off = 0, pfx = 0;
+    const bool hit = have && trie_v4(*vl.db, e.y, off, pfx);
+    const uint64_t m = __ballot(hit);
+    if (m) {
+        const PackParams& pp = p.pk;
+        uint32_t slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(&pp.counters->n_final, (uint32_t)__popcll(m));
+        slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
+        if (hit) {
+            const uint32_t slot = slot0 + mbcnt64(m);
+            FinalHit f{};
+            f.start = e.x; f.len_type = v4_text_len(e.y) | ((uint32_t)IT_IPV4 << 24);
+            f.value = off; f.kind = 2; f.prefix_len = (uint8_t)pfx; f.n_ids = 0;
+            if (slot < pp.out_cap) pp.out[slot] = f;
+            if (slot < pp.host_cap) pp.host_out[slot] = f;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    vl.cnt = 0;
+}
+
+template <bool INL>
+__device__ __forceinline__ void commit_v4(PendingV4& pd, const WaveCtx& cx, CandWriter& cw, V4Lookup& vl) {
     const TokParams& p = *cx.p;
     const bool emit = pd.ok && ((pd.word >> ((pd.c.v4 >> 8) & 31)) & 1);
-    cw.append(emit, pd.c, p.cands_a, p.cand_a_cap, &p.counters->n_cand_a, Candidate{0u, 0xFFFFFFFFu, 0u, 0u});
+    if constexpr (INL) {
+        const uint64_t m = __ballot(emit);
+        if (m) {
+            // the emitting lanes append in lane order; whenever the stage is full it is flushed (every entry used), the rest follows
+            int32_t idx = (int32_t)(vl.cnt + mbcnt64(m));          // position of this lane's entry in the stream of entries
+            uint32_t total = vl.cnt + (uint32_t)__popcll(m);        // wave-uniform
+            for (;;) {
+                if (emit && idx >= 0 && idx < (int32_t)V4_STAGE) vl.stage[idx] = make_uint2(pd.c.start, pd.c.v4);
+                if (total < V4_STAGE) { vl.cnt = total; break; }
+                vl.cnt = V4_STAGE;
+                v4_lookup_flush(vl, p);
+                idx -= (int32_t)V4_STAGE;
+                total -= V4_STAGE;
+            }
+        }
+    } else {
+        cw.append(emit, pd.c, p.cands_a, p.cand_a_cap, &p.counters->n_cand_a, Candidate{0u, 0xFFFFFFFFu, 0u, 0u});
+    }
     pd.ok = false;
 }
 
@@ -155,11 +219,12 @@ __device__ __forceinline__ bool d_ipv4_lean(const uint32_t (&w)[5], const uint8_
     return bad == 0;
 }
 
+template <bool INL>
 __device__ __forceinline__ void drain_v4(uint32_t* ring, uint32_t& head, uint32_t& tail, uint32_t n, bool final, const WaveCtx& cx,
-                                         PendingV4& pd, CandWriter& cw) {
+                                         PendingV4& pd, CandWriter& cw, V4Lookup& vl) {
     const uint32_t lane = lane_id();
     const TokParams& p = *cx.p;
-    commit_v4(pd, cx, cw);
+    commit_v4<INL>(pd, cx, cw, vl);
     __builtin_amdgcn_wave_barrier();
     const bool have = lane < n;
     uint32_t ent = 0;
@@ -309,7 +374,8 @@ template <int K> __device__ __forceinline__ uint32_t ahead(uint32_t P, uint32_t 
 
 // ALL: every extractor is enabled and the public-suffix first-byte class is the narrow one (the command line's and the
 // bulk scan's configuration): no run-time flag tests in the block loop.
-template <bool ALL>
+// INL: TokParams::inline_v4 (the wave looks its IPv4 candidates up itself)
+template <bool ALL, bool INL>
 __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     constexpr uint32_t RAW_DW = RAW_BYTES / 4;
     __shared__ uint8_t ctab[256];    // byte classes for the few bytes in front of a segment (the blocks themselves are bit-sliced)
@@ -341,6 +407,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0;   // ring heads / tails (wave-uniform)
     uint32_t v4_old = 0, dom_old = 0;            // block start of the oldest ring entry (valid while the ring is non-empty)
     CandWriter cw_cand(wb_cand[wave], p.cand_chunk);   // IPv4 candidates: sparse when the /24 bitmap filters, else one per line
+    V4Lookup vl{reinterpret_cast<uint2*>(wb_cand[wave]), 0u, &db};   // TokParams::inline_v4: the same LDS holds {start, address} pairs
     DomWriter cw_dom;
     RareWriter cw_misc(wb_misc[wave]), cw_tok(wb_tok[wave]);   // rare anchors and long tokens are sparse: dense lists
     uint2* rare_out = reinterpret_cast<uint2*>(p.rare);
@@ -410,7 +477,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             // ---- anchors whose look-back bytes are about to be overwritten in the raw window leave first
             if (blk >= seg_start + RAW_BYTES - BLK_BYTES) {
                 const uint32_t lim = blk - (RAW_BYTES - BLK_BYTES);   // entries of blocks <= lim expire
-                if (v4t != v4h && v4_old <= lim) { drain_v4(rv4, v4h, v4t, v4t - v4h, false, cx, pend, cw_cand); v4_old = blk - BLK_BYTES; }
+                if (v4t != v4h && v4_old <= lim) { drain_v4<INL>(rv4, v4h, v4t, v4t - v4h, false, cx, pend, cw_cand, vl); v4_old = blk - BLK_BYTES; }
                 if (dt != dh && dom_old <= lim) { drain_dom(rdom, dh, dt, dt - dh, false, cx, cw_dom); dom_old = blk - BLK_BYTES; }
             }
             // ---- this lane's 8 dwords: raw bytes into the window (natural byte order); prefetch the next block
@@ -487,7 +554,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                     }
                     if (v4t == v4h) v4_old = blk;
                     v4t += (uint32_t)__popcll(m);
-                    if (v4t - v4h >= 64) { drain_v4(rv4, v4h, v4t, 64u, false, cx, pend, cw_cand); v4_old = blk; }
+                    if (v4t - v4h >= 64) { drain_v4<INL>(rv4, v4h, v4t, 64u, false, cx, pend, cw_cand, vl); v4_old = blk; }
                 }
             }
             if (en_v6 || en_at) {
@@ -583,9 +650,10 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         }
         // the next segment of this wave is not contiguous: finish the rings while their bytes are still in the window
         if (dt != dh) drain_dom(rdom, dh, dt, dt - dh, true, cx, cw_dom);
-        if (v4t != v4h) drain_v4(rv4, v4h, v4t, v4t - v4h, true, cx, pend, cw_cand);
+        if (v4t != v4h) drain_v4<INL>(rv4, v4h, v4t, v4t - v4h, true, cx, pend, cw_cand, vl);
     }
-    commit_v4(pend, cx, cw_cand);
+    commit_v4<INL>(pend, cx, cw_cand, vl);
+    if constexpr (INL) v4_lookup_flush(vl, p);
     cw_misc.flush(rare_out, p.rare_cap, &p.counters->n_rare);
     cw_tok.flush(tok_out, p.tok_cap, &p.counters->n_tok);
     // mark the unused tail of every open chunk
@@ -607,14 +675,17 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
 // workgroups of k_anchor that are resident on one CU at the same time (register / LDS limited)
 int anchor_blocks_per_cu() {
     int n = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_anchor<true>, AW * 64, 0);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_anchor<true, true>, AW * 64, 0);
     if (e != hipSuccess || n < 1) n = 3;
     return n;
 }
 
 void launch_anchor(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
-    if ((p.flags & EX_ALL) == EX_ALL && !anchor_tl_wide(db)) hipLaunchKernelGGL(k_anchor<true>, dim3(grid), dim3(AW * 64), 0, stream, p, db);
-    else hipLaunchKernelGGL(k_anchor<false>, dim3(grid), dim3(AW * 64), 0, stream, p, db);
+    const bool all = (p.flags & EX_ALL) == EX_ALL && !anchor_tl_wide(db);
+    if (all && p.inline_v4) hipLaunchKernelGGL((k_anchor<true, true>), dim3(grid), dim3(AW * 64), 0, stream, p, db);
+    else if (all) hipLaunchKernelGGL((k_anchor<true, false>), dim3(grid), dim3(AW * 64), 0, stream, p, db);
+    else if (p.inline_v4) hipLaunchKernelGGL((k_anchor<false, true>), dim3(grid), dim3(AW * 64), 0, stream, p, db);
+    else hipLaunchKernelGGL((k_anchor<false, false>), dim3(grid), dim3(AW * 64), 0, stream, p, db);
     check_launch("launch_anchor");
 }
 

@@ -19,29 +19,7 @@
 namespace mxy {
 
 // ------------------------------------------------------------------------------------------------ stage B: lookups
-// SearchTree::lookup_v4 / lookup_v6 (tree:46-125). Returns record (> node_count) or 0 for "not found".
-__device__ bool trie_v4(const DevDb& db, uint32_t addr, uint32_t& data_off, uint32_t& prefix) {
-    // levels 0..15 come from the first-level table (DeviceDb::upload), the rest is the reference's walk
-    const uint2 e = db.ip_l1[addr >> 16];
-    const uint32_t kind = e.x & 0xFF;
-    if (kind == 1) return false;
-    if (kind == 2) { data_off = e.y; prefix = e.x >> 8; return true; }
-    uint32_t node = e.y;
-    for (int bi = 16; bi < 32; ++bi) {
-        uint2 nd = db.ip_nodes[node];
-        uint32_t rec = ((addr >> (31 - bi)) & 1) ? nd.y : nd.x;
-        if (rec == db.node_count) return false;
-        if (rec < db.node_count) node = rec;
-        else {
-            uint32_t off = rec - db.node_count;
-            if (off < 16) return false;  // reference: MmdbError -> lookup error; treated as not found (never produced by builders)
-            data_off = off - 16;
-            prefix = (uint32_t)bi + 1;  // tree:76-80: depth counts from 96 in v6 trees and 96 is subtracted again
-            return true;
-        }
-    }
-    return false;
-}
+// SearchTree::lookup_v4 (tree:46-90): trie_v4 in device_shared.h (k_anchor uses it too). lookup_v6 (tree:92-125):
 __device__ bool trie_v6(const DevDb& db, const uint16_t seg[8], uint32_t& data_off, uint32_t& prefix) {
     uint32_t node = 0;
     for (int bi = 0; bi < 128; ++bi) {
@@ -874,6 +852,20 @@ void launch_lookup(const LookupParams& p_in, const DevDb& db, int grid, hipStrea
     // candidates beyond the glob pass's per-lane storage are listed in p.spill: Scanner::fetch launches k_lookup_spill when the
     // counters show that there are any (normally none)
     check_launch("launch_lookup");
+}
+// see launch_finish (scan_types.h)
+__global__ __launch_bounds__(256) void k_finish(ScanCounters* dev, ScanCounters* host, uint32_t n_words) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(dev);
+    uint32_t* h = reinterpret_cast<uint32_t*>(host);
+    for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) {
+        h[i] = d[i];
+        d[i] = 0;
+    }
+    __threadfence_system();
+}
+void launch_finish(ScanCounters* dev, ScanCounters* host_pinned, int n_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, stream, dev, host_pinned, (uint32_t)(n_blocks * sizeof(ScanCounters) / 4));
+    check_launch("launch_finish");
 }
 void launch_lookup_spill(const LookupParams& p, const DevDb& db, hipStream_t stream) {
     hipLaunchKernelGGL(k_lookup_spill, dim3(p.spill_blocks), dim3(SPILL_THREADS), 0, stream, p, db);

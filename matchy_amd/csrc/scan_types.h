@@ -56,6 +56,9 @@ struct DevDb {
     uint32_t ip_bm24_any;      // 0: no bit of ip_bm24 is set (the database answers no IPv4 address: k_anchor lists no IPv4 candidate)
     const uint32_t* ip_bm24; // 2^24 bits: bit v set iff the first 24 IPv4 levels for prefix v do not end in "not found"
     const uint2* ip_l1;      // 65536 entries: outcome of the first 16 IPv4 levels (x = kind | prefix << 8, y = node / data offset)
+    const uint2* ip_l24;     // 2^24 entries, same encoding after 24 levels, or null (small trees: the 128 MB table is not built);
+                             // kind 3: the /24 has a leaf table, y = its index
+    const uint2* ip_leaf;    // leaf tables: 256 entries per undecided /24 (x = 1 not found | 2 | prefix << 8 found, y = data offset)
     uint32_t node_count;
     uint32_t ip_version;     // 4 or 6
     uint32_t v4_start_node;  // node reached after the 96 zero-bit steps of tree.rs:258-277 (v6 trees)
@@ -130,6 +133,10 @@ struct ScanCounters {
     alignas(128) uint32_t n_cand;    // candidates appended by the validation kernels (may exceed capacity → overflow)
     alignas(128) uint32_t n_cand_a;  // IPv4 candidates appended by k_anchor: a list of their own (TokParams::cands_a), so that their
                                      // lookups can start when k_anchor ends, beside the validation kernels
+    alignas(128) uint32_t n_cand_m;  // candidates of k_validate over tokens / IPv6 / e-mail anchors and of k_rare when those run on the third
+                                     // stream with a list (and a lookup pass) of their own
+    uint32_t n_cand_d;               // ... of k_validate over the undecided domains (looked up beside the lookups of k_validate_dom's candidates)
+    uint32_t n_cand_r;               // ... and of k_rare (its list is looked up after it, behind the lookups of n_cand_m)
     alignas(128) uint32_t n_dom;     // domain anchors (first byte of a label that follows a dot)
     alignas(128) uint32_t n_rare;    // IPv6 / e-mail anchors (k_anchor)
     alignas(128) uint32_t n_rare_dom;   // domain anchors k_validate_dom could not decide (general walk in k_validate): a list of their own,
@@ -143,50 +150,6 @@ struct ScanCounters {
     alignas(128) uint32_t n_glob_work;   // candidates whose text reaches an output state of the AC automaton (glob work list)
     uint32_t n_spill;                // candidates handed to k_lookup_spill (more glob results / deeper star nesting than a lane of the glob pass holds)
 };
-
-struct TokParams {
-    const uint8_t* log;
-    uint32_t len;
-    uint32_t flags;           // ExtractFlags
-    uint32_t min_labels;
-    uint32_t debug;           // MATCHY_AMD_DEBUG: free for kernel experiments (unused in the shipped kernels)
-    uint32_t filter_v4;       // 1: IPv4 candidates whose /24 has no database entry are counted but not listed (lookup scans)
-    uint32_t filter_lit;      // 1: domain candidates whose XXH64 is not in DevDb::lit_bm are counted but not listed ...
-    uint32_t filter_ac;       // 1: ... unless their text reaches an output state of the glob automaton (databases with globs)
-    uint32_t n_segs;
-    uint32_t seg_bytes;       // bytes of log per wavefront work item: a multiple of SEG_ALIGN chosen from the batch length
-    // One launch of k_anchor covers the byte range [seg_base, scan_end) of the batch: segment s starts at seg_base + s * seg_bytes.
-    // A whole batch is seg_base = 0, scan_end = len + 1 (position `len` closes a trailing token). A scan that is cut into slices
-    // (Scanner::scan_device: the tail of one slice runs beside k_anchor of the next) launches k_anchor once per slice; seg_base
-    // is a multiple of SEG_ALIGN, positions stay absolute, look-back and look-ahead across a cut read the neighbouring bytes.
-    uint32_t seg_base;
-    uint32_t scan_end;
-    Candidate* cands;         // candidates of the validation kernels (domains, e-mail, IPv6, hashes, addresses)
-    uint32_t cand_cap;
-    Candidate* cands_a;       // IPv4 candidates of k_anchor (ScanCounters::n_cand_a)
-    uint32_t cand_a_cap;
-    uint32_t cand_chunk;      // slots k_anchor reserves per atomic for its IPv4 candidates (64: sparse list, 1024: one per line)
-    RareAnchor* rare;         // IPv6 / e-mail anchors
-    uint32_t rare_cap;
-    RareAnchor* rare_dom;     // undecided domain anchors (written by k_validate_dom)
-    uint32_t rare_dom_cap;
-    uint32_t vmode;           // k_validate: bit 0 = long tokens + the rare list, bit 1 = the rare_dom list
-    RareAnchor* tok;          // long-token anchors
-    uint32_t tok_cap;
-    RareAnchor* heavy;        // tokens that passed the cheap prefilters of k_validate and need k_rare
-    uint32_t heavy_cap;
-    // Domain anchors that survive k_anchor's prefilter, with 32 bytes of context copied from its LDS window so that
-    // k_validate reads them coalesced instead of gathering log lines: per 64-slot tile 9 planes of 64 dwords
-    // (dom_plane_index): plane 0 = anchor position j (bit 31 set: no context, 0xFFFFFFFF: unused slot),
-    // planes 1..8 = log[j-24, j+8). dom_cap counts slots.
-    uint32_t* dom_list;
-    uint32_t dom_cap;
-    ScanCounters* counters;
-};
-
-// Called by every launch wrapper right after its hipLaunchKernelGGL: a launch the runtime rejects (LDS or register budget of
-// another target, bad grid) would otherwise show up as a scan without hits. Throws mxy::HipError (engine.cpp).
-void check_launch(const char* kernel);
 
 // Final hit record, bit-identical to matchy_scan_hit_t in include/matchy_amd.h (checked by static_assert in capi.cpp).
 struct FinalHit {
@@ -221,6 +184,61 @@ struct PackParams {
     uint32_t host_ids_cap;
     ScanCounters* counters;
 };
+
+struct TokParams {
+    const uint8_t* log;
+    uint32_t len;
+    uint32_t flags;           // ExtractFlags
+    uint32_t min_labels;
+    uint32_t debug;           // MATCHY_AMD_DEBUG: free for kernel experiments (unused in the shipped kernels)
+    uint32_t filter_v4;       // 1: IPv4 candidates whose /24 has no database entry are counted but not listed (lookup scans)
+    uint32_t filter_lit;      // 1: domain candidates whose XXH64 is not in DevDb::lit_bm are counted but not listed ...
+    uint32_t filter_ac;       // 1: ... unless their text reaches an output state of the glob automaton (databases with globs)
+    uint32_t n_segs;
+    uint32_t seg_bytes;       // bytes of log per wavefront work item: a multiple of SEG_ALIGN chosen from the batch length
+    // One launch of k_anchor covers the byte range [seg_base, scan_end) of the batch: segment s starts at seg_base + s * seg_bytes.
+    // A whole batch is seg_base = 0, scan_end = len + 1 (position `len` closes a trailing token). A scan that is cut into slices
+    // (Scanner::scan_device: the tail of one slice runs beside k_anchor of the next) launches k_anchor once per slice; seg_base
+    // is a multiple of SEG_ALIGN, positions stay absolute, look-back and look-ahead across a cut read the neighbouring bytes.
+    uint32_t seg_base;
+    uint32_t scan_end;
+    Candidate* cands;         // candidates of the validation kernels (domains, e-mail, IPv6, hashes, addresses)
+    uint32_t cand_cap;
+    uint32_t* n_cand;         // the counter of `cands` (ScanCounters::n_cand, or n_cand_m for the list of the third stream)
+    Candidate* cands_a;       // IPv4 candidates of k_anchor (ScanCounters::n_cand_a)
+    uint32_t cand_a_cap;
+    uint32_t cand_chunk;      // slots k_anchor reserves per atomic for its IPv4 candidates (64: sparse list, 1024: one per line)
+    RareAnchor* rare;         // IPv6 / e-mail anchors
+    uint32_t rare_cap;
+    RareAnchor* rare_dom;     // undecided domain anchors (written by k_validate_dom)
+    uint32_t rare_dom_cap;
+    uint32_t vmode;           // k_validate: bit 0 = long tokens + the rare list, bit 1 = the rare_dom list
+    RareAnchor* tok;          // long-token anchors
+    uint32_t tok_cap;
+    RareAnchor* heavy;        // tokens that passed the cheap prefilters of k_validate and need k_rare
+    uint32_t heavy_cap;
+    // Domain anchors that survive k_anchor's prefilter, with 32 bytes of context copied from its LDS window so that
+    // k_validate reads them coalesced instead of gathering log lines: per 64-slot tile 9 planes of 64 dwords
+    // (dom_plane_index): plane 0 = anchor position j (bit 31 set: no context, 0xFFFFFFFF: unused slot),
+    // planes 1..8 = log[j-24, j+8). dom_cap counts slots.
+    uint32_t* dom_list;
+    uint32_t dom_cap;
+    ScanCounters* counters;
+    // inline_v4 = 1 (lookup scans of a database whose /24 bitmap thins the IPv4 candidates): k_anchor looks its IPv4 candidates up
+    // itself — a few dozen at a time, whenever a wave has collected them — and writes the hit records through `pk`; no candidate
+    // list, no lookup kernel for them, and the records cross the bus while the streaming pass runs instead of behind it.
+    uint32_t inline_v4;
+    PackParams pk;
+};
+
+// k_finish (lookup_kernels.hip): the last kernel of a scan. Copies the counter blocks of the scan's slices into pinned host memory
+// and zeroes them on the device for the next scan — one small kernel instead of a device-to-host copy behind the scan and a memset
+// in front of the next one.
+void launch_finish(ScanCounters* dev, ScanCounters* host_pinned, int n_blocks, hipStream_t stream);
+
+// Called by every launch wrapper right after its hipLaunchKernelGGL: a launch the runtime rejects (LDS or register budget of
+// another target, bad grid) would otherwise show up as a scan without hits. Throws mxy::HipError (engine.cpp).
+void check_launch(const char* kernel);
 
 struct LookupParams {
     const uint8_t* log;

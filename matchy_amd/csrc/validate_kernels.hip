@@ -819,8 +819,8 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
     uint32_t* sb = strbuf[threadIdx.x];
     for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
         const uint32_t i = base + threadIdx.x;
-        if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand);
-        else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
+        if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, p.n_cand);
+        else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, p.n_cand, SC);
         pend = false;
         load_rec(i + stride, nxt);
         bool slow = false;
@@ -880,9 +880,9 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
         sw.append(slow, RareAnchor{cur.j & 0x7FFFFFFFu, (uint32_t)RARE_DOM}, p.rare_dom, p.rare_dom_cap, &p.counters->n_rare_dom);
         cur = nxt;
     }
-    if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand);
-    else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, &p.counters->n_cand, SC);
-    cw.flush(p.cands, p.cand_cap, &p.counters->n_cand);
+    if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, p.n_cand);
+    else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, p.n_cand, SC);
+    cw.flush(p.cands, p.cand_cap, p.n_cand);
     cw_dense.pad_rest(p.cands, p.cand_cap, SC);
     sw.flush(p.rare_dom, p.rare_dom_cap, &p.counters->n_rare_dom);
     // validated domain candidates, listed or not
@@ -893,13 +893,21 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
 
 // k_validate — stage A2b: one lane per long token (hex hashes; prefix tests for the address formats) and per rare
 // anchor: IPv6, e-mail, and the domain anchors k_validate_dom could not decide (general right-to-left walk).
+// VM = TokParams::vmode of the launch (bit 0: long tokens + k_anchor's rare anchors, bit 1: the undecided domains). The two halves
+// need different LDS — the IPv6 windows (20 KB) for the first, the public-suffix tables (20 KB) for the second — and the first runs
+// BESIDE k_validate_dom, whose workgroups hold most of a CU's LDS: with 26 KB instead of 47 its workgroups find room at once
+// instead of waiting for k_validate_dom's to retire.
+template <uint32_t VM>
 __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
-    __shared__ uint32_t bloom[TLD_BLOOM_WORDS];
-    __shared__ uint2 tldtab[1u << TLD_TAB_BITS];
-    __shared__ __attribute__((aligned(16))) uint8_t winbuf[256 * 80];   // one 80-byte IPv6 window per lane
-    for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += blockDim.x) bloom[i] = db.tld_bloom[i];
-    for (uint32_t i = threadIdx.x; i < (1u << TLD_TAB_BITS); i += blockDim.x) tldtab[i] = db.tld_tab[i];
-    __syncthreads();
+    constexpr bool MISC = (VM & 1u) != 0, DOM = (VM & 2u) != 0;
+    __shared__ uint32_t bloom[DOM ? TLD_BLOOM_WORDS : 1];
+    __shared__ uint2 tldtab[DOM ? (1u << TLD_TAB_BITS) : 1];
+    __shared__ __attribute__((aligned(16))) uint8_t winbuf[MISC ? 256 * 80 : 16];   // one 80-byte IPv6 window per lane
+    if constexpr (DOM) {
+        for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += blockDim.x) bloom[i] = db.tld_bloom[i];
+        for (uint32_t i = threadIdx.x; i < (1u << TLD_TAB_BITS); i += blockDim.x) tldtab[i] = db.tld_tab[i];
+        __syncthreads();
+    }
     LogView lg{p.log, p.len};
     __shared__ Candidate wb_cand[4][64];
     BufferedWriter<Candidate> cw(wb_cand[threadIdx.x >> 6]);
@@ -910,7 +918,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     // reference's from_utf8 precondition is implied by the per-symbol checks.
     __shared__ RareAnchor wb_heavy[4][64];
     BufferedWriter<RareAnchor> hw(wb_heavy[threadIdx.x >> 6]);
-    const uint32_t nt = (p.vmode & 1u) ? min(p.counters->n_tok, p.tok_cap) : 0u;
+    const uint32_t nt = MISC ? min(p.counters->n_tok, p.tok_cap) : 0u;
     for (uint32_t base = blockIdx.x * blockDim.x; base < nt; base += stride) {
         const uint32_t i = base + threadIdx.x;
         RareAnchor ra{0, 0xFF};
@@ -926,7 +934,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
                 const int ht = tl == 32 ? IT_MD5 : tl == 40 ? IT_SHA1 : tl == 64 ? IT_SHA256 : tl == 96 ? IT_SHA384 : tl == 128 ? IT_SHA512 : -1;
                 if (ht >= 0 && all_hex_wide(s, tl)) { c.start = ra.pos; c.len_type = tl | ((uint32_t)ht << 24); emit = true; }
             }
-            cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand);
+            cw.append(emit, c, p.cands, p.cand_cap, p.n_cand);
         }
         // a token can yield several items: hash, Bitcoin, Ethereum and Monero are independent extractors
         {
@@ -945,11 +953,12 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     hw.flush(p.heavy, p.heavy_cap, &p.counters->n_heavy);
     // IPv6 ("::") and e-mail ('@') anchors from the rare list. The IPv6 parser reads its bytes many times: each lane
     // copies log[p2-40, p2+40) into its LDS window with five wide loads first.
-    uint8_t* win = winbuf + threadIdx.x * 80;
+    uint8_t* win = winbuf + (MISC ? threadIdx.x * 80 : 0);
     // two lists through the same code: k_anchor's rare anchors (vmode bit 0) and the domain anchors k_validate_dom left (bit 1);
     // the engine runs the first beside k_validate_dom on a stream of its own and the second behind it
+    uint32_t unlisted = 0;   // valid candidates this lane did not list (they cannot hit)
     for (uint32_t li = 0; li < 2; ++li) {
-    if (!((p.vmode >> li) & 1u)) continue;
+    if (!((VM >> li) & 1u)) continue;
     const RareAnchor* rlist = li ? p.rare_dom : p.rare;
     const uint32_t nr = li ? min(p.counters->n_rare_dom, p.rare_dom_cap) : min(p.counters->n_rare, p.rare_cap);
     for (uint32_t base = blockIdx.x * blockDim.x; base < nr; base += stride) {
@@ -959,7 +968,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         const uint32_t kind = ra.len_kind & 0xFF;
         Candidate c{0, 0, 0, 0};
         bool emit = false;
-        if (kind == RARE_V6) {
+        if (MISC && kind == RARE_V6) {
             uint32_t s, e;
             bool ok;
             if (ra.pos >= 40 && ra.pos + 40 <= lg.len) {
@@ -974,11 +983,21 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
                 ok = val_ipv6(lg, ra.pos, s, e);
             }
             if (ok) { c.start = s; c.len_type = (e - s) | ((uint32_t)IT_IPV6 << 24); emit = true; }
+            // An IPv4 tree answers an IPv6 address from its first 32 bits only (SearchTree::lookup_v6 walks from node 0 whatever the
+            // tree's version, tree.rs:92-125, and a 32-level tree ends there): the /24 bitmap of the database decides for most
+            // addresses that nothing can be found — such candidates are counted, not listed (like the IPv4 candidates of k_anchor).
+            if (ok && p.filter_v4 && db.ip_version == 4 && ra.pos >= 40 && ra.pos + 40 <= lg.len && e - s <= 39) {
+                uint16_t seg[8];
+                if (d_parse_ipv6(win + (s - (ra.pos - 40)), e - s, seg)) {
+                    const uint32_t top24 = ((uint32_t)seg[0] << 8) | (seg[1] >> 8);
+                    if (!((db.ip_bm24[top24 >> 5] >> (top24 & 31)) & 1)) { emit = false; ++unlisted; }
+                }
+            }
         }
         // e-mail anchors: the local part leftwards (a lane that meets a long run gets the wave's help), then the rest
         {
             EmailState es{ra.pos, (uint32_t)'@', false, false};
-            const bool is_at = kind == RARE_AT;
+            const bool is_at = MISC && kind == RARE_AT;
             bool el = is_at && email_local_scan(lg, es, true);
             for (uint64_t lm = __ballot(el); lm; lm &= lm - 1) {
                 const int src = __ffsll((long long)lm) - 1;
@@ -1000,7 +1019,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         DomLong dl{};
         int dr = WALK_NO;
         uint32_t ds = 0, de = 0;
-        if (kind == RARE_DOM) dr = val_domain(lg, db, bloom, tldtab, p.min_labels, ra.pos, ds, de, &dl);
+        if (DOM && kind == RARE_DOM) dr = val_domain(lg, db, bloom, tldtab, p.min_labels, ra.pos, ds, de, &dl);
         for (uint64_t lm = __ballot(dr == WALK_LONG); lm; lm &= lm - 1) {
             const int src = __ffsll((long long)lm) - 1;
             WalkState st;
@@ -1022,11 +1041,13 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
             if (de - ds > 0xFFFFFFu) atomicOr(&p.counters->error, 4u);
             c.start = ds; c.len_type = (de - ds) | ((uint32_t)IT_DOMAIN << 24); emit = true;
         }
-        cw.append(emit, c, p.cands, p.cand_cap, &p.counters->n_cand);
+        cw.append(emit, c, p.cands, p.cand_cap, p.n_cand);
     }
     }
-    cw.flush(p.cands, p.cand_cap, &p.counters->n_cand);
-    if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
+    cw.flush(p.cands, p.cand_cap, p.n_cand);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) unlisted += __shfl_down(unlisted, off);
+    if (lane_id() == 0 && cw.total + unlisted) atomicAdd(&p.counters->cand_true, cw.total + unlisted);
 }
 
 // k_rare — stage A3: checksum validators (Base58Check, Bech32, EIP-55, Monero): very rare in logs and heavy in
@@ -1066,9 +1087,9 @@ __global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
             else if (kind == HEAVY_XMR) { if (val_monero(tb, tl, dec)) ty = IT_MONERO; }
             if (ty >= 0) { ct.start = ra.pos; ct.len_type = tl | ((uint32_t)ty << 24); em = true; }
         }
-        cw.append(em, ct, p.cands, p.cand_cap, &p.counters->n_cand);
+        cw.append(em, ct, p.cands, p.cand_cap, p.n_cand);
     }
-    cw.flush(p.cands, p.cand_cap, &p.counters->n_cand);
+    cw.flush(p.cands, p.cand_cap, p.n_cand);
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->cand_true, cw.total);
 }
 
@@ -1090,7 +1111,9 @@ void launch_validate_dom(const TokParams& p, const DevDb& db, int grid, hipStrea
 // k_validate (tokens, rare anchors, undecided domains: TokParams::vmode says which lists) has a fraction of the work and is
 // latency-bound: every workgroup stages the suffix tables first, so few workgroups (one per CU measured best for the whole job)
 void launch_validate_misc(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_validate, dim3(grid), dim3(256), 0, stream, p, db);
+    if (p.vmode == 1u) hipLaunchKernelGGL(k_validate<1u>, dim3(grid), dim3(256), 0, stream, p, db);
+    else if (p.vmode == 2u) hipLaunchKernelGGL(k_validate<2u>, dim3(grid), dim3(256), 0, stream, p, db);
+    else hipLaunchKernelGGL(k_validate<3u>, dim3(grid), dim3(256), 0, stream, p, db);
     check_launch("launch_validate_misc");
 }
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
