@@ -6,6 +6,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -150,11 +151,15 @@ bool read_file(const char* path, std::vector<uint8_t>& out) {
 
 matchy_t* open_bytes(std::vector<uint8_t>&& bytes) {
     try {
+        const bool trace = getenv("MATCHY_AMD_TRACE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
         auto db = std::make_unique<Db>();
         db->img = std::make_shared<DbImage>();
         std::string err;
         if (!db->img->open(std::move(bytes), err)) { set_error(err); return nullptr; }
         db->format = db->img->format_name();
+        if (trace) fprintf(stderr, "[matchy_amd] open: parsed and checked after %.1f ms\n", ms());
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
             set_error("matchy_amd: no HIP device available (this build has no CPU lookup path)");
@@ -165,7 +170,9 @@ matchy_t* open_bytes(std::vector<uint8_t>&& bytes) {
         if (const char* e = getenv("MATCHY_AMD_DEVICE")) dev0 = atoi(e);
         if (dev0 < 0 || dev0 >= ndev) { set_error("MATCHY_AMD_DEVICE out of range"); return nullptr; }
         db->default_device = dev0;
+        if (trace) { (void)hipSetDevice(dev0); (void)hipFree(nullptr); fprintf(stderr, "[matchy_amd] open: HIP runtime up after %.1f ms\n", ms()); }
         db->device_db(dev0);
+        if (trace) fprintf(stderr, "[matchy_amd] open: uploaded after %.1f ms\n", ms());
         return reinterpret_cast<matchy_t*>(db.release());
     } catch (const HipError& e) { set_error(e.what); return nullptr; }
     catch (const std::exception& e) { set_error(e.what()); return nullptr; }

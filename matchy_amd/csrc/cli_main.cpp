@@ -313,12 +313,27 @@ struct MatchPipeline {
     bool json = true;
     std::vector<std::string> sources;
 
-    void submit(Batch&& b) {
+    size_t submit(Batch&& b) {
         std::unique_lock<std::mutex> lk(mu);
         cv_space.wait(lk, [&] { return q.size() < max_q; });
-        b.seq = submitted++;
+        const size_t seq = b.seq = submitted++;
         q.push_back(std::move(b));
         cv_work.notify_one();
+        return seq;
+    }
+    // Mapped inputs: the mapping of a file is released by the printer as soon as the file's last batch has been printed — the
+    // page tables of a file of gigabytes take tens of milliseconds to tear down, and that runs beside the scans of the next
+    // files instead of behind the last one.
+    struct Mapping { void* p; size_t len; size_t last_seq; bool released; };
+    std::vector<Mapping> mappings;   // guarded by mu
+    void add_mapping(void* p, size_t len, size_t last_seq) { std::lock_guard<std::mutex> lk(mu); mappings.push_back({p, len, last_seq, false}); }
+    void release_mappings(size_t printed_below) {   // every batch with seq < printed_below is done
+        std::vector<Mapping> go;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (Mapping& m : mappings) if (!m.released && m.last_seq < printed_below) { m.released = true; go.push_back(m); }
+        }
+        for (const Mapping& m : go) munmap(m.p, m.len);
     }
     void close() { std::lock_guard<std::mutex> lk(mu); closed = true; cv_work.notify_all(); cv_done.notify_all(); }
 
@@ -326,12 +341,16 @@ struct MatchPipeline {
     void run_batch(matchy_scanner_t* sc, const Batch& b, Done& d) {
         d.input = b.input;
         if (!b.len) return;
+        static const bool trace = getenv("MATCHY_AMD_TRACE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
 #ifdef MADV_POPULATE_READ
         if (b.mapped) {   // pre-fault the batch's pages in one call (in the worker: the workers run side by side)
             const uintptr_t a = (uintptr_t)b.ptr & ~(uintptr_t)4095;
             (void)madvise((void*)a, (uintptr_t)b.ptr + b.len - a, MADV_POPULATE_READ);
         }
 #endif
+        const double t_pop = ms();
         matchy_scan_result_t r;
         memset(&r, 0, sizeof(r));
         if (matchy_scanner_scan(sc, b.ptr, b.len, &r) != MATCHY_SUCCESS) {
@@ -339,6 +358,7 @@ struct MatchPipeline {
             d.ok = false;
             return;
         }
+        const double t_scan = ms();
         Totals& t = d.t;
         t.lines += r.lines; t.candidates += r.candidates; t.bytes += b.len; t.matches += r.n_hits;
         // lines with matches: hits come sorted by offset; a new line starts when a '\n' lies between two hit starts
@@ -354,7 +374,9 @@ struct MatchPipeline {
                 if (line) { d.out += line; d.out.push_back('\n'); matchy_free_string(line); }
             }
         }
+        const double t_loop = ms();
         matchy_scan_result_free(&r);
+        if (trace) fprintf(stderr, "[matchy] batch %zu B: pre-fault %.3f ms, scan %.3f ms, hits loop %.3f ms, free %.3f ms\n", b.len, t_pop, t_scan - t_pop, t_loop - t_scan, ms() - t_loop);
     }
     void worker(matchy_scanner_t* sc) {
         for (;;) {
@@ -387,6 +409,7 @@ struct MatchPipeline {
                 done.erase(next);
             }
             ++next;
+            release_mappings(next);
             if (!d.out.empty()) fwrite(d.out.data(), 1, d.out.size(), stdout);
             total.lines += d.t.lines; total.lines_with_matches += d.t.lines_with_matches; total.matches += d.t.matches;
             total.candidates += d.t.candidates; total.bytes += d.t.bytes;
@@ -399,7 +422,7 @@ struct MatchPipeline {
 // (crates/matchy/src/file_reader.rs:45-75, by extension); "-" is stdin. Regular files are mapped and their batches are
 // views of the mapping (no copy on the host; each worker pre-faults its batch's pages). Returns false when
 // the input could not be read. Mappings go to `maps` and are released by the caller after the pipeline has drained.
-bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t batch_bytes, std::vector<std::pair<void*, size_t>>& maps) {
+bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t batch_bytes) {
     const bool gz = ends_with_ci(path, ".gz");
     int fd = path == "-" ? 0 : open(path.c_str(), O_RDONLY);
     if (fd < 0) { fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), strerror(errno)); return false; }
@@ -409,9 +432,9 @@ bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t
         void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
         if (m != MAP_FAILED) {
             close(fd);
-            maps.push_back({m, size});
             (void)madvise(m, size, MADV_SEQUENTIAL);
             const uint8_t* base = (const uint8_t*)m;
+            size_t last_seq = 0;
             for (size_t pos = 0; pos < size;) {
                 size_t end = std::min(size, pos + batch_bytes);
                 if (end < size) {   // newline-aligned cut; a line longer than the batch extends it to that line's end
@@ -424,9 +447,10 @@ bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t
                 }
                 Batch b;
                 b.input = input; b.ptr = base + pos; b.len = end - pos; b.mapped = true;
-                pl.submit(std::move(b));
+                last_seq = pl.submit(std::move(b));
                 pos = end;
             }
+            pl.add_mapping(m, size, last_seq);
             return true;
         }
     }
@@ -620,6 +644,9 @@ int cmd_match(int argc, char** argv) {
         db = matchy_open(dbpath.c_str());
     }
     if (!db) { fprintf(stderr, "Error: Failed to open database %s: %s\n", dbpath.c_str(), matchy_amd_last_error()); return 1; }
+    const bool trace = getenv("MATCHY_AMD_TRACE") != nullptr;
+    auto since0 = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    if (trace) fprintf(stderr, "[matchy] database open after %.1f ms\n", since0());
     uint32_t mask = 0;
     if (!extractors.empty()) {
         uint32_t auto_mask = 0;
@@ -640,6 +667,7 @@ int cmd_match(int argc, char** argv) {
         }
         scanners.push_back(sc);
     }
+    if (trace) fprintf(stderr, "[matchy] %zu scanner(s) created after %.1f ms\n", scanners.size(), since0());
     MatchPipeline pl;
     pl.json = format == "json";
     pl.max_q = scanners.size() + 1;
@@ -655,18 +683,18 @@ int cmd_match(int argc, char** argv) {
     }
     Totals t;
     std::vector<char> input_failed(paths.size(), 0);
-    std::vector<std::pair<void*, size_t>> maps;
     std::vector<std::thread> workers;
     for (auto* sc : scanners) workers.emplace_back([&pl, sc] { pl.worker(sc); });
     std::thread printer([&] { pl.printer(t, input_failed); });
     for (size_t i = 0; i < paths.size(); ++i)
-        if (!read_input(pl, i, paths[i], batch_bytes, maps)) input_failed[i] = 1;
+        if (!read_input(pl, i, paths[i], batch_bytes)) input_failed[i] = 1;
     pl.close();
     for (auto& w : workers) w.join();
     pl.close();   // wake the printer once more now that every batch is in `done`
     printer.join();
     fflush(stdout);
-    for (auto& mp : maps) munmap(mp.first, mp.second);
+    if (trace) fprintf(stderr, "[matchy] all batches done after %.1f ms\n", since0());
+    pl.release_mappings((size_t)-1);
     if (follow) follow_inputs(pl, scanners[0], paths, stats, t);
     size_t failed = 0;
     for (char f : input_failed) failed += f != 0;
@@ -693,6 +721,7 @@ int cmd_match(int argc, char** argv) {
     }
     for (auto* sc : scanners) matchy_scanner_free(sc);
     matchy_close(db);
+    if (trace) fprintf(stderr, "[matchy] cleaned up after %.1f ms\n", since0());
     if (failed) { fprintf(stderr, "Error: %zu file(s) failed to process\n", failed); return 1; }
     return 0;
 }

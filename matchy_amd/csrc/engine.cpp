@@ -186,120 +186,72 @@ void DeviceDb::upload(const DbImage& img, int dev) {
         bytes_uploaded += l1.size() * sizeof(uint2);
         // /24 occupancy bitmap (2 MiB): bit v is clear iff lookup_v4 of every address under prefix v ends in "not found"
         // within the first 24 levels. The streaming kernel drops such candidates right after validation (they are still
-        // counted), so only addresses that can hit reach k_lookup. Built by one depth-first walk of the top 24 levels.
+        // counted), so only addresses that can hit reach the lookups.
+        // First 24 levels as a direct table (2^24 entries, 128 MB of the 288 GB), and below a /24 that is not decided yet a LEAF
+        // table with the outcome for each of its 256 addresses (2 KB per such /24: 40 K host addresses are 80 MB, 900 K are
+        // 1.8 GB — what 288 GB of HBM are for): every IPv4 lookup is two dependent loads instead of 1 + up to 16. Entry kind 3 in
+        // the /24 table: y = leaf index. Leaf tables are capped at 16 GB (MATCHY_AMD_LEAF_MB); /24s beyond the cap keep kind 0
+        // (continue at node y: the reference's walk). All three are built on the device (ip_tables.hip): one walk per /24 and
+        // per leaf address over the tree that was uploaded above. Tiny trees (< 4096 nodes; MATCHY_AMD_L24=0 / 1 forces) do
+        // without the 128 MB table: 16-level table + walk, bitmap from the host.
+        bool want24 = img.node_count >= 4096;
+        if (const char* e = getenv("MATCHY_AMD_L24")) want24 = atoi(e) != 0 && img.node_count > 0;
         std::vector<uint32_t> bm(1u << 19, 0u);
-        if (img.node_count > 0) {
-            auto set_range = [&](uint32_t first, uint32_t count) {
-                for (uint32_t v = first; v < first + count;) {
-                    if ((v & 31) == 0 && v + 32 <= first + count) { bm[v >> 5] = 0xFFFFFFFFu; v += 32; }
-                    else { bm[v >> 5] |= 1u << (v & 31); ++v; }
-                }
-            };
-            struct Frame { uint32_t node, prefix, depth; };
-            std::vector<Frame> st;
-            st.push_back({v4_start, 0u, 0u});
-            while (!st.empty()) {
-                const Frame f = st.back();
-                st.pop_back();
-                const uint2 nd = nodes[f.node];
-                for (uint32_t bit = 0; bit < 2; ++bit) {
-                    const uint32_t rec = bit ? nd.y : nd.x;
-                    const uint32_t depth = f.depth + 1;                       // levels consumed
-                    const uint32_t prefix = f.prefix | (bit << (24 - depth));  // left-aligned in 24 bits
-                    if (rec == img.node_count) continue;
-                    if (rec < img.node_count) {
-                        if (depth == 24) set_range(prefix, 1);
-                        else st.push_back({rec, prefix, depth});
-                    } else if (rec - img.node_count >= 16) {
-                        set_range(prefix, 1u << (24 - depth));
-                    }
-                }
+        if (want24) {
+            ip_l24.alloc((size_t)1 << 24);
+            ip_bm24.alloc(bm.size());
+            DevBuf<uint32_t> ctr;
+            ctr.alloc(2);
+            MXY_HIP(hipMemset(ctr.p, 0, 8));
+            launch_ip_l24(ip_nodes.p, img.node_count, v4_start, ip_l24.p, ip_bm24.p, ctr.p, nullptr);
+            uint32_t undecided = 0;
+            MXY_HIP(hipMemcpy(&undecided, ctr.p, 4, hipMemcpyDeviceToHost));
+            size_t cap_leaf = ((size_t)16 << 30) / (256 * sizeof(uint2));
+            if (const char* e = getenv("MATCHY_AMD_LEAF_MB")) cap_leaf = ((size_t)atoll(e) << 20) / (256 * sizeof(uint2));
+            const size_t n_leaf = std::min<size_t>(undecided, cap_leaf);
+            if (n_leaf) {
+                ip_leaf.alloc(n_leaf * 256);
+                DevBuf<uint32_t> leaf_node;
+                leaf_node.alloc(n_leaf);
+                launch_ip_leaf(ip_nodes.p, img.node_count, ip_l24.p, ctr.p + 1, (uint32_t)n_leaf, leaf_node.p, ip_leaf.p, nullptr);
+                MXY_HIP(hipDeviceSynchronize());   // leaf_node is released below
+                view.ip_leaf = ip_leaf.p;
+                bytes_uploaded += n_leaf * 256 * sizeof(uint2);
             }
-        }
-        // First 24 levels as a direct table (2^24 entries, 128 MB of the 288 GB): a lookup is one load plus at most 8 dependent
-        // node loads instead of 1 + 16. Built when the tree is big enough for the walks to matter (MATCHY_AMD_L24=0 / 1 forces).
-        {
-            bool want = img.node_count >= 4096;
-            if (const char* e = getenv("MATCHY_AMD_L24")) want = atoi(e) != 0 && img.node_count > 0;
-            if (want) {
-                std::vector<uint2> l24((size_t)1 << 24, make_uint2(1u, 0u));
+            view.ip_l24 = ip_l24.p;
+            bytes_uploaded += ((size_t)1 << 24) * sizeof(uint2);
+            MXY_HIP(hipMemcpy(bm.data(), ip_bm24.p, bm.size() * 4, hipMemcpyDeviceToHost));   // for the statistics below
+        } else {
+            if (img.node_count > 0) {
+                auto set_range = [&](uint32_t first, uint32_t count) {
+                    for (uint32_t v = first; v < first + count;) {
+                        if ((v & 31) == 0 && v + 32 <= first + count) { bm[v >> 5] = 0xFFFFFFFFu; v += 32; }
+                        else { bm[v >> 5] |= 1u << (v & 31); ++v; }
+                    }
+                };
                 struct Frame { uint32_t node, prefix, depth; };
                 std::vector<Frame> st;
-                for (uint32_t v = 0; v < 65536; ++v) {
-                    const uint2 e = l1[v];
-                    if ((e.x & 0xFF) != 0) {   // decided within 16 levels: the 256 entries below repeat it
-                        if ((e.x & 0xFF) == 2) for (uint32_t k = 0; k < 256; ++k) l24[((size_t)v << 8) | k] = e;
-                        continue;
-                    }
-                    st.push_back({e.y, v << 8, 16u});
-                    while (!st.empty()) {
-                        const Frame f = st.back();
-                        st.pop_back();
-                        const uint2 nd = nodes[f.node];
-                        for (uint32_t bit = 0; bit < 2; ++bit) {
-                            const uint32_t rec = bit ? nd.y : nd.x;
-                            const uint32_t depth = f.depth + 1;
-                            const uint32_t prefix = f.prefix | (bit << (24 - depth));
-                            const uint32_t span = 1u << (24 - depth);
-                            if (rec == img.node_count) continue;
-                            if (rec < img.node_count) {
-                                if (depth == 24) l24[prefix] = make_uint2(0u, rec);
-                                else st.push_back({rec, prefix, depth});
-                            } else if (rec - img.node_count >= 16) {
-                                const uint2 found = make_uint2(2u | (depth << 8), rec - img.node_count - 16);
-                                for (uint32_t k = 0; k < span; ++k) l24[prefix + k] = found;
-                            }
+                st.push_back({v4_start, 0u, 0u});
+                while (!st.empty()) {
+                    const Frame f = st.back();
+                    st.pop_back();
+                    const uint2 nd = nodes[f.node];
+                    for (uint32_t bit = 0; bit < 2; ++bit) {
+                        const uint32_t rec = bit ? nd.y : nd.x;
+                        const uint32_t depth = f.depth + 1;                       // levels consumed
+                        const uint32_t prefix = f.prefix | (bit << (24 - depth));  // left-aligned in 24 bits
+                        if (rec == img.node_count) continue;
+                        if (rec < img.node_count) {
+                            if (depth == 24) set_range(prefix, 1);
+                            else st.push_back({rec, prefix, depth});
+                        } else if (rec - img.node_count >= 16) {
+                            set_range(prefix, 1u << (24 - depth));
                         }
                     }
                 }
-                // ... and below a /24 that is not decided yet: a LEAF table with the outcome for each of its 256 addresses (2 KB per
-                // such /24: 40 K host addresses are 80 MB, 900 K are 1.8 GB — what 288 GB of HBM are for), so that every IPv4
-                // lookup is exactly two dependent loads. Entry kind 3 in the /24 table: y = leaf index. Capped at 16 GB; /24s
-                // beyond the cap keep kind 0 (continue at node y: the reference's walk).
-                {
-                    size_t n_leaf = 0;
-                    for (const uint2& e : l24) n_leaf += (e.x & 0xFF) == 0;
-                    size_t cap_leaf = ((size_t)16 << 30) / (256 * sizeof(uint2));
-                    if (const char* e = getenv("MATCHY_AMD_LEAF_MB")) cap_leaf = ((size_t)atoll(e) << 20) / (256 * sizeof(uint2));
-                    n_leaf = std::min(n_leaf, cap_leaf);
-                    if (n_leaf) {
-                        std::vector<uint2> leaf(n_leaf * 256, make_uint2(1u, 0u));
-                        size_t next = 0;
-                        for (size_t v = 0; v < l24.size() && next < n_leaf; ++v) {
-                            if ((l24[v].x & 0xFF) != 0) continue;
-                            uint2* out = leaf.data() + next * 256;
-                            st.push_back({l24[v].y, 0u, 24u});
-                            while (!st.empty()) {
-                                const Frame f = st.back();
-                                st.pop_back();
-                                const uint2 nd = nodes[f.node];
-                                for (uint32_t bit = 0; bit < 2; ++bit) {
-                                    const uint32_t rec = bit ? nd.y : nd.x;
-                                    const uint32_t depth = f.depth + 1;                       // 25..32
-                                    const uint32_t prefix = f.prefix | (bit << (32 - depth));  // low 8 address bits, left-aligned
-                                    if (rec == img.node_count) continue;
-                                    if (rec < img.node_count) {
-                                        if (depth < 32) st.push_back({rec, prefix, depth});   // a node below bit 32 answers nothing (tree.rs:46-90)
-                                    } else if (rec - img.node_count >= 16) {
-                                        const uint2 found = make_uint2(2u | (depth << 8), rec - img.node_count - 16);
-                                        for (uint32_t k = 0, span = 1u << (32 - depth); k < span; ++k) out[prefix + k] = found;
-                                    }
-                                }
-                            }
-                            l24[v] = make_uint2(3u, (uint32_t)next);
-                            ++next;
-                        }
-                        ip_leaf.upload(leaf);
-                        view.ip_leaf = ip_leaf.p;
-                        bytes_uploaded += leaf.size() * sizeof(uint2);
-                    }
-                }
-                ip_l24.upload(l24);
-                view.ip_l24 = ip_l24.p;
-                bytes_uploaded += l24.size() * sizeof(uint2);
             }
+            ip_bm24.upload(bm);
         }
-        ip_bm24.upload(bm);
         view.ip_bm24 = ip_bm24.p;
         {
             uint64_t set = 0;
@@ -1131,10 +1083,44 @@ void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_
             n = (const uint8_t*)nl - (data + pos) + 1;
         }
         if (staging_.n < n + 16) staging_.alloc(n + 16 + n / 8);
-        if (n) MXY_HIP(hipMemcpyAsync(staging_.p, data + pos, n, hipMemcpyHostToDevice, host_stream_));
+        // Pageable host memory (a mapped file, a heap buffer) reaches the device through the runtime's own pinned staging at
+        // ~20 GB/s; pinned for the duration of the copy (hipHostRegister: ~5 ms per GB, tools/ubench/h2d_rate2.cpp) the DMA
+        // engine reads the pages themselves at the bus rate (~57 GB/s). Only whole pages inside the piece are registered —
+        // neighbouring pieces (other scanners working on the same mapping) never share a page of their registered ranges —
+        // the few bytes in front of and behind them travel as they did. Memory that is pinned already, small pieces and
+        // MATCHY_AMD_NO_REGISTER=1 take the plain copy.
+        const bool trace_h = getenv("MATCHY_AMD_TRACE") != nullptr;
+        const auto th0 = std::chrono::steady_clock::now();
+        auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+        const uint8_t* src = data + pos;
+        const uint8_t* reg_lo = nullptr;
+        size_t reg_len = 0;
+        static const bool no_reg = getenv("MATCHY_AMD_NO_REGISTER") != nullptr;
+        if (!no_reg && n >= ((size_t)4 << 20)) {
+            const uintptr_t a = ((uintptr_t)src + 4095) & ~(uintptr_t)4095, b = ((uintptr_t)src + n) & ~(uintptr_t)4095;
+            hipPointerAttribute_t attr;
+            const bool known = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type != hipMemoryTypeUnregistered;
+            (void)hipGetLastError();
+            if (!known && b > a && hipHostRegister((void*)a, b - a, hipHostRegisterDefault) == hipSuccess) { reg_lo = (const uint8_t*)a; reg_len = b - a; }
+            (void)hipGetLastError();
+        }
+        struct Unreg { const uint8_t* p; ~Unreg() { if (p) (void)hipHostUnregister((void*)p); } } unreg{reg_lo};
+        const double t_reg = ms_since(th0);
+        if (reg_lo) {
+            const size_t head = (size_t)(reg_lo - src), tail = n - head - reg_len;
+            if (head) MXY_HIP(hipMemcpyAsync(staging_.p, src, head, hipMemcpyHostToDevice, host_stream_));
+            MXY_HIP(hipMemcpyAsync(staging_.p + head, reg_lo, reg_len, hipMemcpyHostToDevice, host_stream_));
+            if (tail) MXY_HIP(hipMemcpyAsync(staging_.p + head + reg_len, reg_lo + reg_len, tail, hipMemcpyHostToDevice, host_stream_));
+        } else if (n) MXY_HIP(hipMemcpyAsync(staging_.p, src, n, hipMemcpyHostToDevice, host_stream_));
         scan_device(staging_.p, (uint32_t)n, lookup, host_stream_);
         ScanOutput part;
-        fetch(part, want_cands, host_stream_, lookup && fin ? HITS_FINAL : HITS_NONE, true);
+        const double t_launch = ms_since(th0);
+        fetch(part, want_cands, host_stream_, lookup && fin ? HITS_FINAL : HITS_NONE, true);   // synchronises the stream: the copy is done
+        if (trace_h) {
+            static const auto t_proc = std::chrono::steady_clock::now();
+            fprintf(stderr, "[matchy_amd] t=%.1f ms scan_host piece %zu B: registered %zu B in %.3f ms, launches done after %.3f ms, results after %.3f ms\n",
+                    ms_since(t_proc), n, reg_len, t_reg, t_launch, ms_since(th0));
+        }
         out.lines += part.lines; out.n_cand += part.n_cand; out.n_hits += part.n_hits;
         for (int t = 0; t < IT_COUNT; ++t) out.by_type[t] += part.by_type[t];
         if (fin && part.n_fin) {

@@ -24,6 +24,9 @@ void launch_lookup_ip(const LookupParams& p, const DevDb& db, int grid, bool den
 // k_lookup_spill over p.spill (launched by Scanner::fetch when a scan has spilled candidates); threads = spill_threads() per block
 void launch_lookup_spill(const LookupParams& p, const DevDb& db, hipStream_t stream);
 uint32_t spill_threads();
+// ip_tables.hip: the /24 table + /24 bitmap, and the leaf tables of the undecided /24s, built on the device from the uploaded tree
+void launch_ip_l24(const uint2* nodes, uint32_t node_count, uint32_t v4_start, uint2* l24, uint32_t* bm24, uint32_t* n_undecided, hipStream_t s);
+void launch_ip_leaf(const uint2* nodes, uint32_t node_count, uint2* l24, uint32_t* next, uint32_t n_leaf, uint32_t* leaf_node, uint2* leaf, hipStream_t s);
 
 struct HipError { std::string what; };
 #define MXY_HIP(expr)                                                                                   \
