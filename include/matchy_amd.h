@@ -304,6 +304,9 @@ const char *matchy_amd_last_error(void);
 /* Diagnostics: states of the flattened Aho-Corasick automaton on the handle's default device; 0 = the database has no glob
  * section or its automaton is walked node by node (flattened table above MATCHY_AMD_DFA_MAX_MB, default 8192), -1 = error. */
 int32_t matchy_amd_ac_dfa_states(const matchy_t *db);
+/* Diagnostics: 1 when the database's globs are all of the form *LITERAL with one common first byte ("*.evil.com" lists) and the
+ * scan decides glob candidates from hashed suffixes of a name instead of walking the automaton; 0 otherwise, -1 = error. */
+int32_t matchy_amd_suffix_filter(const matchy_t *db);
 /* HIP devices visible to the process (0 when there is none); `matchy match --devices all` */
 int32_t matchy_amd_device_count(void);
 /* Deterministic builds for tests: fixes the build_epoch metadata value. */

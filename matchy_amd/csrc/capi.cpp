@@ -233,6 +233,14 @@ int32_t matchy_amd_ac_dfa_states(const matchy_t* db_) {
         return (int32_t)std::min<uint32_t>(db->device_db(db->default_device)->view.dfa ? db->device_db(db->default_device)->view.dfa_states : 0u, 0x7FFFFFFFu);
     } catch (...) { return -1; }
 }
+int32_t matchy_amd_suffix_filter(const matchy_t* db_) {
+    if (!db_) return -1;
+    Db* db = const_cast<Db*>(reinterpret_cast<const Db*>(db_));
+    try {
+        std::lock_guard<std::mutex> lk(db->mu);
+        return db->device_db(db->default_device)->view.sfx_bm ? 1 : 0;
+    } catch (...) { return -1; }
+}
 int32_t matchy_amd_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;

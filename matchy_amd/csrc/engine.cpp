@@ -341,6 +341,51 @@ void DeviceDb::upload(const DbImage& img, int dev) {
             }
         }
         bytes_uploaded += pv.size() + (off.size() + ids.size()) * 4;
+        // Suffix filter (DevDb::sfx_bm): every pattern is star + literal of >= 3 bytes (shorter ones can never match: they get no
+        // automaton literal, Q8), all literals begin with the same byte, at most 4 different counts of that byte per literal.
+        if (view.dfa && view.wild_count == 0 && view.pattern_count && !getenv("MATCHY_AMD_NO_SUFFIX_FILTER")) {
+            const bool ci_db = img.match_mode == 1;
+            bool ok = true;
+            int first = -1;
+            uint32_t dots = 0;
+            std::vector<std::pair<uint32_t, uint32_t>> lits;   // (offset, length) in the paraglob buffer
+            for (uint32_t pid = 0; pid < view.pattern_count && ok; ++pid) {
+                const size_t io = (size_t)view.glob_seg_off + (size_t)pid * 8;
+                const uint32_t firsth = r32(io), count = r32(io + 4) & 0xFFFFu;
+                if (count != 2 || (size_t)firsth + 24 > img.pg_len) { ok = false; break; }
+                const uint8_t* h0 = pgp + firsth;
+                const uint8_t* h1 = pgp + firsth + 12;
+                uint32_t dlen, doff;
+                memcpy(&dlen, h1 + 4, 4); memcpy(&doff, h1 + 8, 4);
+                if (h0[0] != 1 || h1[0] != 0 || (size_t)doff + dlen > img.pg_len) { ok = false; break; }
+                if (dlen < 3) continue;   // never matches
+                const uint8_t* l = pgp + doff;
+                const int fb = ci_db ? (int)ascii_lower1(l[0]) : (int)l[0];
+                if (first < 0) first = fb;
+                if (fb != first) { ok = false; break; }
+                uint32_t d = 0;
+                for (uint32_t k = 0; k < dlen; ++k) d += (ci_db ? ascii_lower1(l[k]) : l[k]) == (uint32_t)first;
+                if (d > 32) { ok = false; break; }
+                dots |= 1u << (d - 1);
+                if (dlen <= 31) lits.push_back({doff, dlen});   // a longer literal cannot end a name of <= 31 bytes (the ones decided here)
+            }
+            if (ok && first >= 0 && __builtin_popcount(dots) <= 4) {
+                size_t bits = (size_t)1 << 16;
+                while (bits < lits.size() * 64 && bits < ((size_t)1 << 31)) bits <<= 1;
+                std::vector<uint32_t> bm(bits / 32, 0u);
+                const uint32_t bmask = (uint32_t)(bits - 1);
+                for (auto& ol : lits) {
+                    uint64_t lane[4] = {0, 0, 0, 0};
+                    memcpy(lane, pgp + ol.first, ol.second);
+                    if (ci_db) for (uint64_t& w : lane) w = ascii_lower8(w);
+                    const uint32_t b = name_hash31(lane[0], lane[1], lane[2], lane[3], ol.second) & bmask;
+                    bm[b >> 5] |= 1u << (b & 31);
+                }
+                sfx_bm.upload(bm);
+                view.sfx_bm = sfx_bm.p; view.sfx_mask = bmask; view.sfx_first = (uint32_t)first; view.sfx_dots = dots;
+                bytes_uploaded += bm.size() * 4;
+            }
+        }
     }
     view.ci = img.match_mode == 1 ? 1u : 0u;
     if (view.ci) {

@@ -69,7 +69,7 @@ struct DeviceDb {
     int device = 0;
     DevDb view{};
     DevBuf<uint2> ip_nodes, ip_l1, ip_l24, ip_leaf;
-    DevBuf<uint32_t> ip_bm24, lit_bm;
+    DevBuf<uint32_t> ip_bm24, lit_bm, sfx_bm;
     DevBuf<uint2> tld_tab;
     DevBuf<uint32_t> dfa, dfa_node;
     DevBuf<uint8_t> dfa_cls;

@@ -705,7 +705,8 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
                 uint32_t off, pfx;
                 if (db.has_ip && d_parse_ipv6(text, tl, seg) && trie_v6(db, seg, off, pfx)) { h.kind = 2; h.a = off; h.prefix_len = (uint8_t)pfx; emit = true; }
             } else {
-                if (!GLOB && p.ac_filter && ac_touches_output(db, dv, text, tl)) defer = true;
+                // producers that know already (k_validate_dom's suffix filter) say so in the candidate: no automaton walk then
+                if (!GLOB && p.ac_filter && (c.pad == CAND_GLOB || (c.pad != CAND_NO_GLOB && ac_touches_output(db, dv, text, tl)))) defer = true;
                 else {
                     uint32_t pid = 0xFFFFFFFFu;
                     if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q)) pid = q; }

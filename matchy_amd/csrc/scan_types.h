@@ -22,8 +22,10 @@ struct Candidate {
     uint32_t start;      // byte offset in the scanned buffer
     uint32_t len_type;   // length in bits 0..23, ItemType in bits 24..31
     uint32_t v4;         // IPv4 address (host order) for IT_IPV4, else 0
-    uint32_t pad;
+    uint32_t pad;        // string candidates of databases with globs: what the producer already knows — 0 nothing (the lookup walks the
+                         // automaton), CAND_NO_GLOB no glob can match, CAND_GLOB some glob may (straight to the glob pass)
 };
+constexpr uint32_t CAND_NO_GLOB = 1, CAND_GLOB = 2;
 
 // Anchors that need the rare-path validators (IPv6, e-mail, hash / crypto tokens), 8 bytes.
 enum RareKind : uint32_t { RARE_V6 = 0, RARE_AT = 1, RARE_TOK = 2, HEAVY_B58 = 3, HEAVY_BECH32 = 4, HEAVY_ETH = 5, HEAVY_XMR = 6, RARE_DOM = 7 };
@@ -90,6 +92,15 @@ struct DevDb {
     const uint32_t* dfa_node;
     uint32_t dfa_k;
     uint32_t dfa_states;          // number of states; they are numbered breadth-first, so the first rows are the shallowest
+    // Suffix filter (databases whose globs are all of the form *LITERAL with one common first byte, e.g. "*.evil.com": what
+    // indicator feeds hold): a glob can only match a name that ENDS with its literal, and the literal then starts at the d-th
+    // occurrence of its first byte counted from the end of the name, d = occurrences of that byte in the literal. sfx_bm is a
+    // bitmap over name_hash31 of the literals (<= 31 bytes; ASCII-folded for case-insensitive databases), sfx_first the byte,
+    // sfx_dots bit d-1 set for every d that occurs. k_validate_dom tests <= 4 suffixes per name instead of walking the automaton.
+    const uint32_t* sfx_bm;       // null: no suffix filter for this database
+    uint32_t sfx_mask;
+    uint32_t sfx_first;
+    uint32_t sfx_dots;
     const uint32_t* lit2pat_off;  // [n_ac_lits + 1]
     const uint32_t* lit2pat;
     uint32_t n_ac_lits;

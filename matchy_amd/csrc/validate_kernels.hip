@@ -771,8 +771,11 @@ __device__ bool val_eth(const uint8_t* a, uint8_t* lower) {  // ext:1328-1361, 1
 // AC (p.filter_ac): databases with globs — a name is listed if its hash is in the literal bitmap or its text reaches an output
 // state of the glob automaton (walked here from the context bytes, shallow rows in LDS), so k_lookup does not have to fetch
 // the text of every valid name from the log again.
-template <bool AC>
+// MODE 2 (DevDb::sfx_bm): databases whose globs are all *LITERAL — the name must END with a literal, which a few hashed suffixes
+// decide (no automaton walk, no chain of dependent look-ups); the candidate carries the verdict (Candidate::pad).
+template <int MODE>
 __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
+    constexpr bool AC = MODE == 1, SFX = MODE == 2;
     __shared__ uint2 tldtab[1u << TLD_TAB_BITS];
     __shared__ __attribute__((aligned(16))) uint32_t strbuf[256][8];   // per-lane context bytes for hashing
     __shared__ uint8_t dcls[AC ? 256 : 4];
@@ -815,12 +818,26 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
     // those loads (vmcnt counts loads and stores in order) then never waits for a store in flight. The same delay gives
     // the literal-bitmap load (p.filter_lit) a whole iteration to arrive.
     uint32_t pend_start = 0, pend_lt = 0, pend_word = 0xFFFFFFFFu, pend_bit = 0, n_valid = 0;
-    bool pend = false;
+    uint32_t pend_sw[SFX ? 4 : 1] = {0}, pend_sb[SFX ? 4 : 1] = {0};   // suffix filter: bitmap words in flight and their bits
+    bool pend = false, pend_over = false;
     uint32_t* sb = strbuf[threadIdx.x];
+    // the candidate of the previous iteration: listed if a literal key or (databases with globs) a glob can match it
+    auto emit_pending = [&]() {
+        if (!p.filter_lit) { cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, p.n_cand, SC); return; }
+        bool lit = (pend_word >> pend_bit) & 1;
+        uint32_t flag = 0;
+        if constexpr (SFX) {
+            bool g = pend_over;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g = g || ((pend_sw[q] >> pend_sb[q]) & 1);
+            flag = g ? CAND_GLOB : CAND_NO_GLOB;
+            lit = lit || g;
+        }
+        cw.append(pend && lit, Candidate{pend_start, pend_lt, 0u, flag}, p.cands, p.cand_cap, p.n_cand);
+    };
     for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
         const uint32_t i = base + threadIdx.x;
-        if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, p.n_cand);
-        else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, p.n_cand, SC);
+        emit_pending();
         pend = false;
         load_rec(i + stride, nxt);
         bool slow = false;
@@ -859,6 +876,52 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
                     const uint32_t b = name_hash31(ln[0], ln[1], ln[2], ln[3], n) & db.lit_bm_mask;
                     pend_word = db.lit_bm ? db.lit_bm[b >> 5] : 0u;
                     pend_bit = b & 31;
+                    if constexpr (SFX) {
+                        // positions of the literals' first byte inside the name (bit k <-> byte k), from byte-lane SWAR on the name
+                        const uint64_t fb = 0x0101010101010101ull * db.sfx_first;
+                        uint32_t M = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint64_t x = ln[k] ^ fb;
+                            const uint64_t z = ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull;   // bit 7 of the bytes that are equal
+                            const uint32_t lo = (uint32_t)z >> 7, hi = (uint32_t)(z >> 32) >> 7;
+                            M |= ((((lo * 0x01020408u) >> 24) & 0xFu) | ((((hi * 0x01020408u) >> 24) & 0xFu) << 4)) << (8 * k);
+                        }
+                        M &= n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+                        pend_over = false;
+                        uint32_t dm = db.sfx_dots;   // wave-uniform
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            pend_sw[q] = 0; pend_sb[q] = 0;
+                            if (dm) {   // uniform
+                                const uint32_t d = (uint32_t)__builtin_ctz(dm) + 1;
+                                dm &= dm - 1;
+                                uint32_t m = M;
+                                for (uint32_t j = 1; j < d; ++j) m &= ~(m ? (0x80000000u >> __builtin_clz(m)) : 0u);   // drop the d-1 last occurrences
+                                if (m) {
+                                    const uint32_t kk = 31u - (uint32_t)__builtin_clz(m), sl = n - kk;   // the suffix starts at byte kk
+                                    if (sl >= 3) {
+                                        const uint32_t o2 = o + kk, j0 = o2 >> 2, s2 = o2 & 3;
+                                        uint32_t w2[9];
+#pragma unroll
+                                        for (int k = 0; k < 9; ++k) w2[k] = (j0 + k) < 8 ? sb[(j0 + k) & 7] : 0u;
+                                        uint64_t l2[4];
+#pragma unroll
+                                        for (int k = 0; k < 4; ++k)
+                                            l2[k] = (uint64_t)__builtin_amdgcn_alignbyte(w2[2 * k + 1], w2[2 * k], s2) |
+                                                    ((uint64_t)__builtin_amdgcn_alignbyte(w2[2 * k + 2], w2[2 * k + 1], s2) << 32);
+                                        if (db.ci) {
+#pragma unroll
+                                            for (int k = 0; k < 4; ++k) l2[k] = ascii_lower8(l2[k]);
+                                        }
+                                        const uint32_t b2 = name_hash31(l2[0], l2[1], l2[2], l2[3], sl) & db.sfx_mask;
+                                        pend_sw[q] = db.sfx_bm[b2 >> 5];
+                                        pend_sb[q] = b2 & 31;
+                                    }
+                                }
+                            }
+                        }
+                    }
                     if constexpr (AC) {
                         // the name is in ln[] already: byte -> class look-ups do not depend on the state and go out
                         // together, the chain is one LDS row look-up per byte
@@ -880,8 +943,7 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
         sw.append(slow, RareAnchor{cur.j & 0x7FFFFFFFu, (uint32_t)RARE_DOM}, p.rare_dom, p.rare_dom_cap, &p.counters->n_rare_dom);
         cur = nxt;
     }
-    if (p.filter_lit) cw.append(pend && ((pend_word >> pend_bit) & 1), Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, p.n_cand);
-    else cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, p.n_cand, SC);
+    emit_pending();
     cw.flush(p.cands, p.cand_cap, p.n_cand);
     cw_dense.pad_rest(p.cands, p.cand_cap, SC);
     sw.flush(p.rare_dom, p.rare_dom_cap, &p.counters->n_rare_dom);
@@ -1096,16 +1158,17 @@ __global__ __launch_bounds__(64) void k_rare(TokParams p, DevDb db) {
 // ------------------------------------------------------------------------------------------------ launch wrappers
 int validate_blocks_per_cu(bool ac) {
     int n = 0;
-    const hipError_t e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate_dom<true>, 256, 0)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate_dom<false>, 256, 0);
+    const hipError_t e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate_dom<1>, 256, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_validate_dom<0>, 256, 0);
     if (e != hipSuccess || n < 1) n = ac ? 3 : 4;
     return n;
 }
 // grid = workgroups of k_validate_dom
 void launch_validate_dom(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
     if (!(p.flags & EX_DOMAINS)) return;
-    if (p.filter_ac) hipLaunchKernelGGL(k_validate_dom<true>, dim3(grid), dim3(256), 0, stream, p, db);
-    else hipLaunchKernelGGL(k_validate_dom<false>, dim3(grid), dim3(256), 0, stream, p, db);
+    if (p.filter_ac && db.sfx_bm) hipLaunchKernelGGL(k_validate_dom<2>, dim3(grid), dim3(256), 0, stream, p, db);
+    else if (p.filter_ac) hipLaunchKernelGGL(k_validate_dom<1>, dim3(grid), dim3(256), 0, stream, p, db);
+    else hipLaunchKernelGGL(k_validate_dom<0>, dim3(grid), dim3(256), 0, stream, p, db);
     check_launch("launch_validate_dom");
 }
 // k_validate (tokens, rare anchors, undecided domains: TokParams::vmode says which lists) has a fraction of the work and is

@@ -1047,3 +1047,60 @@ print("WIDE-OK", seen, len(hits))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "WIDE-OK" in out.stdout
+
+
+@pytest.mark.parametrize("ci", [False, True])
+@pytest.mark.parametrize("first", [".", "-"])
+def test_suffix_globs_take_the_suffix_filter(M, oracle, ci, first):
+    """Databases whose globs are all *LITERAL with one common first byte (what "*.domain" indicator lists are): k_validate_dom
+    decides from a few hashed suffixes of the name whether a glob can match (DevDb::sfx_bm) instead of walking the automaton, and
+    tells the lookup pass (Candidate::pad). Names that end with a literal, contain one in the middle, equal it without the leading
+    byte, differ in case; literals with one, two and three occurrences of the first byte; a literal of 33 bytes (cannot end a short
+    name) and one of 2 bytes (never matches, Q8); literal keys beside the globs. Scan (both entries) and queries vs the oracle."""
+    rng = random.Random(99 + ci)
+    f = first
+    lits = [f"{f}evil{i}.com" for i in range(40)] + [f"{f}a{f}bad{i}.net" for i in range(20)] + [f"{f}x{f}y{f}deep{i}.org" for i in range(10)] + \
+           [f"{f}co", f"{f}" + "long" * 8 + ".com", f"{f}Mixed{f}Case.io"]
+    b = M.DatabaseBuilder(build_epoch=9, case_insensitive=ci)
+    for i, l in enumerate(lits):
+        b.add_entry("*" + l, {"g": i})
+    b.add_entry("plain-key.example.com", {"lit": 1})
+    b.add_entry("evil3.com", {"lit": 2})            # a literal key that is also the tail of a glob literal
+    blob = b.build()
+    b.close()
+    names = []
+    for l in lits:
+        tail = l[1:] if f == "." else l
+        for pre in ("www", "a.b", "x-y", "WWW", ""):
+            names.append(pre + l)                    # ends with the literal
+        names.append(tail)                           # the literal without its first byte: no match for "." literals
+        names.append("www" + l + ".attacker.net")    # literal in the middle
+        names.append("www" + l.upper())
+        names.append("www" + l[:-1] + "x")
+    names += ["plain-key.example.com", "evil3.com", "host.evil3.com", "evil3.com.evil4.com", "a.b.c.d.e.f.g.evil5.com", "nothing.example.org"]
+    rng.shuffle(names)
+    log = b"".join(rng.choice([b"GET http://", b"host=", b" "]) + nm.encode() + rng.choice([b"/x ", b" ", b"\n", b"\" "]) for nm in names) + b"\n"
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, log)
+    assert gs == ws
+    assert gh == wh
+    assert gl == wl
+    assert len(gh) > 150
+    db = M.Database(blob)
+    assert M.lib().matchy_amd_suffix_filter(db.handle) == 1      # the suffix filter really is what ran
+    odb = oracle.Database(blob)
+    for nm in names:
+        want, got = odb.lookup(nm), db.lookup(nm)
+        if want["kind"] == "pattern" and want["data"] and want["data"][0] is not None:
+            assert got == {"found": True, "prefix_len": 0, "data": want["data"][0]}, nm
+        elif want["kind"] != "pattern":
+            assert got is None, (nm, got)
+    db.close()
+    # one glob of another shape (prefix) and the database takes the automaton walk again
+    b = M.DatabaseBuilder(build_epoch=9, case_insensitive=ci)
+    for i, l in enumerate(lits[:5]):
+        b.add_entry("*" + l, {"g": i})
+    b.add_entry("evil*", {"p": 1})
+    db = M.Database(b.build())
+    b.close()
+    assert M.lib().matchy_amd_suffix_filter(db.handle) == 0
+    db.close()
