@@ -10,6 +10,7 @@ There is no CPU fallback anywhere in this package: if libmatchy_amd.so is missin
 layer raises, and without a HIP device Database()/Extractor() raise RuntimeError.
 """
 import ctypes as C
+import os
 import json
 from pathlib import Path
 
@@ -102,9 +103,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
-        raise ImportError(f"{LIB_PATH} is missing: run `python -m matchy_amd.build` (hipcc, gfx950) first")
-    L = C.CDLL(str(LIB_PATH))
+    # MATCHY_AMD_LIB: another build of the same library (kernel A/B experiments: tools/ab.sh); never a fallback
+    path = Path(os.environ["MATCHY_AMD_LIB"]) if os.environ.get("MATCHY_AMD_LIB") else LIB_PATH
+    if not path.exists():
+        raise ImportError(f"{path} is missing: run `python -m matchy_amd.build` (hipcc, gfx950) first")
+    L = C.CDLL(str(path))
     vp, cp, u8p = C.c_void_p, C.c_char_p, C.POINTER(C.c_uint8)
     sig = {
         "matchy_builder_new": (vp, []),

@@ -199,14 +199,18 @@ struct DomWriter {
             if (base + k < cap) out[dom_plane_index(base + k, 0)] = 0xFFFFFFFFu;
         used = ANCHOR_CHUNK;
     }
-    // all lanes of the converged wave call this; returns the lane's slot, or 0xFFFFFFFF (not emitting / list full)
-    __device__ __forceinline__ uint32_t reserve(bool emit, uint32_t* out, uint32_t cap, uint32_t* counter) {
+    // all lanes of the converged wave call this; returns the lane's slot, or 0xFFFFFFFF (not emitting / list full).
+    // counter_fn() yields the list counter: it is called only when a new chunk is needed (once per ANCHOR_CHUNK entries), so the
+    // caller can fetch the pointer there instead of holding it in registers
+    template <class F>
+    __device__ __forceinline__ uint32_t reserve(bool emit, uint32_t* out, uint32_t cap, F counter_fn) {
         const uint64_t m = __ballot(emit);
         if (m == 0) return 0xFFFFFFFFu;
         const uint32_t n = (uint32_t)__popcll(m);
         if (base == 0xFFFFFFFFu || used + n > ANCHOR_CHUNK) {
             pad_rest(out, cap);
             uint32_t b = 0;
+            uint32_t* const counter = counter_fn();
             if (lane_id() == 0) b = atomicAdd(counter, ANCHOR_CHUNK);
             base = __builtin_amdgcn_readfirstlane(b);
             used = 0;

@@ -10,23 +10,24 @@ namespace mxy {
 // (DevDb::ip_l24, 128 MB, when the tree is big enough to pay for it) and, for a /24 with entries below it, a leaf table with the
 // outcome for each of its 256 addresses (ip_leaf) — two dependent loads per lookup. Small trees: the first 16 levels (ip_l1) and
 // the reference's walk, one dependent 8-byte load per level.
-__device__ __forceinline__ bool trie_v4(const DevDb& db, uint32_t addr, uint32_t& data_off, uint32_t& prefix) {
-    uint2 e = db.ip_l24 ? db.ip_l24[addr >> 8] : db.ip_l1[addr >> 16];
+struct IpTables { const uint2* l24; const uint2* l1; const uint2* leaf; const uint2* nodes; uint32_t node_count; };
+__device__ __forceinline__ bool trie_v4_tables(const IpTables& t, uint32_t addr, uint32_t& data_off, uint32_t& prefix) {
+    uint2 e = t.l24 ? t.l24[addr >> 8] : t.l1[addr >> 16];
     uint32_t kind = e.x & 0xFF;
     if (kind == 3) {   // leaf table of this /24: the outcome for each of its 256 addresses
-        e = db.ip_leaf[((size_t)e.y << 8) | (addr & 0xFFu)];
+        e = t.leaf[((size_t)e.y << 8) | (addr & 0xFFu)];
         kind = e.x & 0xFF;
     }
     if (kind == 1) return false;
     if (kind == 2) { data_off = e.y; prefix = e.x >> 8; return true; }
     uint32_t node = e.y;
-    for (int bi = db.ip_l24 ? 24 : 16; bi < 32; ++bi) {
-        const uint2 nd = db.ip_nodes[node];
+    for (int bi = t.l24 ? 24 : 16; bi < 32; ++bi) {
+        const uint2 nd = t.nodes[node];
         const uint32_t rec = ((addr >> (31 - bi)) & 1) ? nd.y : nd.x;
-        if (rec == db.node_count) return false;
-        if (rec < db.node_count) node = rec;
+        if (rec == t.node_count) return false;
+        if (rec < t.node_count) node = rec;
         else {
-            const uint32_t off = rec - db.node_count;
+            const uint32_t off = rec - t.node_count;
             if (off < 16) return false;  // reference: MmdbError -> lookup error; treated as not found (never produced by builders)
             data_off = off - 16;
             prefix = (uint32_t)bi + 1;   // tree:76-80: depth counts from 96 in v6 trees and 96 is subtracted again
@@ -34,6 +35,9 @@ __device__ __forceinline__ bool trie_v4(const DevDb& db, uint32_t addr, uint32_t
         }
     }
     return false;
+}
+__device__ __forceinline__ bool trie_v4(const DevDb& db, uint32_t addr, uint32_t& data_off, uint32_t& prefix) {
+    return trie_v4_tables(IpTables{db.ip_l24, db.ip_l1, db.ip_leaf, db.ip_nodes, db.node_count}, addr, data_off, prefix);
 }
 
 // Rust `<Ipv6Addr as FromStr>` restricted to [0-9A-Fa-f:] input (no embedded IPv4 possible): read_ipv6_addr.

@@ -109,11 +109,72 @@ struct PendingV4 {
 // and at the end of the wave's work — one lane per entry walks the trie (trie_v4: first-levels table + at most 8 / 16 dependent
 // node loads) and the hits leave as final records: one atomic on the record counter per flush, device array + pinned host mirror
 // like pack_pending in lookup_kernels.hip. A few flushes per wave and batch; the other waves of the SIMD cover the load latency.
+// Parameters of the COLD paths (list flushes, the inline lookups: a few times per thousand blocks) are read from the kernel-argument
+// segment where they are needed instead of living in scalar registers through the block loop: the loop is short of them (the
+// compiler was spilling two dozen to vector-register lanes per block — v_readlane / v_writelane on the vector pipe this kernel is
+// bound by). The empty asm makes the pointer opaque, so the loads stay where the code is.
+typedef const TokParams __attribute__((address_space(4)))* ColdTok;
+typedef const DevDb __attribute__((address_space(4)))* ColdDb;
+__device__ __forceinline__ ColdTok cold_tok() {
+    ColdTok q = (ColdTok)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return q;
+}
+__device__ __forceinline__ ColdDb cold_db() {   // k_anchor(TokParams, DevDb): the second argument follows the first
+    static_assert(sizeof(TokParams) % 8 == 0 && alignof(DevDb) == 8, "kernel-argument layout");
+    ColdTok q = cold_tok();
+    return (ColdDb)((const char __attribute__((address_space(4)))*)q + sizeof(TokParams));
+}
+
+// BufferedWriter (device_common.h) for k_anchor's two sparse lists, with the destination (list, capacity, counter) fetched from
+// the kernel arguments when a flush happens instead of being passed — and kept in scalar registers — at every append.
+// WHICH: 0 = rare anchors (IPv6 / e-mail), 1 = long tokens.
+template <int WHICH>
+struct SparseWriter {
+    uint2* buf;          // RARE_STAGE entries of LDS owned by this wave
+    uint32_t cnt = 0;    // wave-uniform
+    __device__ __forceinline__ explicit SparseWriter(uint2* lds) : buf(lds) {}
+    struct Dest { uint2* out; uint32_t cap; uint32_t* counter; };
+    __device__ __forceinline__ static Dest dest() {
+        const ColdTok kp = cold_tok();
+        if (WHICH == 0) return Dest{reinterpret_cast<uint2*>(kp->rare), kp->rare_cap, &kp->counters->n_rare};
+        return Dest{reinterpret_cast<uint2*>(kp->tok), kp->tok_cap, &kp->counters->n_tok};
+    }
+    __device__ __forceinline__ void flush() {
+        if (cnt == 0) return;
+        const Dest d = dest();
+        uint32_t b = 0;
+        if (lane_id() == 0) b = atomicAdd(d.counter, cnt);
+        b = __builtin_amdgcn_readfirstlane(b);
+        __builtin_amdgcn_wave_barrier();
+        if (lane_id() < cnt && b + lane_id() < d.cap) d.out[b + lane_id()] = buf[lane_id()];
+        __builtin_amdgcn_wave_barrier();
+        cnt = 0;
+    }
+    // all lanes of the (converged) wave call this
+    __device__ __forceinline__ void append(bool emit, const uint2& v) {
+        const uint64_t m = __ballot(emit);
+        if (m == 0) return;
+        const uint32_t n = (uint32_t)__popcll(m);
+        const uint32_t rank = mbcnt64(m);
+        if (n > RARE_STAGE) {   // more entries than the stage holds (dense phases): they leave directly, one atomic for all of them
+            const Dest d = dest();
+            uint32_t b = 0;
+            if (lane_id() == 0) b = atomicAdd(d.counter, n);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (emit && b + rank < d.cap) d.out[b + rank] = v;
+            return;
+        }
+        if (cnt + n > RARE_STAGE) flush();
+        if (emit) buf[cnt + rank] = v;
+        cnt += n;
+    }
+};
+
 constexpr uint32_t V4_STAGE = CAND_STAGE * sizeof(Candidate) / sizeof(uint2);
 struct V4Lookup {
     uint2* stage;        // V4_STAGE entries of LDS owned by this wave (the CandWriter's buffer)
     uint32_t cnt = 0;    // wave-uniform
-    const DevDb* db;
 };
 // length of the canonical dotted-quad text of an address (what the extractor accepted: no leading zeros)
 __device__ __forceinline__ uint32_t v4_text_len(uint32_t a) {
@@ -122,7 +183,7 @@ __device__ __forceinline__ uint32_t v4_text_len(uint32_t a) {
     for (int k = 0; k < 4; ++k) { const uint32_t o = (a >> (8 * k)) & 0xFF; n += (o > 9) + (o > 99); }
     return n;
 }
-__device__ __forceinline__ void v4_lookup_flush(V4Lookup& vl, const TokParams& p) {
+__device__ __forceinline__ void v4_lookup_flush(V4Lookup& vl) {
     if (vl.cnt == 0) return;
     const uint32_t lane = lane_id();
     __builtin_amdgcn_wave_barrier();
@@ -130,20 +191,26 @@ __device__ __forceinline__ void v4_lookup_flush(V4Lookup& vl, const TokParams& p
     uint2 e = make_uint2(0u, 0u);
     if (have) e = vl.stage[lane];
     uint32_t off = 0, pfx = 0;
-    const bool hit = have && trie_v4(*vl.db, e.y, off, pfx);
+    const ColdDb kd = cold_db();
+    const IpTables tabs{kd->ip_l24, kd->ip_l1, kd->ip_leaf, kd->ip_nodes, kd->node_count};
+    const bool hit = have && trie_v4_tables(tabs, e.y, off, pfx);
     const uint64_t m = __ballot(hit);
     if (m) {
-        const PackParams& pp = p.pk;
+        const ColdTok kp = cold_tok();
+        ScanCounters* const ctr = kp->pk.counters;
+        FinalHit* const out = kp->pk.out;
+        FinalHit* const host_out = kp->pk.host_out;
+        const uint32_t out_cap = kp->pk.out_cap, host_cap = kp->pk.host_cap;
         uint32_t slot0 = 0;
-        if (lane == 0) slot0 = atomicAdd(&pp.counters->n_final, (uint32_t)__popcll(m));
+        if (lane == 0) slot0 = atomicAdd(&ctr->n_final, (uint32_t)__popcll(m));
         slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
         if (hit) {
             const uint32_t slot = slot0 + mbcnt64(m);
             FinalHit f{};
             f.start = e.x; f.len_type = v4_text_len(e.y) | ((uint32_t)IT_IPV4 << 24);
             f.value = off; f.kind = 2; f.prefix_len = (uint8_t)pfx; f.n_ids = 0;
-            if (slot < pp.out_cap) pp.out[slot] = f;
-            if (slot < pp.host_cap) pp.host_out[slot] = f;
+            if (slot < out_cap) out[slot] = f;
+            if (slot < host_cap) host_out[slot] = f;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -164,7 +231,7 @@ __device__ __forceinline__ void commit_v4(PendingV4& pd, const WaveCtx& cx, Cand
                 if (emit && idx >= 0 && idx < (int32_t)V4_STAGE) vl.stage[idx] = make_uint2(pd.c.start, pd.c.v4);
                 if (total < V4_STAGE) { vl.cnt = total; break; }
                 vl.cnt = V4_STAGE;
-                v4_lookup_flush(vl, p);
+                v4_lookup_flush(vl);
                 idx -= (int32_t)V4_STAGE;
                 total -= V4_STAGE;
             }
@@ -329,7 +396,7 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
             }
         }
     }
-    const uint32_t slot = dw.reserve(keep, p.dom_list, p.dom_cap, &p.counters->n_dom);
+    const uint32_t slot = dw.reserve(keep, p.dom_list, p.dom_cap, [] { return &cold_tok()->counters->n_dom; });
     if (slot != 0xFFFFFFFFu) {
         uint32_t* rec = p.dom_list + dom_plane_index(slot, 0);   // the planes of a 64-slot tile are 256 bytes apart
         rec[0] = have_ctx ? j : (j | 0x80000000u);
@@ -407,11 +474,10 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0;   // ring heads / tails (wave-uniform)
     uint32_t v4_old = 0, dom_old = 0;            // block start of the oldest ring entry (valid while the ring is non-empty)
     CandWriter cw_cand(wb_cand[wave], p.cand_chunk);   // IPv4 candidates: sparse when the /24 bitmap filters, else one per line
-    V4Lookup vl{reinterpret_cast<uint2*>(wb_cand[wave]), 0u, &db};   // TokParams::inline_v4: the same LDS holds {start, address} pairs
+    V4Lookup vl{reinterpret_cast<uint2*>(wb_cand[wave]), 0u};   // TokParams::inline_v4: the same LDS holds {start, address} pairs
     DomWriter cw_dom;
-    RareWriter cw_misc(wb_misc[wave]), cw_tok(wb_tok[wave]);   // rare anchors and long tokens are sparse: dense lists
-    uint2* rare_out = reinterpret_cast<uint2*>(p.rare);
-    uint2* tok_out = reinterpret_cast<uint2*>(p.tok);
+    SparseWriter<0> cw_misc(wb_misc[wave]);   // rare anchors and long tokens are sparse: dense lists
+    SparseWriter<1> cw_tok(wb_tok[wave]);
     WaveCtx cx{&p, raw32, ctab, bloom, db.ip_bm24, 0u, 0u};
     PendingV4 pend;
     const uint32_t lane_off = lane << 2;
@@ -442,11 +508,13 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         }
     };
 
-    for (uint32_t seg = gw; seg < p.n_segs; seg += nw) {
-        const uint32_t seg_start = p.seg_base + seg * p.seg_bytes;
+    for (uint32_t seg = gw;; seg += nw) {
+        const ColdTok ks = cold_tok();   // the segment geometry is needed once per segment: not held through the block loop
+        if (seg >= ks->n_segs) break;
+        const uint32_t seg_start = ks->seg_base + seg * ks->seg_bytes;
         // positions 0..len are scanned: position `len` (padding, class "boundary") closes a trailing token (scan_end = len + 1
         // for the launch that covers the end of the batch)
-        const uint32_t seg_end = min(seg_start + p.seg_bytes, p.scan_end);
+        const uint32_t seg_end = min(seg_start + ks->seg_bytes, ks->scan_end);
         // Plane carries = the word a lane 63 of a block in front of the segment would hold; only its row-7 bits (8 b + 7 =
         // class of byte seg_start - 4 + b) are ever used. In front of the buffer: boundary.
         uint32_t cB = 0x80808080u, cX = 0;   // cX: carry of the packed word X = [C.b2, C.b3, D.b3, T.b3] (see the block loop)
@@ -570,7 +638,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                         v = make_uint2(pos_base + ((t & 7) << 8) + (t >> 3), six ? (uint32_t)RARE_V6 : (uint32_t)RARE_AT);
                         if (six) F6 &= F6 - 1; else FA &= FA - 1;
                     }
-                    cw_misc.append(has, v, rare_out, p.rare_cap, &p.counters->n_rare);
+                    cw_misc.append(has, v);
                 }
             }
 #ifdef MXY_ANCHOR_DEBUG
@@ -640,7 +708,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                             const uint32_t tl = e - (uint32_t)s;
                             const bool tok = mine && !too_long && rowbits != 0 &&
                                              ((tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128);
-                            cw_tok.append(tok, make_uint2((uint32_t)s, (uint32_t)RARE_TOK | (tl << 8)), tok_out, p.tok_cap, &p.counters->n_tok);
+                            cw_tok.append(tok, make_uint2((uint32_t)s, (uint32_t)RARE_TOK | (tl << 8)));
                         }
                         Zprev_row = Zq;
                     }
@@ -653,9 +721,9 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         if (v4t != v4h) drain_v4<INL>(rv4, v4h, v4t, v4t - v4h, true, cx, pend, cw_cand, vl);
     }
     commit_v4<INL>(pend, cx, cw_cand, vl);
-    if constexpr (INL) v4_lookup_flush(vl, p);
-    cw_misc.flush(rare_out, p.rare_cap, &p.counters->n_rare);
-    cw_tok.flush(tok_out, p.tok_cap, &p.counters->n_tok);
+    if constexpr (INL) v4_lookup_flush(vl);
+    cw_misc.flush();
+    cw_tok.flush();
     // mark the unused tail of every open chunk
     cw_dom.pad_rest(p.dom_list, p.dom_cap);
     cw_cand.finish(p.cands_a, p.cand_a_cap, &p.counters->n_cand_a, Candidate{0u, 0xFFFFFFFFu, 0u, 0u});
@@ -663,13 +731,13 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         uint32_t nv = pend.n_valid;  // validated IPv4 candidates, listed or not
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nv += __shfl_down(nv, off);
-        if (lane == 0 && nv) atomicAdd(&p.counters->cand_true, nv);
+        if (lane == 0 && nv) atomicAdd(&cold_tok()->counters->cand_true, nv);
     }
     // line count: wave reduction of the per-lane counts, one atomic per wave
     unsigned long long lines = nl_count;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) lines += __shfl_down(lines, off);
-    if (lane == 0 && lines) atomicAdd(&p.counters->lines, lines);
+    if (lane == 0 && lines) atomicAdd(&cold_tok()->counters->lines, lines);
 }
 
 // workgroups of k_anchor that are resident on one CU at the same time (register / LDS limited)
