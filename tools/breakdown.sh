@@ -1,11 +1,12 @@
 #!/bin/bash
-# Instruction breakdown of k_anchor with a throw-away instrumented build (MATCHY_AMD_CFLAGS=-DMXY_ANCHOR_DEBUG):
-# for every MATCHY_AMD_DEBUG value given, one rocprofv3 --pmc pass of bench.py; prints VALU / SALU / LDS wave-instructions
-# and the kernel time. Usage (GPU box, repo root): tools/breakdown.sh <tag> 0 1 2 4 8 ...
+# Instruction breakdown of k_anchor with a throw-away instrumented build (MATCHY_AMD_CFLAGS=-DMXY_ANCHOR_DEBUG python -m matchy_amd.build
+# --force; tools/ab.sh save dbg; rebuild): for every MATCHY_AMD_DEBUG value given, one rocprofv3 --pmc pass of bench.py; prints VALU / SALU /
+# LDS wave-instructions and the kernel time. Usage (GPU box, repo root): tools/breakdown.sh <tag> 0 1 2 4 8 ...
 TAG=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/bd_$TAG
 mkdir -p $OUT
+export MATCHY_AMD_LIB=$PWD/matchy_amd/lib_ab/dbg.so MATCHY_AMD_PSL=$PWD/matchy_amd/data/psl.bin
 for D in "$@"; do
   MATCHY_AMD_DEBUG=$D timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/d$D -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --pipelined 0 > $OUT/d$D.log 2>&1
   python3 - $OUT/d$D $D <<'PY'
