@@ -307,6 +307,14 @@ int32_t matchy_amd_ac_dfa_states(const matchy_t *db);
 /* Diagnostics: 1 when the database's globs are all of the form *LITERAL with one common first byte ("*.evil.com" lists) and the
  * scan decides glob candidates from hashed suffixes of a name instead of walking the automaton; 0 otherwise, -1 = error. */
 int32_t matchy_amd_suffix_filter(const matchy_t *db);
+/* Page-locked host memory (hipHostMalloc): buffers a host fills with log data and hands to matchy_scanner_scan reach the device
+ * by DMA at the bus rate without being pinned per call. `matchy match` reads its input files into such buffers. */
+void *matchy_amd_pinned_alloc(size_t bytes);
+void matchy_amd_pinned_free(void *ptr);
+/* Pin / unpin host memory the caller owns (hipHostRegister; page-aligned ranges): what matchy_scanner_scan does per call for
+ * pageable buffers, for hosts that want to do it ahead of the scan (e.g. on a reader thread). */
+int32_t matchy_amd_host_register(const void *ptr, size_t bytes);
+void matchy_amd_host_unregister(const void *ptr);
 /* HIP devices visible to the process (0 when there is none); `matchy match --devices all` */
 int32_t matchy_amd_device_count(void);
 /* Deterministic builds for tests: fixes the build_epoch metadata value. */

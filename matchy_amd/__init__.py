@@ -41,7 +41,8 @@ EXPORTED_SYMBOLS = [
     "matchy_get_entry_data_list", "matchy_free_entry_data_list", "matchy_validate", "matchy_builder_set_schema",
     "matchy_amd_query_json", "matchy_amd_extractor_create", "matchy_amd_device_count", "matchy_scanner_submit_device",
     "matchy_scanner_wait", "matchy_scanner_set_slices", "matchy_scanner_last_slices", "matchy_scan_result_on_device",
-    "matchy_amd_ac_dfa_states", "matchy_amd_suffix_filter",
+    "matchy_amd_ac_dfa_states", "matchy_amd_suffix_filter", "matchy_amd_pinned_alloc", "matchy_amd_pinned_free",
+    "matchy_amd_host_register", "matchy_amd_host_unregister",
 ]
 
 
@@ -153,6 +154,10 @@ def lib():
         "matchy_scanner_set_profile": (None, [vp, C.c_bool]),
         "matchy_amd_ac_dfa_states": (C.c_int32, [vp]),
         "matchy_amd_suffix_filter": (C.c_int32, [vp]),
+        "matchy_amd_pinned_alloc": (vp, [C.c_size_t]),
+        "matchy_amd_pinned_free": (None, [vp]),
+        "matchy_amd_host_register": (C.c_int32, [vp, C.c_size_t]),
+        "matchy_amd_host_unregister": (None, [vp]),
         "matchy_scanner_set_slices": (None, [vp, C.c_int32]),
         "matchy_scanner_last_slices": (C.c_int32, [vp]),
         "matchy_scan_result_on_device": (C.c_bool, [C.POINTER(_ScanResult)]),

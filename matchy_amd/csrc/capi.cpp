@@ -241,6 +241,18 @@ int32_t matchy_amd_suffix_filter(const matchy_t* db_) {
         return db->device_db(db->default_device)->view.sfx_bm ? 1 : 0;
     } catch (...) { return -1; }
 }
+void* matchy_amd_pinned_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("matchy_amd_pinned_alloc: hipHostMalloc failed"); return nullptr; }
+    return p;
+}
+void matchy_amd_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+int32_t matchy_amd_host_register(const void* ptr, size_t bytes) {
+    if (!ptr || !bytes) return MATCHY_ERROR_INVALID_PARAM;
+    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return MATCHY_ERROR_IO; }
+    return MATCHY_SUCCESS;
+}
+void matchy_amd_host_unregister(const void* ptr) { if (ptr) { (void)hipHostUnregister(const_cast<void*>(ptr)); (void)hipGetLastError(); } }
 int32_t matchy_amd_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;

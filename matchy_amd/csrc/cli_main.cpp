@@ -51,7 +51,7 @@ int usage() {
     fprintf(stderr,
             "usage:\n"
             "  matchy build <INPUT>... -o <FILE> [-f text|csv|json] [-t TYPE] [-d DESC] [--desc-lang LANG] [-i] [-v]\n"
-            "  matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N | --devices LIST|all] [-f]\n"
+            "  matchy match <DATABASE> <INPUT>... [--format json|summary] [-s] [--batch-bytes N] [--extractors LIST] [--device N | --devices LIST|all] [-j N|auto] [-f]\n"
             "  matchy query <DATABASE> <QUERY> [-q]\n"
             "  matchy extract <INPUT>... [--format json|csv|text] [--types LIST] [--min-labels N] [-u] [-s] [--show-candidates]\n"
             "  matchy inspect <DATABASE> [-j] [-v]\n"
@@ -300,7 +300,27 @@ struct RawBuf {
     }
 };
 // `ptr` points into `own` (inputs that are read: stdin, .gz) or into a file mapping that outlives the pipeline
-struct Batch { size_t seq = 0, input = 0; RawBuf own; const uint8_t* ptr = nullptr; size_t len = 0; bool mapped = false; };
+// ... or names a byte range of an open regular file (`fd` >= 0): the worker that takes the batch reads the range into its own pinned buffer
+struct Batch { size_t seq = 0, input = 0; RawBuf own; const uint8_t* ptr = nullptr; size_t len = 0; bool mapped = false; int fd = -1; off_t off = 0;
+               const void* reg = nullptr; };   // reg: page range of a mapped batch the reader pinned ahead of the scan (unpinned by the worker)
+// Page-locked buffer of one worker (matchy_amd_pinned_alloc): file ranges are read into it with pread and reach the device by DMA
+struct PinnedBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    uint8_t* need(size_t n) {
+        if (cap < n) {
+            matchy_amd_pinned_free(p);
+            cap = n + n / 8 + 4096;
+            p = (uint8_t*)matchy_amd_pinned_alloc(cap);
+            if (!p) cap = 0;
+        }
+        return p;
+    }
+    ~PinnedBuf() { matchy_amd_pinned_free(p); }
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+};
 struct Done { std::string out; Totals t; bool ok = true; size_t input = 0; };
 
 struct MatchPipeline {
@@ -324,6 +344,7 @@ struct MatchPipeline {
     // Mapped inputs: the mapping of a file is released by the printer as soon as the file's last batch has been printed — the
     // page tables of a file of gigabytes take tens of milliseconds to tear down, and that runs beside the scans of the next
     // files instead of behind the last one.
+    std::vector<int> open_fds;   // regular files whose ranges are read by the workers (closed by the caller when the pipeline has drained)
     struct Mapping { void* p; size_t len; size_t last_seq; bool released; };
     std::vector<Mapping> mappings;   // guarded by mu
     void add_mapping(void* p, size_t len, size_t last_seq) { std::lock_guard<std::mutex> lk(mu); mappings.push_back({p, len, last_seq, false}); }
@@ -338,14 +359,30 @@ struct MatchPipeline {
     void close() { std::lock_guard<std::mutex> lk(mu); closed = true; cv_work.notify_all(); cv_done.notify_all(); }
 
     // scan one batch and render its matches
-    void run_batch(matchy_scanner_t* sc, const Batch& b, Done& d) {
+    void run_batch(matchy_scanner_t* sc, Batch& b, Done& d, PinnedBuf& pin) {
         d.input = b.input;
         if (!b.len) return;
         static const bool trace = getenv("MATCHY_AMD_TRACE") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+        if (b.fd >= 0) {   // a range of a regular file: into this worker's pinned buffer
+            uint8_t* dst = pin.need(b.len);
+            size_t have = 0;
+            while (dst && have < b.len) {
+                const ssize_t r = pread(b.fd, dst + have, b.len - have, b.off + (off_t)have);
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0) break;
+                have += (size_t)r;
+            }
+            if (!dst || have != b.len) {
+                fprintf(stderr, "[ERROR] Failed to read %s: %s\n", sources[b.input].c_str(), dst ? (have < b.len ? "file shrank or read error" : "") : matchy_amd_last_error());
+                d.ok = false;
+                return;
+            }
+            b.ptr = dst;
+        }
 #ifdef MADV_POPULATE_READ
-        if (b.mapped) {   // pre-fault the batch's pages in one call (in the worker: the workers run side by side)
+        if (b.mapped && !b.reg) {   // pre-fault the batch's pages in one call (in the worker: the workers run side by side)
             const uintptr_t a = (uintptr_t)b.ptr & ~(uintptr_t)4095;
             (void)madvise((void*)a, (uintptr_t)b.ptr + b.len - a, MADV_POPULATE_READ);
         }
@@ -375,10 +412,13 @@ struct MatchPipeline {
             }
         }
         const double t_loop = ms();
+        if (b.reg) { matchy_amd_host_unregister(b.reg); b.reg = nullptr; }
         matchy_scan_result_free(&r);
         if (trace) fprintf(stderr, "[matchy] batch %zu B: pre-fault %.3f ms, scan %.3f ms, hits loop %.3f ms, free %.3f ms\n", b.len, t_pop, t_scan - t_pop, t_loop - t_scan, ms() - t_loop);
     }
-    void worker(matchy_scanner_t* sc) {
+    template <class GetScanner>
+    void worker(GetScanner get_scanner) {   // get_scanner(): this worker's scanner, created at its first batch
+        PinnedBuf pin;
         for (;;) {
             Batch b;
             {
@@ -390,7 +430,9 @@ struct MatchPipeline {
                 cv_space.notify_one();
             }
             Done d;
-            run_batch(sc, b, d);
+            matchy_scanner_t* sc = get_scanner();
+            if (sc) run_batch(sc, b, d, pin);
+            else { d.input = b.input; d.ok = false; }
             std::lock_guard<std::mutex> lk(mu);
             done.emplace(b.seq, std::move(d));
             cv_done.notify_all();
@@ -427,6 +469,51 @@ bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t
     int fd = path == "-" ? 0 : open(path.c_str(), O_RDONLY);
     if (fd < 0) { fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), strerror(errno)); return false; }
     struct stat sb;
+    // Regular files: batches are byte ranges cut at newlines (the cuts are found by reading a few KiB around each nominal end); the
+    // worker that takes a batch reads its range with pread into its own page-locked buffer, from which the DMA engine feeds the GPU
+    // at the bus rate. No mapping: no page tables to build per batch and to tear down per file (a mapped 54 GB input cost 0.3 s of
+    // munmap alone), and with several workers the kernel-side copies of the ranges run side by side (tools/ubench/h2d_rate2.cpp: 8
+    // readers 40-45 GB/s). MATCHY_AMD_MMAP=1 maps the file instead (batches are views of the mapping, pinned per batch).
+    if (!gz && fd != 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && getenv("MATCHY_AMD_PREAD") && !getenv("MATCHY_AMD_NO_MMAP")) {
+        const size_t size = (size_t)sb.st_size;
+        std::vector<uint8_t> probe(65536);
+        // offset just behind the last '\n' in [lo, hi), or (size_t)-1
+        auto last_newline = [&](size_t lo, size_t hi) -> size_t {
+            while (hi > lo) {
+                const size_t n = std::min(probe.size(), hi - lo);
+                const ssize_t r = pread(fd, probe.data(), n, (off_t)(hi - n));
+                if (r != (ssize_t)n) return (size_t)-1;
+                const void* nl = memrchr(probe.data(), '\n', n);
+                if (nl) return hi - n + (size_t)((const uint8_t*)nl - probe.data()) + 1;
+                hi -= n;
+            }
+            return (size_t)-1;
+        };
+        auto next_newline = [&](size_t lo) -> size_t {   // offset just behind the first '\n' at or after lo, or size
+            while (lo < size) {
+                const size_t n = std::min(probe.size(), size - lo);
+                const ssize_t r = pread(fd, probe.data(), n, (off_t)lo);
+                if (r != (ssize_t)n) return size;
+                const void* nl = memchr(probe.data(), '\n', n);
+                if (nl) return lo + (size_t)((const uint8_t*)nl - probe.data()) + 1;
+                lo += n;
+            }
+            return size;
+        };
+        { std::lock_guard<std::mutex> lk(pl.mu); pl.open_fds.push_back(fd); }
+        for (size_t pos = 0; pos < size;) {
+            size_t end = std::min(size, pos + batch_bytes);
+            if (end < size) {   // newline-aligned cut; a line longer than the batch extends it to that line's end
+                const size_t cut = last_newline(pos, end);
+                end = cut != (size_t)-1 ? cut : next_newline(end);
+            }
+            Batch b;
+            b.input = input; b.fd = fd; b.off = (off_t)pos; b.len = end - pos;
+            pl.submit(std::move(b));
+            pos = end;
+        }
+        return true;
+    }
     if (!gz && fd != 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && !getenv("MATCHY_AMD_NO_MMAP")) {
         const size_t size = (size_t)sb.st_size;
         void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -447,6 +534,17 @@ bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t
                 }
                 Batch b;
                 b.input = input; b.ptr = base + pos; b.len = end - pos; b.mapped = true;
+                // This (reader) thread faults the batch's pages in and pins them; the workers only copy, scan and post-process. With
+                // every worker doing its own page faults and pinning, the address-space lock of the process was the limit
+                // (four workers: 28-31 GB/s; with the reader feeding them: 42-45). MATCHY_AMD_NO_FEEDER=1 restores that.
+                static const bool feeder = getenv("MATCHY_AMD_NO_FEEDER") == nullptr;
+                if (feeder && b.len >= ((size_t)4 << 20)) {
+                    const uintptr_t a = ((uintptr_t)b.ptr + 4095) & ~(uintptr_t)4095, z = ((uintptr_t)b.ptr + b.len) & ~(uintptr_t)4095;
+#ifdef MADV_POPULATE_READ
+                    (void)madvise((void*)((uintptr_t)b.ptr & ~(uintptr_t)4095), (uintptr_t)b.ptr + b.len - ((uintptr_t)b.ptr & ~(uintptr_t)4095), MADV_POPULATE_READ);
+#endif
+                    if (z > a && matchy_amd_host_register((const void*)a, z - a) == MATCHY_SUCCESS) b.reg = (const void*)a;
+                }
                 last_seq = pl.submit(std::move(b));
                 pos = end;
             }
@@ -546,7 +644,8 @@ void follow_inputs(MatchPipeline& pl, matchy_scanner_t* sc, const std::vector<st
             any = true;
             b.ptr = b.own.data(); b.len = have;
             Done d;
-            pl.run_batch(sc, b, d);
+            PinnedBuf unused;   // follow batches are read into `own`
+            pl.run_batch(sc, b, d, unused);
             if (!d.out.empty()) {
                 // this batch's records carry the current time
                 char ts[48];
@@ -580,6 +679,7 @@ int cmd_match(int argc, char** argv) {
     bool stats = false, follow = false;
     size_t batch_bytes = (size_t)256 << 20;  // GPU batches: large, so that one launch amortises PCIe latency
     int device = 0;
+    int jobs = 0;   // -j N|auto (matchy.rs:98-103: worker threads): scanners here; auto = 2 (summary) / 4 (json) per device listed once
     if (const char* d = getenv("MATCHY_AMD_DEVICE")) device = atoi(d);
     for (int i = 0; i < argc; ++i) {
         std::string a = argv[i];
@@ -599,7 +699,7 @@ int cmd_match(int argc, char** argv) {
         else if (eqval("--devices", v)) devices = v;
         else if (eqval("--device", v)) device = atoi(v.c_str());
         else if (eqval("--threads", v) || eqval("--readers", v) || eqval("--cache-size", v)) {}
-        else if (a == "-j") (void)next("-j");
+        else if (a == "-j") { const std::string j = next("-j"); jobs = j == "auto" ? 0 : std::max(0, atoi(j.c_str())); }
         else if (a == "-p" || a == "--progress" || a == "--debug-routing") {}
         else if (a == "-f" || a == "--follow") follow = true;
         else if (a.size() > 1 && a[0] == '-') { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
@@ -626,6 +726,21 @@ int cmd_match(int argc, char** argv) {
             devs.push_back(atoi(part.c_str()));
         }
         if (devs.empty()) { fprintf(stderr, "Error: --devices needs at least one device\n"); return 1; }
+    }
+    {
+        // Workers. A device that is listed once gets several scanners (-j N: N in all, spread over the devices): one scanner's hit
+        // post-processing runs under another's transfer (one scanner per GPU: 24 GB/s in the scan phase, two: 44). A device list
+        // with repeats is taken as written.
+        std::vector<int> uniq = devs;
+        std::sort(uniq.begin(), uniq.end());
+        const bool repeats = std::adjacent_find(uniq.begin(), uniq.end()) != uniq.end();
+        if (!repeats) {
+            // auto: two scanners per device keep the bus busy when only counters come back (one copies while the other post-processes);
+            // rendering NDJSON is per-hit host work, which four workers share better
+            const size_t want = jobs > 0 ? std::max<size_t>((size_t)jobs, devs.size()) : devs.size() * (format == "json" ? 4 : 2);
+            const std::vector<int> base = devs;
+            for (size_t k = base.size(); k < want; ++k) devs.push_back(base[k % base.size()]);
+        }
     }
     const auto t0 = std::chrono::steady_clock::now();
     // database: .mxy file, or a .csv / .json source that is built in memory first (match_cmd.rs:20-31, 222-239)
@@ -656,18 +771,16 @@ int cmd_match(int argc, char** argv) {
         std::string err;
         if (!parse_extractors(extractors, auto_mask, mask, err)) { fprintf(stderr, "Error: %s\n", err.c_str()); matchy_close(db); return 1; }
     }
-    std::vector<matchy_scanner_t*> scanners;
-    for (int d : devs) {
-        matchy_scanner_t* sc = matchy_scanner_create(db, mask, d);
-        if (!sc) {
-            fprintf(stderr, "Error: Failed to create the GPU scanner on device %d: %s\n", d, matchy_amd_last_error());
-            for (auto* s2 : scanners) matchy_scanner_free(s2);
-            matchy_close(db);
-            return 1;
-        }
-        scanners.push_back(sc);
+    // the first scanner now (it also serves --follow); the others are created by their worker threads when the first batch reaches
+    // them (a small input never pays for scanners it does not use)
+    std::vector<matchy_scanner_t*> scanners(devs.size(), nullptr);
+    scanners[0] = matchy_scanner_create(db, mask, devs[0]);
+    if (!scanners[0]) {
+        fprintf(stderr, "Error: Failed to create the GPU scanner on device %d: %s\n", devs[0], matchy_amd_last_error());
+        matchy_close(db);
+        return 1;
     }
-    if (trace) fprintf(stderr, "[matchy] %zu scanner(s) created after %.1f ms\n", scanners.size(), since0());
+    if (trace) fprintf(stderr, "[matchy] first of %zu scanner(s) created after %.1f ms\n", scanners.size(), since0());
     MatchPipeline pl;
     pl.json = format == "json";
     pl.max_q = scanners.size() + 1;
@@ -684,7 +797,14 @@ int cmd_match(int argc, char** argv) {
     Totals t;
     std::vector<char> input_failed(paths.size(), 0);
     std::vector<std::thread> workers;
-    for (auto* sc : scanners) workers.emplace_back([&pl, sc] { pl.worker(sc); });
+    for (size_t w = 0; w < scanners.size(); ++w)
+        workers.emplace_back([&pl, &scanners, &devs, db, mask, w] {
+            pl.worker([&]() -> matchy_scanner_t* {
+                if (!scanners[w]) scanners[w] = matchy_scanner_create(db, mask, devs[w]);
+                if (!scanners[w]) fprintf(stderr, "[ERROR] Failed to create the GPU scanner on device %d: %s\n", devs[w], matchy_amd_last_error());
+                return scanners[w];
+            });
+        });
     std::thread printer([&] { pl.printer(t, input_failed); });
     for (size_t i = 0; i < paths.size(); ++i)
         if (!read_input(pl, i, paths[i], batch_bytes)) input_failed[i] = 1;
@@ -695,6 +815,7 @@ int cmd_match(int argc, char** argv) {
     fflush(stdout);
     if (trace) fprintf(stderr, "[matchy] all batches done after %.1f ms\n", since0());
     pl.release_mappings((size_t)-1);
+    for (int fd : pl.open_fds) close(fd);
     if (follow) follow_inputs(pl, scanners[0], paths, stats, t);
     size_t failed = 0;
     for (char f : input_failed) failed += f != 0;
@@ -719,7 +840,7 @@ int cmd_match(int argc, char** argv) {
         fprintf(stderr, "\n[INFO] === Devices ===\n[INFO] HIP devices: %s (%zu scanner%s, batches of %zu MiB)\n", dl.c_str(), scanners.size(),
                 scanners.size() == 1 ? "" : "s", batch_bytes >> 20);
     }
-    for (auto* sc : scanners) matchy_scanner_free(sc);
+    for (auto* sc : scanners) if (sc) matchy_scanner_free(sc);
     matchy_close(db);
     if (trace) fprintf(stderr, "[matchy] cleaned up after %.1f ms\n", since0());
     if (failed) { fprintf(stderr, "Error: %zu file(s) failed to process\n", failed); return 1; }

@@ -1140,16 +1140,20 @@ void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_
         const uint8_t* src = data + pos;
         const uint8_t* reg_lo = nullptr;
         size_t reg_len = 0;
+        bool mine = false;   // this call pinned the range (and unpins it)
         static const bool no_reg = getenv("MATCHY_AMD_NO_REGISTER") != nullptr;
         if (!no_reg && n >= ((size_t)4 << 20)) {
             const uintptr_t a = ((uintptr_t)src + 4095) & ~(uintptr_t)4095, b = ((uintptr_t)src + n) & ~(uintptr_t)4095;
+            // pinned already (hipHostMalloc, or registered by the caller: matchy_amd_host_register on the whole pages)? asked for the
+            // first whole page: the bytes in front of it may belong to a neighbour's page
             hipPointerAttribute_t attr;
-            const bool known = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type != hipMemoryTypeUnregistered;
+            const bool known = b > a && hipPointerGetAttributes(&attr, (const void*)a) == hipSuccess && attr.type != hipMemoryTypeUnregistered;
             (void)hipGetLastError();
-            if (!known && b > a && hipHostRegister((void*)a, b - a, hipHostRegisterDefault) == hipSuccess) { reg_lo = (const uint8_t*)a; reg_len = b - a; }
+            if (known) { reg_lo = (const uint8_t*)a; reg_len = b - a; }
+            else if (b > a && hipHostRegister((void*)a, b - a, hipHostRegisterDefault) == hipSuccess) { reg_lo = (const uint8_t*)a; reg_len = b - a; mine = true; }
             (void)hipGetLastError();
         }
-        struct Unreg { const uint8_t* p; ~Unreg() { if (p) (void)hipHostUnregister((void*)p); } } unreg{reg_lo};
+        struct Unreg { const uint8_t* p; ~Unreg() { if (p) (void)hipHostUnregister((void*)p); } } unreg{mine ? reg_lo : nullptr};
         const double t_reg = ms_since(th0);
         if (reg_lo) {
             const size_t head = (size_t)(reg_lo - src), tail = n - head - reg_len;

@@ -156,6 +156,13 @@ def test_match_config1_end_to_end(cli, tmp_path, oracle):
     both = want_lines + [json.dumps(json.loads(l) | {"source": str(gzp)}, separators=(",", ":"), ensure_ascii=False) for l in want_lines]
     assert [json.loads(l) for l in rd.stdout.decode().splitlines()] == [json.loads(l) for l in both]
     assert b"[INFO] Lines processed: 20,000" in rd.stderr and b"3 scanners" in rd.stderr and b"[INFO] Files processed: 2" in rd.stderr
+    # -j N|auto (the reference's worker-thread option): scanners per device list without repeats; auto = 4 per device when NDJSON is rendered
+    rj = _run([cli, "match", str(dbp), str(logp), "-j", "3", "--batch-bytes", "50000", "-s"])
+    assert rj.returncode == 0 and rj.stdout.decode().splitlines() == want_lines and b"3 scanners" in rj.stderr
+    rj = _run([cli, "match", str(dbp), str(logp), "--batch-bytes", "50000", "-s"])
+    assert rj.returncode == 0 and rj.stdout.decode().splitlines() == want_lines and b"4 scanners" in rj.stderr
+    rj = _run([cli, "match", str(dbp), str(logp), "--batch-bytes", "50000", "-s", "--format", "summary"])
+    assert rj.returncode == 0 and b"2 scanners" in rj.stderr and b"[INFO] Lines processed: 10,000" in rj.stderr
     ra = _run([cli, "match", str(dbp), str(logp), "--devices", "all"])
     assert ra.returncode == 0 and ra.stdout.decode().splitlines() == want_lines
     assert _run([cli, "match", str(dbp), str(logp), "--devices", "0,x"]).returncode == 1

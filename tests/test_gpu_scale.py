@@ -392,3 +392,45 @@ def test_hostile_long_runs(M, oracle):
         assert [v for *_, v in got] == [v for *_, v in want], name
         assert dt < 0.05, (name, dt)   # includes the upload of the buffer; the old single-lane walk took 0.08 s and more
     ex.close()
+
+
+@pytest.mark.parametrize("env", [{"MATCHY_AMD_L24": "0"}, {"MATCHY_AMD_LEAF_MB": "0"}, {"MATCHY_AMD_LEAF_MB": "1"}, {"MATCHY_AMD_L24": "1"}])
+def test_ipv4_lookup_table_variants(M, oracle, monkeypatch, env):
+    """The IPv4 lookup tables are chosen at open: 16-level table + walk (small trees, MATCHY_AMD_L24=0), /24 table + walk (no leaf
+    tables: MATCHY_AMD_LEAF_MB=0), /24 table with leaf tables for SOME /24s and the walk for the rest (a cap of 1 MB = 512 leaf tables),
+    everything (default / forced). All of them against the oracle on the CIDR-heavy mix (dense candidates -> k_lookup_ip) and on the
+    headline mix (sparse candidates -> looked up inside k_anchor), scans through both entries and single queries."""
+    from tools import synth
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for cfgname, lines in (("c5/100", 20000), ("c2/5", 20000)):
+        cfg = synth.config(cfgname)
+        blob = synth.build_db(cfg)
+        log = synth.make_log(cfg, 0, lines)
+        want, _, st = oracle.Database(blob).scan(log, want_json=False)
+        db = M.Database(blob)
+        sc = M.Scanner(db)
+        r = sc.scan(log)
+        assert (r.lines, r.candidates) == (st.lines, st.candidates)
+        assert r.hits() == want
+        r.close()
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        d = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(d), ctypes.c_size_t(len(log) + 64)) == 0
+        assert hip.hipMemcpy(d, log, ctypes.c_size_t(len(log)), 1) == 0
+        r = sc.scan_device(d.value, len(log), fetch_mode=3)
+        assert (r.lines, r.candidates) == (st.lines, st.candidates)
+        assert r.hits() == want
+        r.close()
+        hip.hipFree(d)
+        odb = oracle.Database(blob)
+        seen = 0
+        for h in want[:400]:
+            if h["kind"] == "ip":
+                q = log[h["start"]:h["end"]].decode()
+                w, g = odb.lookup(q), db.lookup(q)
+                assert g == {"found": True, "prefix_len": w["prefix_len"], "data": w["data"]}, q
+                seen += 1
+        assert seen > 20
+        sc.close(); db.close()

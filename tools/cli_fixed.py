@@ -11,17 +11,25 @@ if not os.path.exists("/tmp/c2.log"):
 open("/tmp/small.log", "wb").write(open("/tmp/c2.log", "rb").read(1_000_000))
 size = os.path.getsize("/tmp/c2.log")
 cli = "matchy_amd/bin/matchy"
-def run(files, devs):
+def run(files, jobs):
     t = time.time()
-    r = subprocess.run([cli, "match", "/tmp/c2.mxy"] + files + ["--devices", devs, "--batch-bytes", str(256 << 20), "--format", "summary", "-s"],
-                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    r = subprocess.run([cli, "match", "/tmp/c2.mxy"] + files + ["-j", jobs, "--batch-bytes", str(256 << 20), "--format", "summary", "-s"],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, MATCHY_AMD_TRACE="1"))
     dt = time.time() - t
-    info = [l.split("] ")[1] for l in r.stderr.decode().splitlines() if "Throughput" in l or "Processing time" in l]
-    return dt, info
+    err = r.stderr.decode().splitlines()
+    info = [l.split("] ")[1] for l in err if "Throughput" in l]
+    ph = {}
+    for l in err:   # phase marks of the command line (MATCHY_AMD_TRACE): database open, all batches done
+        for key in ("database open after", "all batches done after"):
+            if key in l:
+                ph[key] = float(l.split(key)[1].split()[0])
+    scan_s = (ph.get("all batches done after", 0) - ph.get("database open after", 0)) / 1e3
+    return dt, info, scan_s
 for i in range(3):
-    dt, info = run(["/tmp/small.log"], "0")
+    dt, info, _ = run(["/tmp/small.log"], "auto")
     print(f"fixed cost (1 MB input): wall {dt:.3f} s {info}", flush=True)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-for devs in ("0", "0,0", "0,0,0"):
-    dt, info = run(["/tmp/c2.log"] * reps, devs)
-    print(f"{reps} x {size} B, devices {devs}: wall {dt:.2f} s = {size * reps / dt / 1e9:.2f} GB/s incl. process start and database upload; {info}", flush=True)
+for jobs in ("1", "2", "auto", "6", "8"):
+    dt, info, scan_s = run(["/tmp/c2.log"] * reps, jobs)
+    print(f"{reps} x {size} B, -j {jobs} ({'4' if jobs == 'auto' else jobs} scanner(s) on one GPU): scan phase {scan_s:.2f} s = {size * reps / max(scan_s, 1e-9) / 1e9:.2f} GB/s; "
+          f"wall {dt:.2f} s = {size * reps / dt / 1e9:.2f} GB/s incl. process start and database upload; {info}", flush=True)
