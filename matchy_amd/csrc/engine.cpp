@@ -473,6 +473,7 @@ Scanner::~Scanner() {
     if (ev_join2_) (void)hipEventDestroy(ev_join2_);
     if (ev_join3_) (void)hipEventDestroy(ev_join3_);
     if (ev_dom_) (void)hipEventDestroy(ev_dom_);
+    if (ev_v1_) (void)hipEventDestroy(ev_v1_);
     if (aux2_stream_) (void)hipStreamDestroy(aux2_stream_);
     if (dom_stream_) (void)hipStreamDestroy(dom_stream_);
     if (host_stream_) (void)hipStreamDestroy(host_stream_);
@@ -702,6 +703,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     last_ptr_ = dptr; last_len_ = len; last_lookup_ = lookup; last_mirror_ = host_mirror; last_fork_ = fork; last_slices_ = slices;
     last_forked_ = false;
     spill_done_ = false;
+    expect_chains_ = 0;
     // MATCHY_AMD_NO_FORK=1 keeps everything on one stream.
     static const bool env_no_fork = getenv("MATCHY_AMD_NO_FORK") != nullptr;
     const bool no_fork = env_no_fork || !fork;
@@ -817,22 +819,46 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         // beside k_validate_dom: half the CUs, so that kernel keeps most of its resident waves
         launch_validate_misc(t1, view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);
         // split lists: the lookups of k_validate's candidates do not wait for k_rare (checksum validators: a chain of their own,
-        // almost always over next to nothing), whose few candidates get a list and a lookup launch behind it
-        if (L.split_misc) launch_lookup(L.lm, view, std::max(1, n_cu_ / 2), aux2_stream_);
+        // almost always over next to nothing), whose few candidates get a list and a lookup launch of their own — on the second
+        // stream when the IPv4 lookups do not need it (they run inside k_anchor), beside the third stream's lookups
+        const bool rare_own = L.split_misc && rare_possible && !L.ip_pass;
+        if (rare_own) {
+            if (!ev_v1_) MXY_HIP(hipEventCreateWithFlags(&ev_v1_, hipEventDisableTiming));
+            MXY_HIP(hipEventRecord(ev_v1_, aux2_stream_));
+        }
+        // Split lists: the side chains do not join the scan's stream through events — the last kernel of each (a k_lookup launch) reports
+        // its end in ScanCounters::chains_done, which k_finish polls (arrive_chain 1: third stream, 2: k_rare's, 3: the fourth stream)
+        static const bool env_join = getenv("MATCHY_AMD_EVENT_JOIN") != nullptr;
+        const bool arrive = L.split_misc && !env_join;
+        uint32_t chains = 0;
+        if (L.split_misc) {
+            LookupParams lm = L.lm;
+            if (arrive && (rare_own || !rare_possible)) { lm.arrive_chain = 1; lm.arrive = counters_.p; ++chains; }
+            launch_lookup(lm, view, std::max(1, n_cu_ / 2), aux2_stream_);
+        }
         if (rare_possible) {   // one wave per SIMD (297 VGPRs)
             TokParams tr = t1;
             tr.vmode = tp.vmode;
             if (L.split_misc) { tr.cands = work_[0].cands_r.p; tr.cand_cap = (uint32_t)work_[0].cands_r.n; tr.n_cand = &counters_.p->n_cand_r; }
-            launch_rare(tr, view, n_cu_ * 4, aux2_stream_);
-            if (L.split_misc) launch_lookup(L.lr, view, std::max(1, n_cu_ / 8), aux2_stream_);
+            hipStream_t rs = rare_own ? aux_stream_ : aux2_stream_;
+            if (rare_own) MXY_HIP(hipStreamWaitEvent(aux_stream_, ev_v1_, 0));
+            launch_rare(tr, view, n_cu_ * 4, rs);
+            if (L.split_misc) {
+                LookupParams lr = L.lr;
+                if (arrive) { lr.arrive_chain = rare_own ? 2u : 1u; lr.arrive = counters_.p; ++chains; }
+                launch_lookup(lr, view, std::max(1, n_cu_ / 8), rs);
+            }
+            if (rare_own && !arrive) MXY_HIP(hipEventRecord(ev_join_, aux_stream_));
         }
-        MXY_HIP(hipEventRecord(ev_join2_, aux2_stream_));
+        if (!arrive) MXY_HIP(hipEventRecord(ev_join2_, aux2_stream_));
         launch_validate_dom(tp, view, n_cu_ * L.gm[1], stream);
         TokParams t2 = tp;
         t2.vmode = 2u;
         if (L.split_misc) {
-            // the few domain anchors k_validate_dom left undecided: general walk + lookups of ITS candidates (a list of their own)
-            // on a fourth stream, beside the lookups of k_validate_dom's candidates instead of in front of them
+            // Behind k_validate_dom two chains: the few domain anchors it left undecided (general walk + lookups of THEIR candidates,
+            // a list of their own) stay on the scan's stream — no event between producer and consumer —, the lookups of
+            // k_validate_dom's candidates go to a fourth stream beside them. That stream then takes the other side streams' end
+            // events in, so the scan's stream joins ONE event (every event wait on it is ~10 us in front of k_finish).
             if (!dom_stream_) {
                 MXY_HIP(hipStreamCreateWithFlags(&dom_stream_, hipStreamNonBlocking));
                 MXY_HIP(hipEventCreateWithFlags(&ev_join3_, hipEventDisableTiming));
@@ -840,13 +866,20 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
             }
             MXY_HIP(hipEventRecord(ev_dom_, stream));
             MXY_HIP(hipStreamWaitEvent(dom_stream_, ev_dom_, 0));
+            {
+                LookupParams lpm = L.lp;
+                if (arrive) { lpm.arrive_chain = 3; lpm.arrive = counters_.p; ++chains; }
+                launch_lookup(lpm, view, n_cu_ * L.gm[2], dom_stream_);
+            }
+            if (arrive) expect_chains_ = chains;
+            else {
+                MXY_HIP(hipStreamWaitEvent(dom_stream_, ev_join2_, 0));
+                if (rare_own) MXY_HIP(hipStreamWaitEvent(dom_stream_, ev_join_, 0));
+                MXY_HIP(hipEventRecord(ev_join3_, dom_stream_));
+            }
             t2.cands = work_[0].cands_d.p; t2.cand_cap = (uint32_t)work_[0].cands_d.n; t2.n_cand = &counters_.p->n_cand_d;
-            launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, dom_stream_);
-            launch_lookup(L.ld, view, std::max(1, n_cu_ / 8), dom_stream_);
-            // one join for the scan's stream: this chain takes the third stream's end in (every event wait on the scan's stream
-            // is ~10 us between its last kernel and k_finish)
-            MXY_HIP(hipStreamWaitEvent(dom_stream_, ev_join2_, 0));
-            MXY_HIP(hipEventRecord(ev_join3_, dom_stream_));
+            launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
+            launch_lookup(L.ld, view, std::max(1, n_cu_ / 8), stream);
         } else {
             launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
             // no timing events inside the forked tail: every packet between two kernels of the chain is ~6-8 us of it, and with
@@ -862,9 +895,9 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     }
     if (lookup) {
         if (L.ip_pass && no_fork) launch_lookup_ip(L.la, view, L.ip_grid, L.ip_dense, stream);
-        launch_lookup(L.lp, view, n_cu_ * L.gm[2], stream);
+        if (no_fork || !L.split_misc) launch_lookup(L.lp, view, n_cu_ * L.gm[2], stream);   // split lists: launched on the fourth stream above
         if (L.ip_pass && !no_fork) MXY_HIP(hipStreamWaitEvent(stream, ev_join_, 0));
-        if (L.split_misc && !no_fork) MXY_HIP(hipStreamWaitEvent(stream, ev_join3_, 0));
+        if (L.split_misc && !no_fork && !expect_chains_) MXY_HIP(hipStreamWaitEvent(stream, ev_join3_, 0));
     }
     if (profile_) MXY_HIP(hipEventRecord(ev_[4], stream));
 }
@@ -888,7 +921,10 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     const int ns = n_slices_;
     for (int attempt = 0;; ++attempt) {
         // k_finish: the counter blocks go to pinned host memory and are cleared on the device for the next scan
-        launch_finish(counters_.p, host_slices_, ns, stream);
+        launch_finish(counters_.p, host_slices_, ns, expect_chains_, stream);
+        // side chains that report to k_finish end behind the last event scan_device recorded: the interval ends behind k_finish then
+        if (profile_ && expect_chains_) MXY_HIP(hipEventRecord(ev_[4], stream));
+        expect_chains_ = 0;   // a rescan sets it again; the spill pass below runs on this stream
         MXY_HIP(hipStreamSynchronize(stream));
         counters_clean_ = true;
         // slice 0 holds n_final / n_final_ids of all slices; statistics are summed
@@ -967,6 +1003,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     const ScanCounters& c = host_counters_;
     if (c.error & 1) throw HipError{"scan: a candidate matches more than 65535 glob patterns (the hit record counts pattern ids in 16 bits)"};
     if (c.error & 4) throw HipError{"scan: a candidate is longer than 16 MiB (24-bit length field)"};
+    if (c.error & 8) throw HipError{"scan: a side stream of the forked scan did not finish (k_finish timed out waiting for it)"};
     const double t_counters = since();
     if (trace) {
         ScanCounters t = host_slices_[0];

@@ -186,6 +186,7 @@ private:
     int plan_slices(uint32_t len, int want, uint32_t (&cuts)[MAX_SLICES + 1]);
     void setup_spill(int sl, LookupParams& lp);
     bool spill_done_ = false;
+    uint32_t expect_chains_ = 0;    // side-stream chains of the last scan_device that report their end to k_finish (0: event joins)
     bool counters_clean_ = false;   // the device counter blocks are zero (k_finish of the last fetch left them so)
     int last_slices_ = 0;
     std::shared_ptr<const DbImage> img_;
@@ -204,7 +205,7 @@ private:
     // per slice
     hipStream_t dom_stream_ = nullptr;
     hipEvent_t ev_anchor_[MAX_SLICES] = {}, ev_misc_[MAX_SLICES] = {};
-    hipEvent_t ev_join3_ = nullptr, ev_dom_ = nullptr;
+    hipEvent_t ev_join3_ = nullptr, ev_dom_ = nullptr, ev_v1_ = nullptr;
     DevBuf<FinalHit> final_;
     DevBuf<uint32_t> final_ids_;
     DevBuf<long long> final_offs_;

@@ -747,6 +747,15 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
     cw.pad_rest(p.hits, p.hit_cap, SH);
     if (!GLOB && p.ac_filter) ww.flush(p.glob_work, p.glob_work_cap, &p.counters->n_glob_work);
     if (lane_id() == 0 && cw.total) atomicAdd(&p.counters->hits_true, cw.total);
+    if (!GLOB && p.arrive_chain) {
+        // last kernel of a side-stream chain: everything this workgroup wrote (records in pinned host memory included) is visible
+        // before its arrival counts; the workgroup that completes the grid reports the chain
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            if (atomicAdd(&p.arrive->arrive_wgs[p.arrive_chain - 1], 1u) == gridDim.x - 1) atomicAdd(&p.arrive->chains_done, 1u);
+        }
+    }
 }
 
 // k_lookup_spill — the candidates the glob pass could not hold (GlobSetList / StarStackFixed overflow): one lane per candidate,
@@ -855,17 +864,30 @@ void launch_lookup(const LookupParams& p_in, const DevDb& db, int grid, hipStrea
     check_launch("launch_lookup");
 }
 // see launch_finish (scan_types.h)
-__global__ __launch_bounds__(256) void k_finish(ScanCounters* dev, ScanCounters* host, uint32_t n_words) {
+__global__ __launch_bounds__(256) void k_finish(ScanCounters* dev, ScanCounters* host, uint32_t n_words, uint32_t expect_chains) {
     uint32_t* d = reinterpret_cast<uint32_t*>(dev);
     uint32_t* h = reinterpret_cast<uint32_t*>(host);
+    if (expect_chains) {
+        // the side-stream chains of this scan report their ends in chains_done: poll it (one lane; the others wait at the barrier).
+        // Bounded: after ~200 ms of wall clock (100 MHz counter) the scan is declared failed instead of spinning on.
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(&dev->chains_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < expect_chains) {
+                if (wall_clock64() - t0 > 20000000ull) { atomicOr(&dev->error, 8u); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        __threadfence();
+    }
     for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) {
         h[i] = d[i];
         d[i] = 0;
     }
     __threadfence_system();
 }
-void launch_finish(ScanCounters* dev, ScanCounters* host_pinned, int n_blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, stream, dev, host_pinned, (uint32_t)(n_blocks * sizeof(ScanCounters) / 4));
+void launch_finish(ScanCounters* dev, ScanCounters* host_pinned, int n_blocks, uint32_t expect_chains, hipStream_t stream) {
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, stream, dev, host_pinned, (uint32_t)(n_blocks * sizeof(ScanCounters) / 4), expect_chains);
     check_launch("launch_finish");
 }
 void launch_lookup_spill(const LookupParams& p, const DevDb& db, hipStream_t stream) {

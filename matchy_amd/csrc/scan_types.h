@@ -158,6 +158,11 @@ struct ScanCounters {
     uint32_t n_ids;
     alignas(128) uint32_t n_final;   // dense final hit records written by pack_record
     uint32_t n_final_ids;            // entries of the pattern-id / data-offset side arrays
+    // Forked scans without globs: the LAST kernel of every side-stream chain counts its finished workgroups in arrive_wgs[chain]; the
+    // workgroup that completes a chain bumps chains_done, and k_finish — launched on the scan's stream without any event wait — polls
+    // it (a cross-stream event join costs ~20 us between the last kernel and k_finish; the poll ends within a microsecond of the last arrival)
+    alignas(128) uint32_t chains_done;
+    uint32_t arrive_wgs[3];
     alignas(128) uint32_t n_glob_work;   // candidates whose text reaches an output state of the AC automaton (glob work list)
     uint32_t n_spill;                // candidates handed to k_lookup_spill (more glob results / deeper star nesting than a lane of the glob pass holds)
 };
@@ -245,7 +250,9 @@ struct TokParams {
 // k_finish (lookup_kernels.hip): the last kernel of a scan. Copies the counter blocks of the scan's slices into pinned host memory
 // and zeroes them on the device for the next scan — one small kernel instead of a device-to-host copy behind the scan and a memset
 // in front of the next one.
-void launch_finish(ScanCounters* dev, ScanCounters* host_pinned, int n_blocks, hipStream_t stream);
+// expect_chains > 0: the kernel first waits (polling ScanCounters::chains_done of block 0, with a time-out that sets error bit 8) until that
+// many side-stream chains have reported their end.
+void launch_finish(ScanCounters* dev, ScanCounters* host_pinned, int n_blocks, uint32_t expect_chains, hipStream_t stream);
 
 // Called by every launch wrapper right after its hipLaunchKernelGGL: a launch the runtime rejects (LDS or register budget of
 // another target, bad grid) would otherwise show up as a scan without hits. Throws mxy::HipError (engine.cpp).
@@ -278,6 +285,10 @@ struct LookupParams {
     uint32_t direct;
     PackParams pk;
     ScanCounters* counters;
+    // side-stream chains of a forked scan (see ScanCounters::chains_done): this launch is the last kernel of chain `arrive_chain`
+    // (1..3; 0 = none) and reports its end in `arrive` (slice 0's counters)
+    uint32_t arrive_chain;
+    ScanCounters* arrive;
 };
 
 
