@@ -24,12 +24,13 @@ def run(files, jobs):
             if key in l:
                 ph[key] = float(l.split(key)[1].split()[0])
     scan_s = (ph.get("all batches done after", 0) - ph.get("database open after", 0)) / 1e3
-    return dt, info, scan_s
+    nsc = [l.split("(")[1].split()[0] for l in err if "HIP devices" in l]
+    return dt, info, scan_s, (nsc[0] if nsc else "?")
 for i in range(3):
-    dt, info, _ = run(["/tmp/small.log"], "auto")
+    dt, info, _, _ = run(["/tmp/small.log"], "auto")
     print(f"fixed cost (1 MB input): wall {dt:.3f} s {info}", flush=True)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 for jobs in ("1", "2", "auto", "6", "8"):
-    dt, info, scan_s = run(["/tmp/c2.log"] * reps, jobs)
-    print(f"{reps} x {size} B, -j {jobs} ({'4' if jobs == 'auto' else jobs} scanner(s) on one GPU): scan phase {scan_s:.2f} s = {size * reps / max(scan_s, 1e-9) / 1e9:.2f} GB/s; "
+    dt, info, scan_s, nsc = run(["/tmp/c2.log"] * reps, jobs)
+    print(f"{reps} x {size} B, -j {jobs} ({nsc} scanner(s) on one GPU): scan phase {scan_s:.2f} s = {size * reps / max(scan_s, 1e-9) / 1e9:.2f} GB/s; "
           f"wall {dt:.2f} s = {size * reps / dt / 1e9:.2f} GB/s incl. process start and database upload; {info}", flush=True)
