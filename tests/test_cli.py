@@ -132,6 +132,18 @@ def test_match_config1_end_to_end(cli, tmp_path, oracle):
     # small batches (newline-aligned cuts + carry), stdin, CSV database built in memory: same match set
     r2 = _run([cli, "match", str(dbp), str(logp), "--batch-bytes", "65536"])
     assert r2.returncode == 0 and r2.stdout.decode().splitlines() == want_lines
+    # the other input paths of regular files: byte ranges read with pread into pinned buffers; workers that fault and pin their
+    # batches themselves (no reader-side feeding); a batch size above the pinning threshold so that the fed path really pins
+    for env in ({"MATCHY_AMD_PREAD": "1"}, {"MATCHY_AMD_NO_FEEDER": "1"}, {"MATCHY_AMD_NO_REGISTER": "1"}):
+        rp = _run([cli, "match", str(dbp), str(logp), "--batch-bytes", "65536", "-j", "3"], env=dict(os.environ, **env))
+        assert rp.returncode == 0 and rp.stdout.decode().splitlines() == want_lines, env
+    big = log * 6                                      # 10+ MB: batches of 5 MB are pinned by the reader
+    bigp = tmp_path / "big.log"
+    bigp.write_bytes(big)
+    wb = [json.loads(l) for l in oracle.Database(dbp.read_bytes()).scan(big, source=str(bigp))[1]]
+    for env in ({}, {"MATCHY_AMD_PREAD": "1"}, {"MATCHY_AMD_NO_FEEDER": "1"}):
+        rb = _run([cli, "match", str(dbp), str(bigp), "--batch-bytes", str(5 << 20), "-j", "2"], env=dict(os.environ, **env))
+        assert rb.returncode == 0 and [json.loads(l) for l in rb.stdout.decode().splitlines()] == wb, env
     r3 = _run([cli, "match", str(tmp_path / "c1.csv"), "-", "--batch-bytes=100000"], input=log)
     assert r3.returncode == 0
     assert [json.loads(l) | {"source": ""} for l in r3.stdout.decode().splitlines()] == [json.loads(l) | {"source": ""} for l in want_lines]
