@@ -23,6 +23,9 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
+fetch_hits = 9
+
+
 def run_strong(args, rank, local_rank, world, rehearse, torch, dist, dev, coll_dev):
     """--scaling strong: ONE job (BASELINE configs[3]: 100 M lines of the C4 log by default) cut into `world` contiguous line
     ranges (sharding.strong_block_for_rank = split_at_newlines semantics), database replicated, no data-path collective.
@@ -80,7 +83,7 @@ def run_strong(args, rank, local_rank, world, rehearse, torch, dist, dev, coll_d
         ln = cand = hits = 0
         kms = 0.0
         for bi, sz in enumerate(sizes):
-            r = scanner.scan_device(dlog.data_ptr() + bi * cap, sz, stream=stream, fetch_mode=1)
+            r = scanner.scan_device(dlog.data_ptr() + bi * cap, sz, stream=stream, fetch_mode=fetch_hits)
             ln += r.lines; cand += r.candidates; hits += r.n_hits
             r.close()
             kms += scanner.timing_ms()["total"]
@@ -188,6 +191,8 @@ def main():
     ap.add_argument("--pipelined", type=int, default=3, help="N > 1: after the timed steps, time the same K steps again with N batches in flight per GPU "
                     "(scanners on their own streams) and report it as the extra object `pipelined` (never as `value`). 0 / 1 = skip "
                     "(tools/prof.sh does, so that a profile shows every kernel of a step running alone)")
+    ap.add_argument("--records", choices=["compact", "full"], default="compact", help="host-resident hit records of the timed steps: compact = IPv4 results "
+                    "as 8-byte records (MATCHY_SCAN_FETCH_HITS | MATCHY_SCAN_FETCH_COMPACT), everything else 16 bytes; full = 16 bytes for every hit")
     ap.add_argument("--slices", type=int, default=0, help="matchy_scanner_set_slices: 0 = the library's default for the batch size, 1 = one launch of every "
                     "kernel over the whole batch, n = n equal slices")
     ap.add_argument("--extract-flags", type=int, default=0, help="diagnostics only: MATCHY_EXTRACT_* bit mask (0 = what the DB needs)")
@@ -203,6 +208,8 @@ def main():
             args.config = "c4"
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    global fetch_hits
+    fetch_hits = 9 if args.records == "compact" else 1   # MATCHY_SCAN_FETCH_HITS [| MATCHY_SCAN_FETCH_COMPACT]
 
     # --gpus N is what runs. Started by torch.distributed.run (WORLD_SIZE set): the launcher's world must be N. Started
     # directly with N > 1: this process becomes the launcher — one rank per GPU as a CHILD process tree, started before
@@ -277,7 +284,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        res = scanner.scan_device(dlog.data_ptr(), nbytes, stream=stream, fetch_mode=1)
+        res = scanner.scan_device(dlog.data_ptr(), nbytes, stream=stream, fetch_mode=fetch_hits)
         out = (res.lines, res.candidates, res.n_hits)
         res.close()
         return out
@@ -314,7 +321,7 @@ def main():
         turn[0] += 1
         if busy[i]:
             collect(i)
-        scanners[i].submit_device(dlog.data_ptr(), nbytes, stream=streams[i], fetch_mode=1)
+        scanners[i].submit_device(dlog.data_ptr(), nbytes, stream=streams[i], fetch_mode=fetch_hits)
         busy[i] = True
 
     def drain():
@@ -496,6 +503,12 @@ def main():
         ghits = res.hits()
         res.close()
         parity = "ok" if ghits == ohits else f"MISMATCH gpu={len(ghits)} cpu={len(ohits)}"
+        # ... and the records as the timed steps fetch them (device order; compact IPv4 records expanded): the same set
+        res = scanner.scan_device(dlog.data_ptr(), sample_end, stream=stream, fetch_mode=fetch_hits)
+        key = lambda h: (h["start"], h["end"], h["type"], h["kind"], h["prefix_len"], h["ip_data_offset"])
+        if sorted(res.hits(), key=key) != sorted(ohits, key=key):
+            parity = f"MISMATCH in the timed fetch mode ({args.records} records)"
+        res.close()
 
     if rank == 0:
         out = {
@@ -519,6 +532,8 @@ def main():
             "candidates_per_step": agg["candidates"],
             "hits_per_step": agg["hits"],
             "slices": scanner.last_slices_timed,
+            "records": args.records + (" (IPv4 results as 8-byte records: matchy_scan_ip4_hit_t; in host memory when a step ends)" if args.records == "compact"
+                                       else " (16-byte matchy_scan_hit_t for every hit; in host memory when a step ends)"),
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "kernel_ms_note": "HIP-event intervals on the scan's stream: k_anchor alone (it also looks the sparse IPv4 candidates up), then everything "
                               "behind it as one interval (k_validate_dom -> k_lookup on the scan's stream; tokens / IPv6 / e-mail, the undecided domains "

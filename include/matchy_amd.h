@@ -235,6 +235,26 @@ typedef struct matchy_scan_hit_t {
 #define MATCHY_SCAN_HIT_END(h) ((uint64_t)(h).start + MATCHY_SCAN_HIT_LEN(h))
 #define MATCHY_SCAN_HIT_TYPE(h) ((uint8_t)((h).len_type >> 24))
 
+/* Compact form of an IPv4 result (fetch_mode MATCHY_SCAN_FETCH_HITS | MATCHY_SCAN_FETCH_COMPACT), 8 bytes: where nearly every line
+ * of a log hits an IP entry (a CIDR-heavy database) the hit records are what crosses PCIe, and half the bytes is half the time.
+ * packed: offset of the entry data in the MMDB data section in bits 0..21, length of the matched text - 7 in bits 22..25 (a dotted
+ * quad has 7..15 bytes), prefix length (0..32) in bits 26..31. matchy_scan_ip4_hit_expand() gives the 16-byte record back. */
+typedef struct matchy_scan_ip4_hit_t {
+  uint32_t start;
+  uint32_t packed;
+} matchy_scan_ip4_hit_t;
+#define MATCHY_SCAN_IP4_DATA_BITS 22
+static inline matchy_scan_hit_t matchy_scan_ip4_hit_expand(matchy_scan_ip4_hit_t c) {
+  matchy_scan_hit_t h;
+  h.start = c.start;
+  h.len_type = (((c.packed >> MATCHY_SCAN_IP4_DATA_BITS) & 15u) + 7u) | ((uint32_t)MATCHY_ITEM_TYPE_IPV4 << 24);
+  h.value = c.packed & ((1u << MATCHY_SCAN_IP4_DATA_BITS) - 1u);
+  h.kind = 2;
+  h.prefix_len = (uint8_t)(c.packed >> (MATCHY_SCAN_IP4_DATA_BITS + 4));
+  h.n_ids = 0;
+  return h;
+}
+
 typedef struct matchy_scan_result_t {
   const matchy_scan_hit_t *hits;  /* matchy_scanner_scan / fetch_mode 3: canonical order (by start, then chunk-path
                                      class order); fetch_mode 1: device order */
@@ -245,6 +265,8 @@ typedef struct matchy_scan_result_t {
   uint64_t lines;                 /* number of '\n' bytes (WorkerStats::lines_processed) */
   uint64_t candidates;            /* WorkerStats::candidates_tested */
   uint64_t bytes;
+  const matchy_scan_ip4_hit_t *ip4_hits; /* MATCHY_SCAN_FETCH_COMPACT: the IPv4 results (they are NOT in `hits` then); else NULL */
+  size_t n_ip4_hits;                     /* matches of the scan = n_hits + n_ip4_hits */
   void *_internal;
 } matchy_scan_result_t;
 
@@ -266,6 +288,10 @@ int32_t matchy_scanner_scan(matchy_scanner_t *scanner, const uint8_t *data, size
  * GPU, and for inputs where nearly every line hits: 16 bytes per hit over PCIe otherwise bound the scan. */
 #define MATCHY_SCAN_FETCH_DEVICE 4u
 #define MATCHY_SCAN_FETCH_SORTED 3u
+/* 1 | 8 = like 1, but the IPv4 results come as 8-byte records in ip4_hits / n_ip4_hits (same borrowing rules; device order) and
+ * everything else in hits as before. Takes effect when the entry data of every IP entry lies in the first 4 MiB of the data section (22-bit offsets) —
+ * otherwise, and with any other fetch mode, the flag is ignored and n_ip4_hits is 0: read both arrays. */
+#define MATCHY_SCAN_FETCH_COMPACT 8u
 int32_t matchy_scanner_scan_device(matchy_scanner_t *scanner, const void *device_ptr, size_t len, void *hip_stream,
                                    uint32_t fetch_mode, matchy_scan_result_t *out);
 /* The two halves of matchy_scanner_scan_device: submit launches one batch on `hip_stream` and returns, wait blocks until

@@ -93,7 +93,8 @@ class _ScanHit(C.Structure):
 class _ScanResult(C.Structure):
     _fields_ = [("hits", C.POINTER(_ScanHit)), ("n_hits", C.c_size_t), ("pattern_ids", C.POINTER(C.c_uint32)),
                 ("data_offsets", C.POINTER(C.c_int64)), ("n_ids", C.c_size_t), ("lines", C.c_uint64),
-                ("candidates", C.c_uint64), ("bytes", C.c_uint64), ("_internal", C.c_void_p)]
+                ("candidates", C.c_uint64), ("bytes", C.c_uint64), ("ip4_hits", C.POINTER(C.c_uint32 * 2)),
+                ("n_ip4_hits", C.c_size_t), ("_internal", C.c_void_p)]
 
 
 _lib = None
@@ -398,17 +399,22 @@ class ScanResult:
         self.lines = raw.lines
         self.candidates = raw.candidates
         self.bytes = raw.bytes
-        self.n_hits = raw.n_hits
+        self.n_ip4_hits = raw.n_ip4_hits   # fetch_mode 1 | 8: IPv4 results as compact records (not in _raw.hits)
+        self.n_hits = raw.n_hits + raw.n_ip4_hits
         self.on_device = bool(lib().matchy_scan_result_on_device(C.byref(raw)))   # fetch_mode 4: device pointers
 
     def hits(self):
         """list of dict(start,end,type,kind,prefix_len,ip_data_offset,ids,offs) in canonical order."""
         r = self._raw
         out = []
-        if not r.hits:
-            return out
         if self.on_device:
             raise RuntimeError("the hit records of this result are in device memory (fetch_mode 4): read them on the GPU")
+        for i in range(r.n_ip4_hits if r.ip4_hits else 0):   # matchy_scan_ip4_hit_expand
+            start, packed = r.ip4_hits[i]
+            out.append(dict(start=start, end=start + ((packed >> 22) & 15) + 7, type=ITEM_TYPE_NAMES[2], kind="ip", prefix_len=packed >> 26,
+                            ip_data_offset=packed & 0x3FFFFF, ids=[], offs=[]))
+        if not r.hits:
+            return out
         for i in range(r.n_hits):
             h = r.hits[i]
             ids = [r.pattern_ids[h.value + k] for k in range(h.n_ids)] if h.kind == 3 else []
@@ -422,8 +428,10 @@ class ScanResult:
         L = lib()
         if self.on_device:
             raise RuntimeError("the hit records of this result are in device memory (fetch_mode 4): read them on the GPU")
-        return [_take_string(L.matchy_scan_hit_to_json(self._scanner._h, C.byref(self._raw), i, text, source.encode()))
-                for i in range(self._raw.n_hits)] if self._raw.hits else []
+        n = (self._raw.n_hits if self._raw.hits else 0) + (self._raw.n_ip4_hits if self._raw.ip4_hits else 0)
+        if not self._raw.hits and self._raw.n_hits:
+            return []   # counters only
+        return [_take_string(L.matchy_scan_hit_to_json(self._scanner._h, C.byref(self._raw), i, text, source.encode())) for i in range(n)]
 
     def close(self):
         if self._raw is not None:
@@ -465,7 +473,8 @@ class Scanner:
 
     def scan_device(self, device_ptr: int, nbytes: int, stream: int = 0, fetch_mode=1) -> ScanResult:
         """fetch_mode: 0 counters only, 1 hit records in device order (borrowed from the scanner's pinned buffers), 3 hit records
-        in canonical order (owned copy), 4 the records stay in device memory (result.on_device: `_raw.hits` / `pattern_ids` /
+        in canonical order (owned copy), 1 | 8 like 1 with the IPv4 results as 8-byte records (n_ip4_hits; hits() / ndjson() read
+        both arrays), 4 the records stay in device memory (result.on_device: `_raw.hits` / `pattern_ids` /
         `data_offsets` are device addresses; hits() raises)."""
         raw = _ScanResult()
         rc = lib().matchy_scanner_scan_device(self._h, device_ptr, nbytes, stream, fetch_mode, C.byref(raw))

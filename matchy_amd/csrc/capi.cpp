@@ -178,6 +178,7 @@ matchy_t* open_bytes(std::vector<uint8_t>&& bytes) {
     catch (const std::exception& e) { set_error(e.what()); return nullptr; }
 }
 
+static_assert(sizeof(matchy_scan_ip4_hit_t) == sizeof(uint2) && MATCHY_SCAN_IP4_DATA_BITS == C4_DATA_BITS && MATCHY_ITEM_TYPE_IPV4 == IT_IPV4, "compact record layout");
 static_assert(sizeof(FinalHit) == sizeof(matchy_scan_hit_t) && sizeof(FinalHit) == 16 && offsetof(FinalHit, value) == offsetof(matchy_scan_hit_t, value) &&
                   offsetof(FinalHit, n_ids) == offsetof(matchy_scan_hit_t, n_ids) && offsetof(FinalHit, kind) == offsetof(matchy_scan_hit_t, kind),
               "pack_record writes matchy_scan_hit_t records directly");
@@ -205,6 +206,9 @@ void fill_result(const FinalHit* fin, size_t n_fin, const uint32_t* ids, const l
     out->pattern_ids = in->ids.data(); out->data_offsets = in->offs.data();
     out->_internal = in;
 }
+
+// MATCHY_SCAN_FETCH_COMPACT only means something for unsorted host-resident records
+bool compact_mode(uint32_t fetch_mode) { return (fetch_mode & MATCHY_SCAN_FETCH_COMPACT) && (fetch_mode & 7u) == MATCHY_SCAN_FETCH_HITS; }
 
 // fetch_mode MATCHY_SCAN_FETCH_DEVICE: the records stay where the lookup kernel wrote them (device memory); only the counters
 // come back.
@@ -763,11 +767,13 @@ int32_t matchy_scanner_scan_device(matchy_scanner_t* s, const void* dptr, size_t
     try {
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         const bool sorted = (fetch_mode & 2) != 0;
-        h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st, (fetch_mode & 1) && !sorted, /*fork=*/true, h->sc->slices());
+        const bool compact = compact_mode(fetch_mode);
+        h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, st, (fetch_mode & 1) && !sorted, /*fork=*/true, h->sc->slices(), compact);
         ScanOutput so;
         h->sc->fetch(so, false, st, (fetch_mode & 1) ? HITS_FINAL : HITS_NONE, sorted);
-        if (fetch_mode == MATCHY_SCAN_FETCH_DEVICE) { fill_device_result(*h->sc, so, len, out); return MATCHY_SUCCESS; }
+        if ((fetch_mode & 7u) == MATCHY_SCAN_FETCH_DEVICE) { fill_device_result(*h->sc, so, len, out); return MATCHY_SUCCESS; }
         fill_result(so.fin, so.n_fin, so.fin_ids, so.fin_offs, so.n_fin_ids, so.lines, so.n_cand, len, !sorted, sorted, out);
+        out->ip4_hits = reinterpret_cast<const matchy_scan_ip4_hit_t*>(so.c4); out->n_ip4_hits = so.n_c4;
         if (!(fetch_mode & 1)) out->n_hits = so.n_hits;  // count only; `hits` stays NULL
         return MATCHY_SUCCESS;
     } catch (const HipError& e) { set_error(e.what); return MATCHY_ERROR_IO; }
@@ -783,7 +789,8 @@ int32_t matchy_scanner_submit_device(matchy_scanner_t* s, const void* dptr, size
     ScannerH* h = reinterpret_cast<ScannerH*>(s);
     try {
         const bool sorted = (fetch_mode & 2) != 0;
-        h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, reinterpret_cast<hipStream_t>(stream), (fetch_mode & 1) && !sorted);
+        h->sc->scan_device(reinterpret_cast<const uint8_t*>(dptr), (uint32_t)len, true, reinterpret_cast<hipStream_t>(stream), (fetch_mode & 1) && !sorted, /*fork=*/false, 0,
+                           compact_mode(fetch_mode));
         h->pending = true; h->pending_len = len; h->pending_mode = fetch_mode; h->pending_stream = stream;
         return MATCHY_SUCCESS;
     } catch (const HipError& e) { set_error(e.what); return MATCHY_ERROR_IO; }
@@ -800,8 +807,9 @@ int32_t matchy_scanner_wait(matchy_scanner_t* s, matchy_scan_result_t* out) {
         hipStream_t st = reinterpret_cast<hipStream_t>(h->pending_stream);
         ScanOutput so;
         h->sc->fetch(so, false, st, (fetch_mode & 1) ? HITS_FINAL : HITS_NONE, sorted);
-        if (fetch_mode == MATCHY_SCAN_FETCH_DEVICE) { fill_device_result(*h->sc, so, h->pending_len, out); return MATCHY_SUCCESS; }
+        if ((fetch_mode & 7u) == MATCHY_SCAN_FETCH_DEVICE) { fill_device_result(*h->sc, so, h->pending_len, out); return MATCHY_SUCCESS; }
         fill_result(so.fin, so.n_fin, so.fin_ids, so.fin_offs, so.n_fin_ids, so.lines, so.n_cand, h->pending_len, !sorted, sorted, out);
+        out->ip4_hits = reinterpret_cast<const matchy_scan_ip4_hit_t*>(so.c4); out->n_ip4_hits = so.n_c4;
         if (!(fetch_mode & 1)) out->n_hits = so.n_hits;
         return MATCHY_SUCCESS;
     } catch (const HipError& e) { set_error(e.what); return MATCHY_ERROR_IO; }
@@ -819,10 +827,12 @@ bool matchy_scan_result_on_device(const matchy_scan_result_t* r) {
 }
 
 char* matchy_scan_hit_to_json(const matchy_scanner_t* s, const matchy_scan_result_t* r, size_t i, const uint8_t* text, const char* source) {
-    if (!s || !r || !text || i >= r->n_hits || !r->hits) return nullptr;
+    // i counts through hits, then through the compact IPv4 records of a MATCHY_SCAN_FETCH_COMPACT result
+    if (!s || !r || !text || i >= r->n_hits + r->n_ip4_hits) return nullptr;
+    if (i < r->n_hits ? !r->hits : !r->ip4_hits) return nullptr;
     if (matchy_scan_result_on_device(r)) { set_error("matchy_scan_hit_to_json: the records of this result are in device memory (MATCHY_SCAN_FETCH_DEVICE)"); return nullptr; }
     const DbImage& img = reinterpret_cast<const ScannerH*>(s)->sc->image();
-    const matchy_scan_hit_t& h = r->hits[i];
+    const matchy_scan_hit_t h = i < r->n_hits ? r->hits[i] : matchy_scan_ip4_hit_expand(r->ip4_hits[i - r->n_hits]);
     const uint32_t hlen = MATCHY_SCAN_HIT_LEN(h);
     std::string matched((const char*)text + h.start, hlen), o = "{";
     if (h.kind == 2) {

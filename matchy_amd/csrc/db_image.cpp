@@ -125,6 +125,7 @@ bool DbImage::check_structure(std::string& err) const {
             else if (record_size == 28) { l = ((uint32_t)(b[3] >> 4) << 24) | ((uint32_t)b[0] << 16) | ((uint32_t)b[1] << 8) | b[2]; r = ((uint32_t)(b[3] & 0xF) << 24) | ((uint32_t)b[4] << 16) | ((uint32_t)b[5] << 8) | b[6]; }
             else { l = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3]; r = ((uint32_t)b[4] << 24) | ((uint32_t)b[5] << 16) | ((uint32_t)b[6] << 8) | b[7]; }
             if ((uint64_t)l >= limit || (uint64_t)r >= limit) { err = "IP tree record points outside the data section"; return false; }
+            max_ip_record = std::max(max_ip_record, std::max(l, r));
         }
     }
     // ---- literal hash: the length-prefixed string of every occupied slot lies inside the pool (lh:467-543)

@@ -44,6 +44,9 @@ struct DbImage {
     // reachable part of the Aho-Corasick automaton (edges, dense tables, failure links, output lists). All arithmetic in
     // 64 bits.
     bool check_structure(std::string& err) const;
+    // largest record of the IP tree (check_structure): above node_count + 16 it is the largest data-section offset an IP result can carry
+    mutable uint32_t max_ip_record = 0;
+    uint32_t max_ip_data_offset() const { return max_ip_record > node_count + 16 ? max_ip_record - node_count - 16 : 0u; }
 
     const uint8_t* data_section() const { return bytes.data() + tree_size + 16; }
     size_t data_section_len() const { return bytes.size() - (tree_size + 16); }

@@ -50,6 +50,13 @@ __device__ __forceinline__ uint32_t class_of(uint32_t b) {
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+// base + number of set bits of m below this lane
+__device__ __forceinline__ uint32_t mbcnt64_add(uint64_t m, uint32_t base) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
+}
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 // Wave-private chunked list writer. A wave reserves CHUNK slots of a global list with ONE atomic and fills them with
 // ballot/mbcnt-compacted appends; slots it never fills are set to `sentinel` so readers can skip them. This keeps

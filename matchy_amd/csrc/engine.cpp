@@ -463,6 +463,8 @@ Scanner::Scanner(std::shared_ptr<const DbImage> img, std::shared_ptr<DeviceDb> d
 Scanner::~Scanner() {
     if (pinned_) (void)hipHostFree(pinned_);
     if (mirror_) (void)hipHostFree(mirror_);
+    if (mirror_c4_) (void)hipHostFree(mirror_c4_);
+    if (pinned_c4_) (void)hipHostFree(pinned_c4_);
     if (host_slices_) (void)hipHostFree(host_slices_);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_anchor_) if (e) (void)hipEventDestroy(e);
@@ -516,6 +518,14 @@ void Scanner::ensure_mirror(uint32_t recs, uint32_t ids) {
     mirror_cap_ = std::max(recs, mirror_cap_); mirror_ids_cap_ = std::max(ids, mirror_ids_cap_);
     const size_t bytes = (size_t)mirror_cap_ * sizeof(FinalHit) + (size_t)mirror_ids_cap_ * 12 + 64;
     MXY_HIP(hipHostMalloc(&mirror_, bytes, hipHostMallocDefault));
+}
+
+void Scanner::ensure_mirror_c4(uint32_t recs) {
+    if (mirror_c4_ && mirror_c4_cap_ >= recs) return;
+    if (mirror_c4_) (void)hipHostFree(mirror_c4_);
+    mirror_c4_ = nullptr;
+    mirror_c4_cap_ = std::max(recs, mirror_c4_cap_);
+    MXY_HIP(hipHostMalloc((void**)&mirror_c4_, (size_t)mirror_c4_cap_ * sizeof(uint2), hipHostMallocDefault));
 }
 
 namespace {
@@ -605,6 +615,10 @@ void Scanner::slice_params(int sl, const uint8_t* dptr, uint32_t len, uint32_t l
             pp.host_ids = (uint32_t*)(mb + (size_t)mirror_cap_ * sizeof(FinalHit));
             pp.host_offs = (long long*)(mb + (size_t)mirror_cap_ * sizeof(FinalHit) + (((size_t)mirror_ids_cap_ * 4 + 7) & ~(size_t)7));
             pp.host_ids_cap = mirror_ids_cap_;
+        }
+        if (compact_) {
+            pp.c4_out = c4_.p; pp.c4_cap = (uint32_t)c4_.n;
+            if (host_mirror) { pp.host_c4 = mirror_c4_; pp.host_c4_cap = mirror_c4_cap_; }
         }
         pp.counters = counters_.p;   // n_final / n_final_ids of slice 0 hand out the slots of the shared record arrays
         // k_lookup writes the final records itself (the PCIe writes of the mirror overlap the lookups); only the
@@ -696,11 +710,13 @@ int Scanner::plan_slices(uint32_t len, int want, uint32_t (&cuts)[MAX_SLICES + 1
     return n;
 }
 
-void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror, bool fork, int slices) {
+void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror, bool fork, int slices, bool compact) {
     if (len >= 0x7FFF0000u) throw HipError{"scan_device: chunk too large (must be < 2^31 bytes)"};
     if (((uintptr_t)dptr & 15) != 0) throw HipError{"scan_device: device pointer must be 16-byte aligned"};
     MXY_HIP(hipSetDevice(ddb_->device));
     last_ptr_ = dptr; last_len_ = len; last_lookup_ = lookup; last_mirror_ = host_mirror; last_fork_ = fork; last_slices_ = slices;
+    last_compact_ = compact;
+    compact_ = compact && lookup && compact_possible();
     last_forked_ = false;
     spill_done_ = false;
     expect_chains_ = 0;
@@ -721,8 +737,10 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     if (lookup && host_mirror) {
         static const uint32_t mirror0 = getenv("MATCHY_AMD_MIRROR_RECS") ? (uint32_t)atoi(getenv("MATCHY_AMD_MIRROR_RECS")) : (1u << 20);
         ensure_mirror(std::max(mirror0, 16u), std::max(mirror0 / 16, 16u));
+        if (compact_) ensure_mirror_c4(std::max(mirror0, 16u));
         mirror_used_ = true;
     }
+    if (compact_ && c4_.n < final_.n) c4_.alloc(final_.n);
     for (int k = 0; k < ns; ++k) slice_params(k, dptr, len, cuts[k], cuts[k + 1], lookup, host_mirror, launch_[k]);
     // the counter blocks are zero already when the last scan ended with fetch() (k_finish copies them out and clears them)
     if (!counters_clean_) MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters) * MAX_SLICES, stream));
@@ -934,7 +952,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
             const ScanCounters& s = host_slices_[k];
             c.lines += s.lines; c.cand_true += s.cand_true; c.hits_true += s.hits_true; c.error |= s.error;
         }
-        bool over = c.n_final > final_.n || c.n_final_ids > final_ids_.n;
+        bool over = c.n_final > final_.n || c.n_final_ids > final_ids_.n || (compact_ && c.n_c4 > c4_.n);
         for (int k = 0; k < ns; ++k) {
             const ScanCounters& s = host_slices_[k];
             const Work& w = work_[k];
@@ -998,7 +1016,8 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
             const size_t want = std::max<size_t>(recs + ids, grown(c.n_final_ids));
             final_ids_.alloc(want); final_offs_.alloc(want);
         }
-        scan_device(last_ptr_, last_len_, last_lookup_, stream, last_mirror_, last_fork_, last_slices_);
+        if (compact_ && c.n_c4 > c4_.n) c4_.alloc(grown(c.n_c4));
+        scan_device(last_ptr_, last_len_, last_lookup_, stream, last_mirror_, last_fork_, last_slices_, last_compact_);
     }
     const ScanCounters& c = host_counters_;
     if (c.error & 1) throw HipError{"scan: a candidate matches more than 65535 glob patterns (the hit record counts pattern ids in 16 bits)"};
@@ -1016,7 +1035,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
                 ns, c.lines, t.n_dom, t.n_rare, t.n_rare_dom, t.n_tok, t.n_heavy, t.n_cand_a, t.n_cand, c.cand_true, t.n_hits, c.hits_true, t.n_ids, t.n_glob_work, c.n_final);
     }
     out.lines = c.lines; out.n_cand = single_ ? c.n_cand : c.cand_true;
-    out.n_hits = !last_lookup_ ? 0 : (single_ ? c.hits_true : c.n_final);
+    out.n_hits = !last_lookup_ ? 0 : (single_ ? c.hits_true : c.n_final + (compact_ ? c.n_c4 : 0u));
     if (profile_) {
         MXY_HIP(hipEventElapsedTime(&timing_.anchor_ms, ev_[0], ev_[1]));
         if (last_forked_) {   // one interval for everything behind k_anchor (kernels on three streams)
@@ -1032,6 +1051,8 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     }
     out.hits.clear(); out.ids.clear(); out.cands.clear();
     out.fin = nullptr; out.fin_ids = nullptr; out.fin_offs = nullptr; out.n_fin = 0; out.n_fin_ids = 0;
+    out.c4 = nullptr; out.n_c4 = 0;
+    const bool had_mirror = mirror_used_;
     Work& w0 = work_[0];   // raw hits and candidate lists are read by one-slice scans only (single queries, extraction)
     const bool get_raw = last_lookup_ && hit_mode == HITS_RAW && c.n_hits;
     const bool get_fin = last_lookup_ && hit_mode == HITS_FINAL && c.n_final;
@@ -1077,6 +1098,21 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         }
         out.fin = (const FinalHit*)base; out.n_fin = c.n_final;
         out.fin_ids = (const uint32_t*)(base + hb); out.fin_offs = (const long long*)(base + hb + ib); out.n_fin_ids = c.n_final_ids;
+    }
+    if (last_lookup_ && hit_mode == HITS_FINAL && compact_ && c.n_c4) {
+        if (had_mirror && !sorted && c.n_c4 <= mirror_c4_cap_) out.c4 = mirror_c4_;   // written by the kernels
+        else {
+            if (had_mirror) { mirror_used_ = false; ensure_mirror_c4(c.n_c4 + c.n_c4 / 2); }   // a larger mirror next time
+            if (pinned_c4_n_ < c.n_c4) {
+                if (pinned_c4_) (void)hipHostFree(pinned_c4_);
+                pinned_c4_ = nullptr;
+                pinned_c4_n_ = (size_t)c.n_c4 + c.n_c4 / 4 + 1024;
+                MXY_HIP(hipHostMalloc((void**)&pinned_c4_, pinned_c4_n_ * sizeof(uint2), hipHostMallocDefault));
+            }
+            MXY_HIP(hipMemcpyAsync(pinned_c4_, c4_.p, (size_t)c.n_c4 * sizeof(uint2), hipMemcpyDeviceToHost, stream));
+            out.c4 = pinned_c4_;
+        }
+        out.n_c4 = c.n_c4;
     }
     if (want_cands && c.n_cand + c.n_cand_a) {   // k_anchor's IPv4 list, then the validation kernels' list
         out.cands.resize((size_t)c.n_cand_a + c.n_cand);

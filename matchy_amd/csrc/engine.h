@@ -103,6 +103,9 @@ struct ScanOutput {
     const uint32_t* fin_ids = nullptr;
     const long long* fin_offs = nullptr;
     size_t n_fin = 0, n_fin_ids = 0;
+    // compact IPv4 records of a scan with `compact` set (they are NOT in fin then), BORROWED like fin
+    const uint2* c4 = nullptr;
+    size_t n_c4 = 0;
     uint64_t lines = 0;
     uint32_t n_cand = 0, n_hits = 0;
     uint64_t by_type[IT_COUNT] = {0};
@@ -121,7 +124,11 @@ public:
     // host-to-device copy (scan_host) stay on one stream per scanner: the runtime multiplexes streams onto a few hardware queues,
     // and three scanners with three streams each ran 25 % slower than with one each.
     // slices > 1 (with fork): cut the batch into that many slices (see MAX_SLICES); 0 = the scanner's default for the batch size
-    void scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror = false, bool fork = false, int slices = 0);
+    // compact: IPv4 results leave as 8-byte records (ScanOutput::c4, scan_types.h c4_pack) when compact_possible()
+    void scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStream_t stream, bool host_mirror = false, bool fork = false, int slices = 0,
+                     bool compact = false);
+    // the compact record holds data-section offsets of C4_DATA_BITS bits: every offset an IP result of this database can carry must fit
+    bool compact_possible() const { return img_->max_ip_data_offset() < (1u << C4_DATA_BITS); }
     // Copies counters (and hits / candidates) back. Call after scan_device; synchronises the stream.
     // sorted: the final records are put into canonical order on the GPU (sort_hits.hip) before they are copied back
     void fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode = HITS_FINAL, bool sorted = false);
@@ -221,6 +228,14 @@ private:
     uint32_t mirror_cap_ = 0, mirror_ids_cap_ = 0;
     bool mirror_used_ = false, last_mirror_ = false;
     void ensure_mirror(uint32_t recs, uint32_t ids);
+    // compact IPv4 records (scan_device `compact`): device array, pinned mirror written by the kernels, pinned block of the copy path
+    DevBuf<uint2> c4_;
+    uint2* mirror_c4_ = nullptr;
+    uint32_t mirror_c4_cap_ = 0;
+    void ensure_mirror_c4(uint32_t recs);
+    uint2* pinned_c4_ = nullptr;
+    size_t pinned_c4_n_ = 0;
+    bool compact_ = false, last_compact_ = false;   // of the last scan_device: in effect / as asked for
     void* pinned_ = nullptr;   // one pinned block: FinalHit[n] | u32 ids[m] | i64 offs[m]  (or Hit[n] for HITS_RAW)
     size_t pinned_bytes_ = 0;
     void ensure_pinned(size_t bytes);

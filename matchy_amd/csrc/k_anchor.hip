@@ -46,14 +46,6 @@ constexpr uint32_t QCAP = 128;              // ring entries per wave and type
 constexpr uint32_t RAW_BYTES = 8192;
 static_assert(SEG_ALIGN % RAW_BYTES == 0 && RAW_BYTES % BLK_BYTES == 0 && RAW_BYTES >= 3 * BLK_BYTES, "window wraps on block edges inside a segment");
 
-// base + number of set bits of m below this lane
-__device__ __forceinline__ uint32_t mbcnt64_add(uint64_t m, uint32_t base) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
-}
-__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
 // N dwords of the circular window starting at absolute byte position `a`, shifted so that byte `a` is byte 0. The first
 // RAW_MIRROR bytes of the window are kept a second time behind its end, so a read that starts near the end runs straight on
 // (constant offsets: ds_read2_b32 pairs, no wrap arithmetic per dword).
@@ -198,19 +190,33 @@ __device__ __forceinline__ void v4_lookup_flush(V4Lookup& vl) {
     if (m) {
         const ColdTok kp = cold_tok();
         ScanCounters* const ctr = kp->pk.counters;
-        FinalHit* const out = kp->pk.out;
-        FinalHit* const host_out = kp->pk.host_out;
-        const uint32_t out_cap = kp->pk.out_cap, host_cap = kp->pk.host_cap;
-        uint32_t slot0 = 0;
-        if (lane == 0) slot0 = atomicAdd(&ctr->n_final, (uint32_t)__popcll(m));
-        slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
-        if (hit) {
-            const uint32_t slot = slot0 + mbcnt64(m);
-            FinalHit f{};
-            f.start = e.x; f.len_type = v4_text_len(e.y) | ((uint32_t)IT_IPV4 << 24);
-            f.value = off; f.kind = 2; f.prefix_len = (uint8_t)pfx; f.n_ids = 0;
-            if (slot < out_cap) out[slot] = f;
-            if (slot < host_cap) host_out[slot] = f;
+        if (uint2* const c4 = kp->pk.c4_out) {   // compact records (MATCHY_SCAN_FETCH_COMPACT)
+            uint2* const host_c4 = kp->pk.host_c4;
+            const uint32_t c4_cap = kp->pk.c4_cap, host_cap = kp->pk.host_c4_cap;
+            uint32_t slot0 = 0;
+            if (lane == 0) slot0 = atomicAdd(&ctr->n_c4, (uint32_t)__popcll(m));
+            slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
+            if (hit) {
+                const uint32_t slot = slot0 + mbcnt64(m);
+                const uint2 r = c4_pack(e.x, v4_text_len(e.y), off, pfx);
+                if (slot < c4_cap) c4[slot] = r;
+                if (slot < host_cap) host_c4[slot] = r;
+            }
+        } else {
+            FinalHit* const out = kp->pk.out;
+            FinalHit* const host_out = kp->pk.host_out;
+            const uint32_t out_cap = kp->pk.out_cap, host_cap = kp->pk.host_cap;
+            uint32_t slot0 = 0;
+            if (lane == 0) slot0 = atomicAdd(&ctr->n_final, (uint32_t)__popcll(m));
+            slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
+            if (hit) {
+                const uint32_t slot = slot0 + mbcnt64(m);
+                FinalHit f{};
+                f.start = e.x; f.len_type = v4_text_len(e.y) | ((uint32_t)IT_IPV4 << 24);
+                f.value = off; f.kind = 2; f.prefix_len = (uint8_t)pfx; f.n_ids = 0;
+                if (slot < out_cap) out[slot] = f;
+                if (slot < host_cap) host_out[slot] = f;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();

@@ -158,6 +158,7 @@ struct ScanCounters {
     uint32_t n_ids;
     alignas(128) uint32_t n_final;   // dense final hit records written by pack_record
     uint32_t n_final_ids;            // entries of the pattern-id / data-offset side arrays
+    uint32_t n_c4;                   // compact IPv4 records (PackParams::c4_out)
     // Forked scans without globs: the LAST kernel of every side-stream chain counts its finished workgroups in arrive_wgs[chain]; the
     // workgroup that completes a chain bumps chains_done, and k_finish — launched on the scan's stream without any event wait — polls
     // it (a cross-stream event join costs ~20 us between the last kernel and k_finish; the poll ends within a microsecond of the last arrival)
@@ -198,8 +199,20 @@ struct PackParams {
     uint32_t* host_ids;
     long long* host_offs;
     uint32_t host_ids_cap;
+    // MATCHY_SCAN_FETCH_COMPACT: IPv4 results leave as 8-byte records (c4_pack) in arrays of their own — device copy + pinned host mirror like
+    // `out` / `host_out`, slots from ScanCounters::n_c4 — instead of as FinalHit records. nullptr: every result is a FinalHit.
+    uint2* c4_out;
+    uint2* host_c4;
+    uint32_t c4_cap, host_c4_cap;
     ScanCounters* counters;
 };
+
+// Compact IPv4 result, bit-identical to matchy_scan_ip4_hit_t (include/matchy_amd.h): start | data offset in bits 0..21, text length - 7
+// in bits 22..25, prefix length in bits 26..31. Only offered for databases whose data section is at most 4 MiB (Scanner::compact_possible).
+constexpr uint32_t C4_DATA_BITS = 22;
+__host__ __device__ inline uint2 c4_pack(uint32_t start, uint32_t len, uint32_t data_off, uint32_t prefix) {
+    return make_uint2(start, data_off | ((len - 7u) << C4_DATA_BITS) | (prefix << (C4_DATA_BITS + 4)));
+}
 
 struct TokParams {
     const uint8_t* log;

@@ -145,6 +145,26 @@ def _scan_both(M, oracle, blob, text):
                 assert rs.hits() == got_hits
                 rs.close()
         sc.set_slices(0)
+        # ... and with the IPv4 results as compact 8-byte records (fetch_mode 1 | 8, device order): same matches, every IPv4 result
+        # in the compact array (these databases' data sections are far below the 4 MiB the record addresses); forked, sliced and
+        # through submit / wait (one stream)
+        key = lambda h: (h["start"], h["end"], h["type"], h["kind"])
+        n_v4 = sum(1 for h in got_hits if h["type"] == "IPv4")
+        for how in ("forked", "sliced", "submitted"):
+            if how == "sliced":
+                if len(text) < 3 * 8192:
+                    continue
+                sc.set_slices(3)
+            if how == "submitted":
+                sc.submit_device(dptr.value, len(text), fetch_mode=9)
+                rc = sc.wait()
+            else:
+                rc = sc.scan_device(dptr.value, len(text), fetch_mode=9)
+            sc.set_slices(0)
+            assert (rc.lines, rc.candidates, rc.n_hits, rc.n_ip4_hits) == (*got_stats, len(got_hits), n_v4), how
+            assert sorted(rc.hits(), key=key) == sorted(got_hits, key=key), how
+            assert sorted(rc.ndjson(text, source="t.log")) == sorted(got_lines), how
+            rc.close()
         hip.hipFree(dptr)
     sc.close(); db.close()
     odb = oracle.Database(blob)
@@ -167,6 +187,34 @@ def test_scan_small_combined_database(M, oracle):
     assert gl == wl
     assert gs == ws
     assert len(gh) >= 8
+
+
+def test_compact_records_need_a_small_data_section(M, oracle):
+    """MATCHY_SCAN_FETCH_COMPACT addresses the data section with 22 bits: a database with more than 4 MiB of entry data keeps
+    the 16-byte records (the flag is ignored: n_ip4_hits 0, same matches)."""
+    import ctypes
+    b = M.DatabaseBuilder(build_epoch=1)
+    for k in range(40):
+        b.add_entry(f"10.{k}.0.0/16", {"blob": ("%02d" % k) * 70000})   # 140 KB of data each: 5.6 MB
+    b.add_entry("evil.example.com", {"d": 1})
+    blob = b.build()
+    text = b"".join(b"client 10.%d.%d.7 asked evil.example.com\n" % (k % 50, k) for k in range(400))
+    want, want_lines, st = oracle.Database(blob).scan(text, source="t.log")
+    db = M.Database(blob)
+    sc = M.Scanner(db)
+    hip = ctypes.CDLL("libamdhip64.so")
+    dptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(len(text) + 64)) == 0
+    assert hip.hipMemcpy(dptr, text, ctypes.c_size_t(len(text)), 1) == 0
+    r = sc.scan_device(dptr.value, len(text), fetch_mode=9)
+    assert r.n_ip4_hits == 0 and r.n_hits == len(want) > 400
+    key = lambda h: (h["start"], h["end"], h["type"])
+    assert sorted(r.hits(), key=key) == sorted(want, key=key)
+    assert max(h["ip_data_offset"] for h in want) >= 1 << 22
+    assert sorted(r.ndjson(text, source="t.log")) == sorted(want_lines)
+    r.close()
+    hip.hipFree(dptr)
+    sc.close(); db.close()
 
 
 @pytest.mark.parametrize("cfgname,lines", [("c1", 10000), ("c2/20", 20000), ("c3/20", 20000), ("c3b/20", 20000), ("c4/20", 20000),

@@ -234,6 +234,13 @@ def test_scan_device_fetch_modes(M, oracle, cfgname, mirror, monkeypatch):
         r3.close()
         assert h3 == want
         assert sorted(h1, key=key) == sorted(want, key=key)
+        # fetch_mode 1 | 8: the IPv4 results as compact 8-byte records in an array (and a pinned mirror) of their own — with the
+        # 64-record mirror the first scan takes the copy path and grows it
+        r9 = sc.scan_device(d.data_ptr(), len(log), fetch_mode=9)
+        assert (r9.lines, r9.candidates, r9.n_hits) == (st.lines, st.candidates, len(want))
+        assert r9.n_ip4_hits == sum(1 for h in want if h["type"] == "IPv4") > 0
+        assert sorted(r9.hits(), key=key) == sorted(want, key=key)
+        r9.close()
         # fetch_mode 4: the records stay in device memory (borrowed device pointers); copied back here they are the same set
         r4 = sc.scan_device(d.data_ptr(), len(log), fetch_mode=4)
         assert (r4.lines, r4.candidates, r4.n_hits) == (st.lines, st.candidates, len(want))
@@ -330,6 +337,22 @@ def test_config5_full_database(M, oracle):
     assert stats == (st.lines, st.candidates)
     assert len(hits) == len(want) and len(want) > lines
     assert hits == want
+    # the same log resident in HBM with compact IPv4 records (fetch_mode 1 | 8): more records than the first pinned mirror holds
+    # (copy path, then a larger mirror), then straight from the mirror the lookup kernel writes
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    dptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(len(log) + 64)) == 0
+    assert hip.hipMemcpy(dptr, log, ctypes.c_size_t(len(log)), 1) == 0
+    key = lambda h: (h["start"], h["end"], h["type"], h["prefix_len"], h["ip_data_offset"])
+    want_sorted = sorted(want, key=key)
+    for rep in range(2):
+        r9 = sc.scan_device(dptr.value, len(log), fetch_mode=9)
+        assert (r9.lines, r9.candidates, r9.n_hits) == (st.lines, st.candidates, len(want))
+        assert r9.n_ip4_hits == sum(1 for h in want if h["type"] == "IPv4") > lines // 2
+        assert sorted(r9.hits(), key=key) == want_sorted
+        r9.close()
+    hip.hipFree(dptr)
     sc.close(); db.close()
 
 
