@@ -833,6 +833,8 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
             flag = g ? CAND_GLOB : CAND_NO_GLOB;
             lit = lit || g;
         }
+        // the automaton was walked over the whole name right here: k_lookup need not walk it again to route the candidate
+        if constexpr (AC) flag = pend_over ? CAND_GLOB : CAND_NO_GLOB;
         cw.append(pend && lit, Candidate{pend_start, pend_lt, 0u, flag}, p.cands, p.cand_cap, p.n_cand);
     };
     for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
@@ -935,7 +937,8 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
                                 any |= t;
                             }
                         }
-                        if (any >> 31) { pend_word = 0xFFFFFFFFu; pend_bit = 0; }
+                        pend_over = (any >> 31) != 0;
+                        if (pend_over) { pend_word = 0xFFFFFFFFu; pend_bit = 0; }
                     }
                 }
             }
