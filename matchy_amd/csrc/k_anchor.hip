@@ -441,6 +441,16 @@ __device__ __forceinline__ uint32_t plane_next_dword(uint32_t P, uint32_t ahead)
     const uint32_t fix63 = ((s0 >> 1) & 0x7F7F7F7Fu) | ahead;
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fix63, (int)P, DPP_WAVE_SHL1, 0xF, 0xF, false);
 }
+// inclusive prefix sum over the 64 lanes: four row shifts (zeros shifted in), then the row totals broadcast into the following rows
+__device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
 // class of the byte k positions earlier / later (k = 1..4), aligned to this position
 template <int K> __device__ __forceinline__ uint32_t back(uint32_t P, uint32_t PV) { return K == 4 ? PV : __builtin_amdgcn_alignbyte(P, PV, 4 - K); }
 template <int K> __device__ __forceinline__ uint32_t ahead(uint32_t P, uint32_t NV) { return K == 4 ? NV : __builtin_amdgcn_alignbyte(NV, P, K); }
@@ -605,30 +615,64 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             if (p.debug & 8) Fd = 0;
             if (p.debug & 64) { nl_count += (F4 | Fd | F6) & 1; F4 = 0; Fd = 0; F6 = 0; }
 #endif
-            if (en_dom) {
-                for (;;) {
-                    const uint64_t m = __ballot(Fd != 0);
-                    if (!m) break;
-                    if (Fd) {
-                        rdom[mbcnt64_add(m, dt) & (QCAP - 1)] = ent_base | (uint32_t)__builtin_ctz(Fd);
-                        Fd &= Fd - 1;
-                    }
+            // ---- anchors into the rings. One inclusive wave scan of the per-lane anchor counts (both kinds in one word, six DPP adds)
+            // gives every lane the ring positions of its own anchors: the lanes then write them without any further cross-lane step
+            // (the ballot loop below costs a ballot, two mbcnt and a dozen scalar instructions per anchor of the busiest lane).
+            // A block with more anchors than the ring has room for (dense runs of dots) takes the ballot loop, which drains as it goes.
+            const uint32_t cnt2 = (en_dom ? (uint32_t)__popc(Fd) : 0u) | ((en_v4 ? (uint32_t)__popc(F4) : 0u) << 16);
+            const uint32_t incl2 = wave_incl_scan_add(cnt2);
+            const uint32_t tot2 = (uint32_t)__builtin_amdgcn_readlane((int)incl2, 63);
+            const uint32_t excl2 = incl2 - cnt2;
+            if (en_dom && (tot2 & 0xFFFFu)) {
+                const uint32_t total = tot2 & 0xFFFFu;
+                if (dt - dh + total <= QCAP) {
                     if (dt == dh) dom_old = blk;
-                    dt += (uint32_t)__popcll(m);
-                    if (dt - dh >= 64) { drain_dom(rdom, dh, dt, 64u, false, cx, cw_dom); dom_old = blk; }
+                    uint32_t idx = dt + (excl2 & 0xFFFFu);
+                    while (Fd) {
+                        rdom[idx & (QCAP - 1)] = ent_base | (uint32_t)__builtin_ctz(Fd);
+                        Fd &= Fd - 1;
+                        ++idx;
+                    }
+                    dt += total;
+                    while (dt - dh >= 64) { drain_dom(rdom, dh, dt, 64u, false, cx, cw_dom); dom_old = blk; }
+                } else {
+                    for (;;) {
+                        const uint64_t m = __ballot(Fd != 0);
+                        if (!m) break;
+                        if (Fd) {
+                            rdom[mbcnt64_add(m, dt) & (QCAP - 1)] = ent_base | (uint32_t)__builtin_ctz(Fd);
+                            Fd &= Fd - 1;
+                        }
+                        if (dt == dh) dom_old = blk;
+                        dt += (uint32_t)__popcll(m);
+                        if (dt - dh >= 64) { drain_dom(rdom, dh, dt, 64u, false, cx, cw_dom); dom_old = blk; }
+                    }
                 }
             }
-            if (en_v4) {
-                for (;;) {
-                    const uint64_t m = __ballot(F4 != 0);
-                    if (!m) break;
-                    if (F4) {
-                        rv4[mbcnt64_add(m, v4t) & (QCAP - 1)] = ent_base | (uint32_t)__builtin_ctz(F4);
-                        F4 &= F4 - 1;
-                    }
+            if (en_v4 && (tot2 >> 16)) {
+                const uint32_t total = tot2 >> 16;
+                if (v4t - v4h + total <= QCAP) {
                     if (v4t == v4h) v4_old = blk;
-                    v4t += (uint32_t)__popcll(m);
-                    if (v4t - v4h >= 64) { drain_v4<INL>(rv4, v4h, v4t, 64u, false, cx, pend, cw_cand, vl); v4_old = blk; }
+                    uint32_t idx = v4t + (excl2 >> 16);
+                    while (F4) {
+                        rv4[idx & (QCAP - 1)] = ent_base | (uint32_t)__builtin_ctz(F4);
+                        F4 &= F4 - 1;
+                        ++idx;
+                    }
+                    v4t += total;
+                    while (v4t - v4h >= 64) { drain_v4<INL>(rv4, v4h, v4t, 64u, false, cx, pend, cw_cand, vl); v4_old = blk; }
+                } else {
+                    for (;;) {
+                        const uint64_t m = __ballot(F4 != 0);
+                        if (!m) break;
+                        if (F4) {
+                            rv4[mbcnt64_add(m, v4t) & (QCAP - 1)] = ent_base | (uint32_t)__builtin_ctz(F4);
+                            F4 &= F4 - 1;
+                        }
+                        if (v4t == v4h) v4_old = blk;
+                        v4t += (uint32_t)__popcll(m);
+                        if (v4t - v4h >= 64) { drain_v4<INL>(rv4, v4h, v4t, 64u, false, cx, pend, cw_cand, vl); v4_old = blk; }
+                    }
                 }
             }
             if (en_v6 || en_at) {
