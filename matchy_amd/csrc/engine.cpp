@@ -571,7 +571,7 @@ void Scanner::slice_params(int sl, const uint8_t* dptr, uint32_t len, uint32_t l
     tp.cand_chunk = (lookup && ddb_->view.ip_bm24_permille <= 250) ? 64u : 1024u;
     tp.rare = w.rare.p; tp.rare_cap = (uint32_t)w.rare.n;
     tp.rare_dom = w.rare_dom.p; tp.rare_dom_cap = (uint32_t)w.rare_dom.n;
-    tp.vmode = 3u;
+    tp.vmode = 7u;
     tp.tok = w.tok.p; tp.tok_cap = (uint32_t)w.tok.n;
     tp.heavy = w.heavy.p; tp.heavy_cap = (uint32_t)w.heavy.n;
     tp.dom_list = w.dom_list.p; tp.dom_cap = (uint32_t)w.dom_slots;
@@ -777,7 +777,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
             }
             MXY_HIP(hipStreamWaitEvent(aux2_stream_, done, 0));
             TokParams t1 = L.tp;
-            t1.vmode = 1u;
+            t1.vmode = 5u;
             if (L.split_misc) { t1.cands = work_[k].cands_m.p; t1.cand_cap = (uint32_t)work_[k].cands_m.n; t1.n_cand = &(counters_.p + k)->n_cand_m; }
             launch_validate_misc(t1, view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);
             if (L.split_misc) launch_lookup(L.lm, view, std::max(1, n_cu_ / 2), aux2_stream_);
@@ -832,18 +832,24 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         }
         MXY_HIP(hipStreamWaitEvent(aux2_stream_, fork, 0));
         TokParams t1 = tp;
-        t1.vmode = 1u;
+        t1.vmode = 5u;
         if (L.split_misc) { t1.cands = work_[0].cands_m.p; t1.cand_cap = (uint32_t)work_[0].cands_m.n; t1.n_cand = &counters_.p->n_cand_m; }
-        // beside k_validate_dom: half the CUs, so that kernel keeps most of its resident waves
-        launch_validate_misc(t1, view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);
         // split lists: the lookups of k_validate's candidates do not wait for k_rare (checksum validators: a chain of their own,
         // almost always over next to nothing), whose few candidates get a list and a lookup launch of their own — on the second
-        // stream when the IPv4 lookups do not need it (they run inside k_anchor), beside the third stream's lookups
+        // stream when the IPv4 lookups do not need it (they run inside k_anchor), beside the third stream's lookups. The long tokens
+        // — k_rare takes what they leave — then get a launch of their own in front of the rare anchors (IPv6 / e-mail: ten times as
+        // many, 0.12 ms), so that k_rare runs beside those instead of behind them.
         const bool rare_own = L.split_misc && rare_possible && !L.ip_pass;
         if (rare_own) {
+            TokParams tt = t1;
+            tt.vmode = 4u;
+            launch_validate_misc(tt, view, std::max(1, n_cu_ / 8), aux2_stream_);
             if (!ev_v1_) MXY_HIP(hipEventCreateWithFlags(&ev_v1_, hipEventDisableTiming));
             MXY_HIP(hipEventRecord(ev_v1_, aux2_stream_));
+            t1.vmode = 1u;
         }
+        // beside k_validate_dom: half the CUs, so that kernel keeps most of its resident waves
+        launch_validate_misc(t1, view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);
         // Split lists: the side chains do not join the scan's stream through events — the last kernel of each (a k_lookup launch) reports
         // its end in ScanCounters::chains_done, which k_finish polls (arrive_chain 1: third stream, 2: k_rare's, 3: the fourth stream)
         static const bool env_join = getenv("MATCHY_AMD_EVENT_JOIN") != nullptr;

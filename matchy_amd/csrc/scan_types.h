@@ -241,7 +241,7 @@ struct TokParams {
     uint32_t rare_cap;
     RareAnchor* rare_dom;     // undecided domain anchors (written by k_validate_dom)
     uint32_t rare_dom_cap;
-    uint32_t vmode;           // k_validate: bit 0 = long tokens + the rare list, bit 1 = the rare_dom list
+    uint32_t vmode;           // k_validate: bit 0 = the rare list (IPv6 / e-mail anchors), bit 1 = the rare_dom list, bit 2 = the long tokens
     RareAnchor* tok;          // long-token anchors
     uint32_t tok_cap;
     RareAnchor* heavy;        // tokens that passed the cheap prefilters of k_validate and need k_rare

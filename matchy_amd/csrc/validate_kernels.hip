@@ -958,16 +958,21 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
 
 // k_validate — stage A2b: one lane per long token (hex hashes; prefix tests for the address formats) and per rare
 // anchor: IPv6, e-mail, and the domain anchors k_validate_dom could not decide (general right-to-left walk).
-// VM = TokParams::vmode of the launch (bit 0: long tokens + k_anchor's rare anchors, bit 1: the undecided domains). The two halves
+// VM = TokParams::vmode of the launch (bit 0: k_anchor's rare anchors, bit 1: the undecided domains, bit 2: the long tokens — a launch of
+// their own in forked scans, so that k_rare, which takes what they leave, can start beside the rare anchors). The two halves
 // need different LDS — the IPv6 windows (20 KB) for the first, the public-suffix tables (20 KB) for the second — and the first runs
 // BESIDE k_validate_dom, whose workgroups hold most of a CU's LDS: with 26 KB instead of 47 its workgroups find room at once
 // instead of waiting for k_validate_dom's to retire.
 template <uint32_t VM>
 __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
-    constexpr bool MISC = (VM & 1u) != 0, DOM = (VM & 2u) != 0;
+    constexpr bool MISC = (VM & 1u) != 0, DOM = (VM & 2u) != 0, TOK = (VM & 4u) != 0;
     __shared__ uint32_t bloom[DOM ? TLD_BLOOM_WORDS : 1];
     __shared__ uint2 tldtab[DOM ? (1u << TLD_TAB_BITS) : 1];
     __shared__ __attribute__((aligned(16))) uint8_t winbuf[MISC ? 256 * 80 : 16];   // one 80-byte IPv6 window per lane
+    if constexpr (DOM && !MISC) {
+        // the undecided domains are a few thousand per batch: workgroups beyond the list leave before they stage 20 KB of tables
+        if (blockIdx.x * blockDim.x >= min(p.counters->n_rare_dom, p.rare_dom_cap)) return;
+    }
     if constexpr (DOM) {
         for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += blockDim.x) bloom[i] = db.tld_bloom[i];
         for (uint32_t i = threadIdx.x; i < (1u << TLD_TAB_BITS); i += blockDim.x) tldtab[i] = db.tld_tab[i];
@@ -983,7 +988,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     // reference's from_utf8 precondition is implied by the per-symbol checks.
     __shared__ RareAnchor wb_heavy[4][64];
     BufferedWriter<RareAnchor> hw(wb_heavy[threadIdx.x >> 6]);
-    const uint32_t nt = MISC ? min(p.counters->n_tok, p.tok_cap) : 0u;
+    const uint32_t nt = TOK ? min(p.counters->n_tok, p.tok_cap) : 0u;
     for (uint32_t base = blockIdx.x * blockDim.x; base < nt; base += stride) {
         const uint32_t i = base + threadIdx.x;
         RareAnchor ra{0, 0xFF};
@@ -1177,9 +1182,11 @@ void launch_validate_dom(const TokParams& p, const DevDb& db, int grid, hipStrea
 // k_validate (tokens, rare anchors, undecided domains: TokParams::vmode says which lists) has a fraction of the work and is
 // latency-bound: every workgroup stages the suffix tables first, so few workgroups (one per CU measured best for the whole job)
 void launch_validate_misc(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
-    if (p.vmode == 1u) hipLaunchKernelGGL(k_validate<1u>, dim3(grid), dim3(256), 0, stream, p, db);
+    if (p.vmode == 5u) hipLaunchKernelGGL(k_validate<5u>, dim3(grid), dim3(256), 0, stream, p, db);
+    else if (p.vmode == 4u) hipLaunchKernelGGL(k_validate<4u>, dim3(grid), dim3(256), 0, stream, p, db);
+    else if (p.vmode == 1u) hipLaunchKernelGGL(k_validate<1u>, dim3(grid), dim3(256), 0, stream, p, db);
     else if (p.vmode == 2u) hipLaunchKernelGGL(k_validate<2u>, dim3(grid), dim3(256), 0, stream, p, db);
-    else hipLaunchKernelGGL(k_validate<3u>, dim3(grid), dim3(256), 0, stream, p, db);
+    else hipLaunchKernelGGL(k_validate<7u>, dim3(grid), dim3(256), 0, stream, p, db);
     check_launch("launch_validate_misc");
 }
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
