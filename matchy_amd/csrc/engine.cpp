@@ -937,6 +937,22 @@ size_t sort_hits_temp_bytes(uint32_t n);
 hipError_t sort_hits(const FinalHit* fin, uint32_t n, unsigned long long* keys, uint32_t* vals, void* temp, size_t temp_bytes, FinalHit* out,
                      hipStream_t stream);
 
+// Wait for the stream: the scan behind it is about a millisecond, and the runtime's blocking wait takes tens of microseconds to
+// notice the end — poll the stream for the first milliseconds (a scan of a large batch), then block.
+static void wait_stream(hipStream_t stream) {
+    static const bool env_block = getenv("MATCHY_AMD_BLOCKING_WAIT") != nullptr;
+    if (!env_block) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t e = hipStreamQuery(stream);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) throw HipError{std::string("hipStreamQuery: ") + hipGetErrorString(e)};
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4)) break;
+        }
+    }
+    MXY_HIP(hipStreamSynchronize(stream));
+}
+
 void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMode hit_mode, bool sorted) {
     const bool trace = !single_ && getenv("MATCHY_AMD_TRACE");
     MXY_HIP(hipSetDevice(ddb_->device));   // regrown buffers must land on this scanner's device whatever thread calls
@@ -949,7 +965,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         // side chains that report to k_finish end behind the last event scan_device recorded: the interval ends behind k_finish then
         if (profile_ && expect_chains_) MXY_HIP(hipEventRecord(ev_[4], stream));
         expect_chains_ = 0;   // a rescan sets it again; the spill pass below runs on this stream
-        MXY_HIP(hipStreamSynchronize(stream));
+        wait_stream(stream);
         counters_clean_ = true;
         // slice 0 holds n_final / n_final_ids of all slices; statistics are summed
         ScanCounters& c = host_counters_;
@@ -1125,7 +1141,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         if (c.n_cand_a) MXY_HIP(hipMemcpyAsync(out.cands.data(), w0.cands_a.p, (size_t)c.n_cand_a * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
         if (c.n_cand) MXY_HIP(hipMemcpyAsync(out.cands.data() + c.n_cand_a, w0.cands.p, (size_t)c.n_cand * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
     }
-    MXY_HIP(hipStreamSynchronize(stream));
+    wait_stream(stream);
     if (trace) fprintf(stderr, "[matchy_amd] fetch: counters after %.3f ms, records after %.3f ms\n", t_counters, since());
     // drop the padding slots of partially filled chunks
     if (get_raw) {
