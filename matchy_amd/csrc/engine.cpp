@@ -893,7 +893,10 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
             {
                 LookupParams lpm = L.lp;
                 if (arrive) { lpm.arrive_chain = 3; lpm.arrive = counters_.p; ++chains; }
-                launch_lookup(lpm, view, n_cu_ * L.gm[2], dom_stream_);
+                static const int lp_wgs = getenv("MATCHY_AMD_LPGRID") ? atoi(getenv("MATCHY_AMD_LPGRID")) : 0;
+                // three workgroups per four CUs: every workgroup ends with a pair of returning atomics on the two record counters, and
+                // with 512 of them those queue up behind each other (64 / 128 / 192 / 256 / 512 workgroups: tail 0.236 / 0.218 / 0.217 / 0.218 / 0.227 ms)
+                launch_lookup(lpm, view, lp_wgs > 0 ? lp_wgs : std::max(1, n_cu_ * 3 / 4), dom_stream_);
             }
             if (arrive) expect_chains_ = chains;
             else {

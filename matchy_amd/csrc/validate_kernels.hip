@@ -1089,7 +1089,15 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         DomLong dl{};
         int dr = WALK_NO;
         uint32_t ds = 0, de = 0;
-        if (DOM && kind == RARE_DOM) dr = val_domain(lg, db, bloom, tldtab, p.min_labels, ra.pos, ds, de, &dl);
+        if (DOM && kind == RARE_DOM) {
+            // The walk is a chain of dependent 8-byte loads going left from the anchor, and the lanes of a wave take them one
+            // after the other (different lengths, different branches): ~100 load round trips per wave. Touch the two 128-byte
+            // lines in front of the anchor first — one round trip to HBM for both — and the chain runs out of the cache.
+            const uint32_t a0 = ra.pos & ~127u;
+            uint32_t t0 = lg.p[a0], t1 = a0 >= 128 ? lg.p[a0 - 128] : 0u;
+            asm volatile("" ::"v"(t0), "v"(t1));
+            dr = val_domain(lg, db, bloom, tldtab, p.min_labels, ra.pos, ds, de, &dl);
+        }
         for (uint64_t lm = __ballot(dr == WALK_LONG); lm; lm &= lm - 1) {
             const int src = __ffsll((long long)lm) - 1;
             WalkState st;
