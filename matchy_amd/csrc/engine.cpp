@@ -940,11 +940,12 @@ size_t sort_hits_temp_bytes(uint32_t n);
 hipError_t sort_hits(const FinalHit* fin, uint32_t n, unsigned long long* keys, uint32_t* vals, void* temp, size_t temp_bytes, FinalHit* out,
                      hipStream_t stream);
 
-// Wait for the stream: the scan behind it is about a millisecond, and the runtime's blocking wait takes tens of microseconds to
-// notice the end — poll the stream for the first milliseconds (a scan of a large batch), then block.
-static void wait_stream(hipStream_t stream) {
+// Wait for the stream. poll: the scan behind it is about a millisecond (device-resident input), and the runtime's blocking wait
+// takes ~10 us longer to notice the end — poll the stream for the first milliseconds, then block. Host-buffer scans wait for tens
+// of milliseconds of copies with other threads busy in the runtime (the command line's reader and second scanner): they block.
+static void wait_stream(hipStream_t stream, bool poll) {
     static const bool env_block = getenv("MATCHY_AMD_BLOCKING_WAIT") != nullptr;
-    if (!env_block) {
+    if (poll && !env_block) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
             const hipError_t e = hipStreamQuery(stream);
@@ -968,7 +969,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         // side chains that report to k_finish end behind the last event scan_device recorded: the interval ends behind k_finish then
         if (profile_ && expect_chains_) MXY_HIP(hipEventRecord(ev_[4], stream));
         expect_chains_ = 0;   // a rescan sets it again; the spill pass below runs on this stream
-        wait_stream(stream);
+        wait_stream(stream, last_fork_);
         counters_clean_ = true;
         // slice 0 holds n_final / n_final_ids of all slices; statistics are summed
         ScanCounters& c = host_counters_;
@@ -1144,7 +1145,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         if (c.n_cand_a) MXY_HIP(hipMemcpyAsync(out.cands.data(), w0.cands_a.p, (size_t)c.n_cand_a * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
         if (c.n_cand) MXY_HIP(hipMemcpyAsync(out.cands.data() + c.n_cand_a, w0.cands.p, (size_t)c.n_cand * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
     }
-    wait_stream(stream);
+    wait_stream(stream, last_fork_);
     if (trace) fprintf(stderr, "[matchy_amd] fetch: counters after %.3f ms, records after %.3f ms\n", t_counters, since());
     // drop the padding slots of partially filled chunks
     if (get_raw) {
