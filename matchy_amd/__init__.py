@@ -401,7 +401,14 @@ class ScanResult:
         self.bytes = raw.bytes
         self.n_ip4_hits = raw.n_ip4_hits   # fetch_mode 1 | 8: IPv4 results as compact records (not in _raw.hits)
         self.n_hits = raw.n_hits + raw.n_ip4_hits
-        self.on_device = bool(lib().matchy_scan_result_on_device(C.byref(raw)))   # fetch_mode 4: device pointers
+        self._on_device = None
+
+    @property
+    def on_device(self):
+        """fetch_mode 4: the arrays of the result are device pointers"""
+        if self._on_device is None:
+            self._on_device = bool(lib().matchy_scan_result_on_device(C.byref(self._raw))) if self._raw is not None else False
+        return self._on_device
 
     def hits(self):
         """list of dict(start,end,type,kind,prefix_len,ip_data_offset,ids,offs) in canonical order."""

@@ -843,7 +843,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         if (rare_own) {
             TokParams tt = t1;
             tt.vmode = 4u;
-            launch_validate_misc(tt, view, std::max(1, n_cu_ / 8), aux2_stream_);
+            launch_validate_misc(tt, view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);   // 6 KB of LDS, workgroups beyond the list leave at once
             if (!ev_v1_) MXY_HIP(hipEventCreateWithFlags(&ev_v1_, hipEventDisableTiming));
             MXY_HIP(hipEventRecord(ev_v1_, aux2_stream_));
             t1.vmode = 1u;
@@ -894,9 +894,10 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
                 LookupParams lpm = L.lp;
                 if (arrive) { lpm.arrive_chain = 3; lpm.arrive = counters_.p; ++chains; }
                 static const int lp_wgs = getenv("MATCHY_AMD_LPGRID") ? atoi(getenv("MATCHY_AMD_LPGRID")) : 0;
-                // three workgroups per four CUs: every workgroup ends with a pair of returning atomics on the two record counters, and
-                // with 512 of them those queue up behind each other (64 / 128 / 192 / 256 / 512 workgroups: tail 0.236 / 0.218 / 0.217 / 0.218 / 0.227 ms)
-                launch_lookup(lpm, view, lp_wgs > 0 ? lp_wgs : std::max(1, n_cu_ * 3 / 4), dom_stream_);
+                // one workgroup per CU: every workgroup ends with a pair of returning atomics on the two record counters, and with 512
+                // of them those queue up behind each other (64 / 128 / 192 / 256 / 512 workgroups: tail 0.236 / 0.218 / 0.217 / 0.218 / 0.227 ms;
+                // not fewer than one per CU: a database that most names hit makes this the kernel with the work)
+                launch_lookup(lpm, view, lp_wgs > 0 ? lp_wgs : n_cu_, dom_stream_);
             }
             if (arrive) expect_chains_ = chains;
             else {

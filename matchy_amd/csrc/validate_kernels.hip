@@ -969,9 +969,12 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     __shared__ uint32_t bloom[DOM ? TLD_BLOOM_WORDS : 1];
     __shared__ uint2 tldtab[DOM ? (1u << TLD_TAB_BITS) : 1];
     __shared__ __attribute__((aligned(16))) uint8_t winbuf[MISC ? 256 * 80 : 16];   // one 80-byte IPv6 window per lane
-    if constexpr (DOM && !MISC) {
+    if constexpr (DOM && !MISC && !TOK) {
         // the undecided domains are a few thousand per batch: workgroups beyond the list leave before they stage 20 KB of tables
         if (blockIdx.x * blockDim.x >= min(p.counters->n_rare_dom, p.rare_dom_cap)) return;
+    }
+    if constexpr (TOK && !MISC && !DOM) {
+        if (blockIdx.x * blockDim.x >= min(p.counters->n_tok, p.tok_cap)) return;
     }
     if constexpr (DOM) {
         for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += blockDim.x) bloom[i] = db.tld_bloom[i];
