@@ -82,7 +82,11 @@ PslHost* load_psl() {
     while (cap < h->suffixes.size() * 3) cap <<= 1;
     h->mask = (uint32_t)(cap - 1);
     h->slots.assign(cap, PslSlot{0, 0, 0});
-    h->bloom.assign(TLD_BLOOM_WORDS, 0);
+    // two filters in one array: [0, TLD_BLOOM_WORDS) over the last labels of all suffixes, byte-wise hash (the general walk of
+    // k_validate); behind it TLD_BLOOM_WORDS / 2 words for k_anchor's prefilter — labels that fit its 8-byte window, TWO bits per label
+    // from the two-multiply hash (bits 0..13 and 14..27). (Until round 3 the prefilter folded the first filter, which also held its
+    // bits, to half its size: a quarter of all short labels passed, "html" among them.)
+    h->bloom.assign(TLD_BLOOM_WORDS + TLD_BLOOM_WORDS / 2, 0);
     for (const std::string& s : h->suffixes) {
         if (s.empty()) continue;
         uint64_t rh = psl_hash_init();
@@ -102,8 +106,10 @@ PslHost* load_psl() {
             memcpy(k8, last, ll);
             uint32_t lo8, hi8;
             memcpy(&lo8, k8, 4); memcpy(&hi8, k8 + 4, 4);
-            const uint32_t b8 = tld_hash8(lo8, hi8) & (TLD_BLOOM_BITS - 1);
-            h->bloom[b8 >> 5] |= 1u << (b8 & 31);
+            const uint32_t h8 = tld_hash8(lo8, hi8);
+            const uint32_t ba = h8 & (TLD_BLOOM_BITS / 2 - 1), bb = (h8 >> 14) & (TLD_BLOOM_BITS / 2 - 1);
+            h->bloom[TLD_BLOOM_WORDS + (ba >> 5)] |= 1u << (ba & 31);
+            h->bloom[TLD_BLOOM_WORDS + (bb >> 5)] |= 1u << (bb & 31);
         }
         h->max_tld_len = std::max<uint32_t>(h->max_tld_len, (uint32_t)ll);
         h->max_suffix_len = std::max<uint32_t>(h->max_suffix_len, (uint32_t)s.size());

@@ -74,7 +74,8 @@ __device__ __forceinline__ uint32_t anchor_pos(uint32_t e) {
 constexpr uint32_t CAND_STAGE = 16, RARE_STAGE = 8;
 typedef StagedChunkWriter<Candidate, CAND_STAGE> CandWriter;
 typedef BufferedWriter<uint2, RARE_STAGE> RareWriter;
-constexpr uint32_t BLOOM_FOLD_WORDS = TLD_BLOOM_WORDS / 2;   // the last-label Bloom filter folded to half its size (bit b | bit b + 16384)
+static_assert(TLD_BLOOM_BITS / 2 == 1u << 14, "the prefilter takes bits 0..13 and 14..27 of the label hash");
+constexpr uint32_t BLOOM_FOLD_WORDS = TLD_BLOOM_WORDS / 2;   // words of the prefilter's own Bloom filter (behind the general one in DevDb::tld_bloom)
 
 struct WaveCtx {
     const TokParams* p;
@@ -382,10 +383,11 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
                 const uint32_t ll = (uint32_t)(__ffsll((long long)ndc) - 1) >> 3;
                 const uint64_t below = (1ull << (8 * ll)) - 1ull;
                 const uint32_t stop = (uint32_t)(w64 >> (8 * ll)) & 0xFF;
-                const uint32_t bit = tld_hash8((uint32_t)(w64 & below), (uint32_t)((w64 & below) >> 32)) & (TLD_BLOOM_BITS / 2 - 1);
+                const uint32_t h8 = tld_hash8((uint32_t)(w64 & below), (uint32_t)((w64 & below) >> 32));
+                const uint32_t bit = h8 & (TLD_BLOOM_BITS / 2 - 1), bit2 = (h8 >> 14) & (TLD_BLOOM_BITS / 2 - 1);
                 // a '.' inside the label: a later dot owns the run; the run must end at a boundary; the label must be
-                // some public suffix's last label
-                keep = (mw.dot & below) == 0 && d_is_boundary(stop) && ((cx.bloom[bit >> 5] >> (bit & 31)) & 1);
+                // some public suffix's last label (two bits of the prefilter's Bloom filter)
+                keep = (mw.dot & below) == 0 && d_is_boundary(stop) && ((cx.bloom[bit >> 5] >> (bit & 31)) & (cx.bloom[bit2 >> 5] >> (bit2 & 31)) & 1);
             } else if (mw.dot) {
                 keep = false;         // 8 domain chars with a dot among them: a later dot owns the run
             } else if (j + 24 <= cx.res_hi) {
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     __shared__ Candidate wb_cand[AW][CAND_STAGE];
 
     ctab[threadIdx.x] = (uint8_t)class_of(threadIdx.x);
-    for (uint32_t i = threadIdx.x; i < BLOOM_FOLD_WORDS; i += AW * 64) bloom[i] = db.tld_bloom[i] | db.tld_bloom[i + BLOOM_FOLD_WORDS];
+    for (uint32_t i = threadIdx.x; i < BLOOM_FOLD_WORDS; i += AW * 64) bloom[i] = db.tld_bloom[TLD_BLOOM_WORDS + i];   // the prefilter's own filter
     __syncthreads();
 
     // readfirstlane: tells the compiler that the wave index — and with it the segment loop, the block position and the ring

@@ -108,7 +108,7 @@ struct DevDb {
     const PslSlot* psl_slots;
     uint32_t psl_mask;
     const uint8_t* psl_pool;
-    const uint32_t* tld_bloom;    // TLD_BLOOM_WORDS words: bloom over the LAST labels of all suffixes
+    const uint32_t* tld_bloom;    // TLD_BLOOM_WORDS words: bloom over the LAST labels of all suffixes; behind them TLD_BLOOM_WORDS / 2 words: k_anchor's prefilter
     uint32_t max_tld_len;
     uint32_t max_suffix_len;      // longest suffix in bytes: a hash walk that has gone further cannot find one any more
     // exact open-addressing table (1 << TLD_TAB_BITS slots) of the last labels of <= 7 bytes: x = bytes 0..3, y = bytes
