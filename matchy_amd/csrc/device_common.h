@@ -106,12 +106,18 @@ struct BufferedWriter {
     uint32_t total = 0;  // entries appended by this wave
     __device__ __forceinline__ explicit BufferedWriter(T* lds) : buf(lds) {}
     __device__ __forceinline__ void flush(T* out, uint32_t cap, uint32_t* counter) {
+        flush_then(out, cap, counter, [](uint32_t, uint32_t) {});
+    }
+    // `after(b, n)` is called by the whole wave once the n staged entries have been written to out[b, b + n) (they are still in buf)
+    template <class F>
+    __device__ __forceinline__ void flush_then(T* out, uint32_t cap, uint32_t* counter, F&& after) {
         if (cnt == 0) return;
         uint32_t b = 0;
         if (lane_id() == 0) b = atomicAdd(counter, cnt);
         b = __builtin_amdgcn_readfirstlane(b);
         __builtin_amdgcn_wave_barrier();
         if (lane_id() < cnt && b + lane_id() < cap) out[b + lane_id()] = buf[lane_id()];
+        after(b, cnt);
         __builtin_amdgcn_wave_barrier();
         cnt = 0;
     }
@@ -131,6 +137,19 @@ struct BufferedWriter {
             return;
         }
         if (cnt + n > CAP) flush(out, cap, counter);
+        if (emit) buf[cnt + rank] = v;
+        cnt += n;
+        total += n;
+    }
+    // append for a full-width stage (CAP = 64) whose flushes call `after` (flush_then)
+    template <class F>
+    __device__ __forceinline__ void append_then(bool emit, const T& v, T* out, uint32_t cap, uint32_t* counter, F&& after) {
+        static_assert(CAP >= 64, "append_then: the stage holds a whole wave's entries");
+        const uint64_t m = __ballot(emit);
+        if (m == 0) return;
+        const uint32_t n = (uint32_t)__popcll(m);
+        const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
+        if (cnt + n > CAP) flush_then(out, cap, counter, after);
         if (emit) buf[cnt + rank] = v;
         cnt += n;
         total += n;

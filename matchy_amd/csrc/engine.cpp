@@ -606,6 +606,11 @@ void Scanner::slice_params(int sl, const uint8_t* dptr, uint32_t len, uint32_t l
         if (ddb_->view.has_glob) {
             if (w.glob_work.n < w.cands.n / 8) w.glob_work.alloc(w.cands.n / 8);
             lp.glob_work = w.glob_work.p; lp.glob_work_cap = (uint32_t)w.glob_work.n;
+            if (early_glob_ && sl == 0 && ac_ok) {
+                if (w.glob_work_d.n < w.cands.n / 8) w.glob_work_d.alloc(w.cands.n / 8);
+                tp.glob_work_d = w.glob_work_d.p; tp.glob_work_d_cap = (uint32_t)w.glob_work_d.n;
+                lp.early_glob = 1u;
+            }
             setup_spill(sl, lp);
         }
         lp.counters = ctr;
@@ -747,7 +752,11 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         mirror_used_ = true;
     }
     if (compact_ && c4_.n < final_.n) c4_.alloc(final_.n);
+    // databases with globs, one slice, forked: k_validate_dom queues the candidates it flags for the glob pass itself (MATCHY_AMD_NO_EARLY_GLOB=1: off)
+    static const bool env_no_early = getenv("MATCHY_AMD_NO_EARLY_GLOB") != nullptr;
+    early_glob_ = !no_fork && ns == 1 && lookup && ddb_->view.has_glob && !env_no_early;
     for (int k = 0; k < ns; ++k) slice_params(k, dptr, len, cuts[k], cuts[k + 1], lookup, host_mirror, launch_[k]);
+    early_glob_ = early_glob_ && launch_[0].lp.early_glob != 0;
     // the counter blocks are zero already when the last scan ended with fetch() (k_finish copies them out and clears them)
     if (!counters_clean_) MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters) * MAX_SLICES, stream));
     counters_clean_ = false;
@@ -915,6 +924,24 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
             launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
             launch_lookup(L.ld, view, std::max(1, n_cu_ / 8), stream);
         } else {
+            if (early_glob_) {
+                // Databases with globs keep one candidate list, but the candidates k_validate_dom flags for the glob pass — most of that
+                // pass's work — are on a work list of their own already (TokParams::glob_work_d): the glob pass over them starts here, on the
+                // fourth stream, beside k_validate<2> and the lean pass over everything else (which skips them and defers what IT finds to
+                // the usual work list for a second, small glob pass behind it).
+                if (!dom_stream_) {
+                    MXY_HIP(hipStreamCreateWithFlags(&dom_stream_, hipStreamNonBlocking));
+                    MXY_HIP(hipEventCreateWithFlags(&ev_join3_, hipEventDisableTiming));
+                    MXY_HIP(hipEventCreateWithFlags(&ev_dom_, hipEventDisableTiming));
+                }
+                MXY_HIP(hipEventRecord(ev_dom_, stream));
+                MXY_HIP(hipStreamWaitEvent(dom_stream_, ev_dom_, 0));
+                LookupParams lg = L.lp;
+                lg.glob_work = work_[0].glob_work_d.p; lg.glob_work_cap = (uint32_t)work_[0].glob_work_d.n;
+                lg.n_work = &counters_.p->n_glob_work_d;
+                launch_lookup_early_glob(lg, view, n_cu_ * L.gm[2], dom_stream_);
+                MXY_HIP(hipEventRecord(ev_join3_, dom_stream_));
+            }
             launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
             // no timing events inside the forked tail: every packet between two kernels of the chain is ~6-8 us of it, and with
             // kernels running side by side the intervals would not be kernel times anyway (ScanTiming: validate_ms = the whole tail)
@@ -932,6 +959,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         if (no_fork || !L.split_misc) launch_lookup(L.lp, view, n_cu_ * L.gm[2], stream);   // split lists: launched on the fourth stream above
         if (L.ip_pass && !no_fork) MXY_HIP(hipStreamWaitEvent(stream, ev_join_, 0));
         if (L.split_misc && !no_fork && !expect_chains_) MXY_HIP(hipStreamWaitEvent(stream, ev_join3_, 0));
+        if (early_glob_ && !no_fork) MXY_HIP(hipStreamWaitEvent(stream, ev_join3_, 0));
     }
     if (profile_) MXY_HIP(hipEventRecord(ev_[4], stream));
 }
@@ -990,7 +1018,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
             const ScanCounters& s = host_slices_[k];
             const Work& w = work_[k];
             over = over || s.n_cand > w.cands.n || s.n_cand_a > w.cands_a.n || s.n_cand_m > w.cands_m.n || s.n_cand_r > w.cands_r.n || s.n_cand_d > w.cands_d.n || s.n_rare > w.rare.n || s.n_rare_dom > w.rare_dom.n || s.n_tok > w.tok.n ||
-                   s.n_heavy > w.heavy.n || (w.glob_work.n && s.n_glob_work > w.glob_work.n) || s.n_hits > w.hits.n || s.n_ids > w.ids.n ||
+                   s.n_heavy > w.heavy.n || (w.glob_work.n && s.n_glob_work > w.glob_work.n) || (early_glob_ && s.n_glob_work_d > w.glob_work_d.n) || s.n_hits > w.hits.n || s.n_ids > w.ids.n ||
                    s.n_dom > w.dom_slots || (w.spill.n && s.n_spill > w.spill.n);
         }
         if (!over) {
@@ -1035,6 +1063,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
             if (s.n_tok > w.tok.n) w.tok.alloc(grown(s.n_tok));
             if (s.n_heavy > w.heavy.n) w.heavy.alloc(grown(s.n_heavy));
             if (w.glob_work.n && s.n_glob_work > w.glob_work.n) w.glob_work.alloc(grown(s.n_glob_work));
+            if (early_glob_ && s.n_glob_work_d > w.glob_work_d.n) w.glob_work_d.alloc(grown(s.n_glob_work_d));
             if (w.spill.n && s.n_spill > w.spill.n) w.spill.alloc(grown(s.n_spill));
             if (s.n_dom > w.dom_slots) {
                 w.dom_slots = (((size_t)s.n_dom + s.n_dom / 4 + ANCHOR_CHUNK) / ANCHOR_CHUNK) * ANCHOR_CHUNK;

@@ -20,6 +20,7 @@ void launch_validate_dom(const TokParams& p, const DevDb& db, int grid, hipStrea
 void launch_validate_misc(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_rare(const TokParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_lookup(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream);
+void launch_lookup_early_glob(const LookupParams& p, const DevDb& db, int grid, hipStream_t stream);
 void launch_lookup_ip(const LookupParams& p, const DevDb& db, int grid, bool dense, hipStream_t stream);
 // k_lookup_spill over p.spill (launched by Scanner::fetch when a scan has spilled candidates); threads = spill_threads() per block
 void launch_lookup_spill(const LookupParams& p, const DevDb& db, hipStream_t stream);
@@ -171,6 +172,7 @@ private:
         size_t dom_slots = 0;
         DevBuf<Hit> hits;                   // single-query path and the spill pass only
         DevBuf<uint32_t> ids, glob_work;
+        DevBuf<uint32_t> glob_work_d;       // work list k_validate_dom fills itself (forked scans of glob databases)
         DevBuf<uint32_t> spill;             // glob candidates beyond the per-lane storage of the glob pass (k_lookup_spill)
         void ensure(uint32_t len);
     };
@@ -193,6 +195,7 @@ private:
     int plan_slices(uint32_t len, int want, uint32_t (&cuts)[MAX_SLICES + 1]);
     void setup_spill(int sl, LookupParams& lp);
     bool spill_done_ = false;
+    bool early_glob_ = false;       // last scan_device: the glob pass over k_validate_dom's flagged candidates runs beside the lean pass
     uint32_t expect_chains_ = 0;    // side-stream chains of the last scan_device that report their end to k_finish (0: event joins)
     bool counters_clean_ = false;   // the device counter blocks are zero (k_finish of the last fetch left them so)
     int last_slices_ = 0;

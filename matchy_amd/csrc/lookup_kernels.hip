@@ -691,8 +691,14 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
     __shared__ uint32_t outq[GLOB ? 256 * GLOB_OUTQ : 1];
     const DfaView dv = dfa_stage<ROWS>(db, cls, rows);
     __syncthreads();
-    const uint32_t n = p.from_work ? min(p.counters->n_glob_work, p.glob_work_cap) : min(p.n_in ? *p.n_in : p.counters->n_cand, p.cand_cap);
+    const uint32_t n = p.from_work ? min(p.n_work ? *p.n_work : p.counters->n_glob_work, p.glob_work_cap) : min(p.n_in ? *p.n_in : p.counters->n_cand, p.cand_cap);
     uint32_t stride = gridDim.x * blockDim.x;
+    // Lean pass, string candidates that come without a verdict (k_validate_dom flags its own: what is left are the long tokens, e-mail
+    // addresses and undecided domains of a batch — some ten thousand in a log scan): the automaton walk that decides whether a candidate
+    // needs the glob pass is a chain of dependent row loads as long as the text — a 64-byte hash: 64 round trips — and the glob pass walks
+    // the text again anyway. While there are few of them they go to the glob pass unwalked; when the anchor lists they come from are long
+    // (hash-dense input) the walk here, in the cheaper kernel, thins them out first.
+    const bool defer_unwalked = !GLOB && p.ac_filter && p.counters->n_tok + p.counters->n_rare + p.counters->n_rare_dom <= 262144u;
     ChunkWriter<Hit, HIT_CHUNK> cw;
     __shared__ uint32_t wb_work[4][64];
     BufferedWriter<uint32_t> ww(wb_work[threadIdx.x >> 6]);   // glob work list: sparse, dense output
@@ -728,7 +734,9 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
                 if (db.has_ip && d_parse_ipv6(text, tl, seg) && trie_v6(db, seg, off, pfx)) { h.kind = 2; h.a = off; h.prefix_len = (uint8_t)pfx; emit = true; }
             } else {
                 // producers that know already (k_validate_dom's suffix filter) say so in the candidate: no automaton walk then
-                if (!GLOB && p.ac_filter && (c.pad == CAND_GLOB || (c.pad != CAND_NO_GLOB && ac_touches_output(db, dv, text, tl)))) defer = true;
+                if (!GLOB && p.ac_filter && p.early_glob && c.pad == CAND_GLOB) {
+                    // queued for the glob pass by its producer (TokParams::glob_work_d): that pass runs beside this one
+                } else if (!GLOB && p.ac_filter && (c.pad == CAND_GLOB || (c.pad != CAND_NO_GLOB && (defer_unwalked || ac_touches_output(db, dv, text, tl))))) defer = true;
                 else {
                     uint32_t pid = 0xFFFFFFFFu;
                     if (db.has_literal) { uint32_t q; if (lit_lookup(db, text, tl, q)) pid = q; }
@@ -884,6 +892,14 @@ void launch_lookup(const LookupParams& p_in, const DevDb& db, int grid, hipStrea
     // candidates beyond the glob pass's per-lane storage are listed in p.spill: Scanner::fetch launches k_lookup_spill when the
     // counters show that there are any (normally none)
     check_launch("launch_lookup");
+}
+// The glob pass over the work list k_validate_dom filled itself (LookupParams::glob_work / n_work point at it): launched when that
+// kernel ends, beside the lean pass over the other candidates (launch_lookup with early_glob = 1)
+void launch_lookup_early_glob(const LookupParams& p_in, const DevDb& db, int grid, hipStream_t stream) {
+    LookupParams p = p_in;
+    p.ac_filter = 0; p.from_work = 1;
+    hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(256), 0, stream, p, db);
+    check_launch("launch_lookup_early_glob");
 }
 // see launch_finish (scan_types.h)
 __global__ __launch_bounds__(256) void k_finish(ScanCounters* dev, ScanCounters* host, uint32_t n_words, uint32_t expect_chains) {

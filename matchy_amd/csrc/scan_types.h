@@ -165,6 +165,7 @@ struct ScanCounters {
     alignas(128) uint32_t chains_done;
     uint32_t arrive_wgs[3];
     alignas(128) uint32_t n_glob_work;   // candidates whose text reaches an output state of the AC automaton (glob work list)
+    uint32_t n_glob_work_d;          // ... queued by k_validate_dom itself (TokParams::glob_work_d): the glob pass over these starts when that kernel ends
     uint32_t n_spill;                // candidates handed to k_lookup_spill (more glob results / deeper star nesting than a lane of the glob pass holds)
 };
 
@@ -241,6 +242,10 @@ struct TokParams {
     uint32_t rare_cap;
     RareAnchor* rare_dom;     // undecided domain anchors (written by k_validate_dom)
     uint32_t rare_dom_cap;
+    // databases with globs, forked scans: k_validate_dom queues the candidates it flags CAND_GLOB on a work list of its own (indices into
+    // `cands`, counter ScanCounters::n_glob_work_d), and the glob pass over them runs beside the lean pass over the rest. nullptr: off
+    uint32_t* glob_work_d;
+    uint32_t glob_work_d_cap;
     uint32_t vmode;           // k_validate: bit 0 = the rare list (IPv6 / e-mail anchors), bit 1 = the rare_dom list, bit 2 = the long tokens
     RareAnchor* tok;          // long-token anchors
     uint32_t tok_cap;
@@ -286,6 +291,8 @@ struct LookupParams {
     uint32_t* glob_work;
     uint32_t glob_work_cap;
     uint32_t ac_filter, from_work;
+    const uint32_t* n_work;   // from_work: entries of glob_work (device memory); null = counters->n_glob_work
+    uint32_t early_glob;      // lean pass: candidates flagged CAND_GLOB were queued by their producer (TokParams::glob_work_d) — skip them
     // glob candidates that exceed the per-lane storage of the glob pass: candidate indices, and per-thread scratch of the
     // spill pass (spill_words words per thread: one bit per pattern id, then the star stack)
     uint32_t* spill;

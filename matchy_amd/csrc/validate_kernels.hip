@@ -821,6 +821,21 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
     uint32_t pend_sw[SFX ? 4 : 1] = {0}, pend_sb[SFX ? 4 : 1] = {0};   // suffix filter: bitmap words in flight and their bits
     bool pend = false, pend_over = false;
     uint32_t* sb = strbuf[threadIdx.x];
+    // TokParams::glob_work_d: the candidates this kernel flags CAND_GLOB go onto a work list of their own as their stage is flushed (their
+    // indices in `cands` are known then), so that the glob pass over them can start when this kernel ends — beside the lean lookup pass over the
+    // rest, which skips them (LookupParams::early_glob)
+    auto queue_glob = [&](uint32_t b, uint32_t n) {
+        if (!p.glob_work_d) return;
+        const uint32_t lane = lane_id();
+        const bool g = lane < n && b + lane < p.cand_cap && cw.buf[lane].pad == CAND_GLOB;
+        const uint64_t m = __ballot(g);
+        if (!m) return;
+        uint32_t wb = 0;
+        if (lane == 0) wb = atomicAdd(&p.counters->n_glob_work_d, (uint32_t)__popcll(m));
+        wb = __builtin_amdgcn_readfirstlane(wb);
+        const uint32_t slot = wb + mbcnt64(m);
+        if (g && slot < p.glob_work_d_cap) p.glob_work_d[slot] = b + lane;
+    };
     // the candidate of the previous iteration: listed if a literal key or (databases with globs) a glob can match it
     auto emit_pending = [&]() {
         if (!p.filter_lit) { cw_dense.append(pend, Candidate{pend_start, pend_lt, 0u, 0u}, p.cands, p.cand_cap, p.n_cand, SC); return; }
@@ -835,7 +850,8 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
         }
         // the automaton was walked over the whole name right here: k_lookup need not walk it again to route the candidate
         if constexpr (AC) flag = pend_over ? CAND_GLOB : CAND_NO_GLOB;
-        cw.append(pend && lit, Candidate{pend_start, pend_lt, 0u, flag}, p.cands, p.cand_cap, p.n_cand);
+        if constexpr (AC || SFX) cw.append_then(pend && lit, Candidate{pend_start, pend_lt, 0u, flag}, p.cands, p.cand_cap, p.n_cand, queue_glob);
+        else cw.append(pend && lit, Candidate{pend_start, pend_lt, 0u, flag}, p.cands, p.cand_cap, p.n_cand);
     };
     for (uint32_t base = blockIdx.x * blockDim.x; base < nd; base += stride) {
         const uint32_t i = base + threadIdx.x;
@@ -947,7 +963,8 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
         cur = nxt;
     }
     emit_pending();
-    cw.flush(p.cands, p.cand_cap, p.n_cand);
+    if constexpr (AC || SFX) cw.flush_then(p.cands, p.cand_cap, p.n_cand, queue_glob);
+    else cw.flush(p.cands, p.cand_cap, p.n_cand);
     cw_dense.pad_rest(p.cands, p.cand_cap, SC);
     sw.flush(p.rare_dom, p.rare_dom_cap, &p.counters->n_rare_dom);
     // validated domain candidates, listed or not
