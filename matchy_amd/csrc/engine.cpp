@@ -659,6 +659,14 @@ void Scanner::slice_params(int sl, const uint8_t* dptr, uint32_t len, uint32_t l
     L.lm = lp;
     L.lr = lp;
     L.ld = lp;
+    if (lp.early_glob) {
+        // forked scan of a glob database: the undecided domains get a list and ONE glob pass over all of it (no work list: a few thousand
+        // candidates) on a stream of their own; what spills there is listed with bit 31 set and read from cands_alt by the spill pass
+        lp.cands_alt = w.cands_d.p; lp.cand_alt_cap = (uint32_t)w.cands_d.n;
+        L.ld = lp;
+        L.ld.cands = w.cands_d.p; L.ld.cand_cap = (uint32_t)w.cands_d.n; L.ld.n_in = &ctr->n_cand_d;
+        L.ld.glob_work = nullptr; L.ld.glob_work_cap = 0; L.ld.early_glob = 0; L.ld.spill_tag = 1u;
+    }
     if (L.split_misc) {
         L.ld.cands = w.cands_d.p; L.ld.cand_cap = (uint32_t)w.cands_d.n; L.ld.n_in = &ctr->n_cand_d;
         L.lm.cands = w.cands_m.p; L.lm.cand_cap = (uint32_t)w.cands_m.n; L.lm.n_in = &ctr->n_cand_m;
@@ -936,13 +944,33 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
                 }
                 MXY_HIP(hipEventRecord(ev_dom_, stream));
                 MXY_HIP(hipStreamWaitEvent(dom_stream_, ev_dom_, 0));
+                // Both side chains report their ends to k_finish (arrival counters, as in the scans without globs: an event join in front of
+                // k_finish costs ~10-20 us each).
+                static const bool env_join_g = getenv("MATCHY_AMD_EVENT_JOIN") != nullptr;
+                uint32_t chains = 0;
                 LookupParams lg = L.lp;
                 lg.glob_work = work_[0].glob_work_d.p; lg.glob_work_cap = (uint32_t)work_[0].glob_work_d.n;
                 lg.n_work = &counters_.p->n_glob_work_d;
+                if (!env_join_g) { lg.arrive_chain = 3; lg.arrive = counters_.p; ++chains; }
                 launch_lookup_early_glob(lg, view, n_cu_ * L.gm[2], dom_stream_);
-                MXY_HIP(hipEventRecord(ev_join3_, dom_stream_));
+                if (env_join_g) MXY_HIP(hipEventRecord(ev_join3_, dom_stream_));
+                glob_join3_ = env_join_g;
+                // ... and the undecided domains (k_validate<2>: general walk) with the glob pass over THEIR candidates leave the scan's
+                // stream for the second one, when the IPv4 lookups do not need it: the lean pass does not have to wait for them
+                static const bool env_no_aside = getenv("MATCHY_AMD_NO_V2_ASIDE") != nullptr;
+                glob_v2_aside_ = !L.ip_pass && !env_no_aside;
+                if (glob_v2_aside_) {
+                    MXY_HIP(hipStreamWaitEvent(aux_stream_, ev_dom_, 0));
+                    t2.cands = work_[0].cands_d.p; t2.cand_cap = (uint32_t)work_[0].cands_d.n; t2.n_cand = &counters_.p->n_cand_d;
+                    launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, aux_stream_);
+                    LookupParams ld = L.ld;
+                    if (!env_join_g) { ld.arrive_chain = 2; ld.arrive = counters_.p; ++chains; }
+                    launch_lookup(ld, view, std::max(2, n_cu_ / 8), aux_stream_);
+                    if (env_join_g) MXY_HIP(hipEventRecord(ev_join_, aux_stream_));
+                }
+                expect_chains_ = chains;
             }
-            launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
+            if (!(early_glob_ && glob_v2_aside_)) launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
             // no timing events inside the forked tail: every packet between two kernels of the chain is ~6-8 us of it, and with
             // kernels running side by side the intervals would not be kernel times anyway (ScanTiming: validate_ms = the whole tail)
             MXY_HIP(hipStreamWaitEvent(stream, ev_join2_, 0));
@@ -959,7 +987,10 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         if (no_fork || !L.split_misc) launch_lookup(L.lp, view, n_cu_ * L.gm[2], stream);   // split lists: launched on the fourth stream above
         if (L.ip_pass && !no_fork) MXY_HIP(hipStreamWaitEvent(stream, ev_join_, 0));
         if (L.split_misc && !no_fork && !expect_chains_) MXY_HIP(hipStreamWaitEvent(stream, ev_join3_, 0));
-        if (early_glob_ && !no_fork) MXY_HIP(hipStreamWaitEvent(stream, ev_join3_, 0));
+        if (early_glob_ && !no_fork && glob_join3_) {
+            MXY_HIP(hipStreamWaitEvent(stream, ev_join3_, 0));
+            if (glob_v2_aside_) MXY_HIP(hipStreamWaitEvent(stream, ev_join_, 0));
+        }
     }
     if (profile_) MXY_HIP(hipEventRecord(ev_[4], stream));
 }

@@ -195,6 +195,7 @@ private:
     int plan_slices(uint32_t len, int want, uint32_t (&cuts)[MAX_SLICES + 1]);
     void setup_spill(int sl, LookupParams& lp);
     bool spill_done_ = false;
+    bool glob_join3_ = false, glob_v2_aside_ = false;   // early glob pass joined by event (MATCHY_AMD_EVENT_JOIN); k_validate<2> and its lookups on the second stream
     bool early_glob_ = false;       // last scan_device: the glob pass over k_validate_dom's flagged candidates runs beside the lean pass
     uint32_t expect_chains_ = 0;    // side-stream chains of the last scan_device that report their end to k_finish (0: event joins)
     bool counters_clean_ = false;   // the device counter blocks are zero (k_finish of the last fetch left them so)

@@ -293,6 +293,11 @@ struct LookupParams {
     uint32_t ac_filter, from_work;
     const uint32_t* n_work;   // from_work: entries of glob_work (device memory); null = counters->n_glob_work
     uint32_t early_glob;      // lean pass: candidates flagged CAND_GLOB were queued by their producer (TokParams::glob_work_d) — skip them
+    // forked scans of glob databases: the undecided domains have a candidate list (and a glob pass) of their own; a candidate of that
+    // list that spills is listed with bit 31 set (spill_tag = 1), and the spill pass reads it from cands_alt
+    const Candidate* cands_alt;
+    uint32_t cand_alt_cap;
+    uint32_t spill_tag;
     // glob candidates that exceed the per-lane storage of the glob pass: candidate indices, and per-thread scratch of the
     // spill pass (spill_words words per thread: one bit per pattern id, then the star stack)
     uint32_t* spill;
