@@ -842,20 +842,27 @@ def test_glob_results_and_star_nesting_beyond_lane_storage(M, oracle):
     # a pattern with 40 '*' (deeper than the 24 frames a lane of the glob pass holds)
     deep = "*".join(name[k] for k in range(0, 41)) + "*com"
     b.add_entry(deep, {"deep": 1})
+    # a SHORT name that more than 32 globs match: k_validate_dom decides it from its context record and flags it for the glob pass itself
+    # (the long name above is an "undecided" anchor: the general walk, a candidate list and a glob pass of its own) — both roads spill
+    short = "a1.b2c3.example.com"
+    for i in range(48):
+        b.add_entry(short[: 1 + i % 9] + "*" + short[9 + i // 9:], {"s": i})
     b.add_entry("*.other-suffix.org", {"o": 1})
     b.add_entry("plain.example.net", {"lit": 1})
     blob = b.build()
     b.close()
-    log = (b"GET http://" + name.encode() + b"/x 1.2.3.4\n" + b"host=www.other-suffix.org plain.example.net\n") * 3 + b"ref=" + name.encode() + b"\n"
+    log = (b"GET http://" + name.encode() + b"/x 1.2.3.4\n" + b"host=www.other-suffix.org plain.example.net\n") * 3 + b"ref=" + name.encode() + b"\n" + b"short " + short.encode() + b" again " + short.encode() + b"\n"
     gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, log)
     assert gs == ws
     assert gh == wh
     assert gl == wl
     big = [h for h in wh if log[h["start"]:h["end"]] == name.encode()]
     assert len(big) == 4 and all(len(h["ids"]) > 60 for h in big)
+    small = [h for h in wh if log[h["start"]:h["end"]] == short.encode()]
+    assert len(small) == 2 and all(len(h["ids"]) > 32 for h in small)
     db = M.Database(blob)
     odb = oracle.Database(blob)
-    for q in (name, "www.other-suffix.org", "plain.example.net", "nothing.example.org"):
+    for q in (name, short, "www.other-suffix.org", "plain.example.net", "nothing.example.org"):
         want, got = odb.lookup(q), db.lookup(q)
         if want["kind"] == "pattern" and want["data"] and want["data"][0] is not None:
             assert got == {"found": True, "prefix_len": 0, "data": want["data"][0]}, q
