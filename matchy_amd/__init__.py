@@ -442,7 +442,8 @@ class ScanResult:
 
     def close(self):
         if self._raw is not None:
-            lib().matchy_scan_result_free(C.byref(self._raw))
+            if self._raw._internal:   # borrowed results (fetch_mode 0 / 1 / 9) own nothing: no call needed
+                lib().matchy_scan_result_free(C.byref(self._raw))
             self._raw = None
 
     def __del__(self):
