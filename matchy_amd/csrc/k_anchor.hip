@@ -39,6 +39,14 @@
 namespace mxy {
 
 constexpr int AW = 4;                       // waves per workgroup
+// Wave priorities (s_setprio). The four waves of a SIMD run the same program at different places, and at equal priority the oldest
+// ready wave issues: a wave in the middle of a dependent chain — ring entry -> window bytes -> class table in a drain, the six DPP
+// steps of the ring-position scan, the rotate chain of the long-token test — then loses issue slots to a wave that is in the 100-odd
+// independent instructions of the bit-matrix transpose and the class functions, and its chain (which nothing else can overlap)
+// stretches. So the transpose and the class functions run at priority 0, everything with cross-lane, LDS or memory latency in it at 1
+// and the drains at 2: the bulk fills the gaps the chains leave instead of delaying them. Same instructions, 0.768 -> 0.677 ms on the
+// headline batch (profiles/r04_k_anchor_priorities.txt).
+constexpr int PRIO_BULK = 0, PRIO_CHAIN = 1, PRIO_DRAIN = 2;
 constexpr uint32_t BLK_BYTES = AB_BLOCK;    // bytes per wave iteration (8 rows of 256)
 constexpr uint32_t QCAP = 128;              // ring entries per wave and type
 // Raw-byte window per wave (circular, block granular): four blocks, so that the anchor rings fill up before their oldest
@@ -298,6 +306,7 @@ __device__ __forceinline__ void drain_v4(uint32_t* ring, uint32_t& head, uint32_
                                          PendingV4& pd, CandWriter& cw, V4Lookup& vl) {
     const uint32_t lane = lane_id();
     const TokParams& p = *cx.p;
+    __builtin_amdgcn_s_setprio(PRIO_DRAIN);
     commit_v4<INL>(pd, cx, cw, vl);
     __builtin_amdgcn_wave_barrier();
     const bool have = lane < n;
@@ -315,7 +324,7 @@ __device__ __forceinline__ void drain_v4(uint32_t* ring, uint32_t& head, uint32_
         tail += (uint32_t)__popcll(rm);
     }
 #ifdef MXY_ANCHOR_DEBUG
-    if (p.debug & 1) return;
+    if (p.debug & 1) { __builtin_amdgcn_s_setprio(PRIO_CHAIN); return; }
 #endif
     const bool go = have && !later;
     // the 20 bytes around the dot come from the LDS window (positions >= len are staged as ' ', a boundary like the end of the
@@ -338,6 +347,7 @@ __device__ __forceinline__ void drain_v4(uint32_t* ring, uint32_t& head, uint32_
         pd.word = p.filter_v4 ? cx.bm24[a >> 13] : 0xFFFFFFFFu;
     }
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_setprio(PRIO_CHAIN);
 }
 
 // Prefilter up to 64 domain anchors (first byte of the last label), one per lane; survivors go to the domain list.
@@ -348,6 +358,7 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
                                           DomWriter& dw) {
     const uint32_t lane = lane_id();
     const TokParams& p = *cx.p;
+    __builtin_amdgcn_s_setprio(PRIO_DRAIN);
     __builtin_amdgcn_wave_barrier();
     uint32_t ent = 0;
     bool keep = false, have_ctx = false;
@@ -367,7 +378,7 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
         tail += (uint32_t)__popcll(rm);
     }
 #ifdef MXY_ANCHOR_DEBUG
-    if (p.debug & 2) return;
+    if (p.debug & 2) { __builtin_amdgcn_s_setprio(PRIO_CHAIN); return; }
 #endif
     if (have && !later) {
         keep = true;
@@ -390,7 +401,11 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
                 keep = (mw.dot & below) == 0 && d_is_boundary(stop) && ((cx.bloom[bit >> 5] >> (bit & 31)) & (cx.bloom[bit2 >> 5] >> (bit2 & 31)) & 1);
             } else if (mw.dot) {
                 keep = false;         // 8 domain chars with a dot among them: a later dot owns the run
+#ifdef MXY_NO_LONG_LABEL
+            } else if (false) {
+#else
             } else if (j + 24 <= cx.res_hi) {
+#endif
                 // a label of 8+ bytes: usually not the last one ("www.examplesite.com" at 'e'). Look 16 bytes further: a
                 // dot before the first non-domain byte settles it; otherwise it stays undecided (long last label)
                 uint32_t more[4];
@@ -412,6 +427,7 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
         for (int k = 0; k < 8; ++k) rec[(1 + k) * DOM_TILE] = ctx[k];
     }
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_setprio(PRIO_CHAIN);
 }
 
 // The shipped public-suffix list only has last labels that start with 'a'..'z' or a byte >= 0x80 (ClassPlanes::TL); any other
@@ -526,6 +542,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         }
     };
 
+    __builtin_amdgcn_s_setprio(PRIO_CHAIN);
     for (uint32_t seg = gw;; seg += nw) {
         const ColdTok ks = cold_tok();   // the segment geometry is needed once per segment: not held through the block loop
         if (seg >= ks->n_segs) break;
@@ -589,11 +606,13 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
             __builtin_amdgcn_wave_barrier();
             cx.res_hi = blk + BLK_BYTES;
             cx.res_lo = cx.res_hi - seg_start > RAW_BYTES ? cx.res_hi - RAW_BYTES : seg_start;
+            __builtin_amdgcn_s_setprio(PRIO_BULK);   // transpose + class functions: independent instructions, they fill gaps
 
             // ---- bit planes and byte classes of the lane's 32 positions: bit t <-> position blk + 256 (t & 7) + 4 lane + (t >> 3)
             bit_transpose8(w);
             const ClassPlanes cl = classify_planes(w, tl_wide);
             nl_count += __popc(cl.NL);
+            __builtin_amdgcn_s_setprio(PRIO_CHAIN);  // from here on cross-lane steps, LDS and memory: see PRIO_CHAIN
             const uint32_t pos_base = blk + lane_off;
             const uint32_t ent_base = blk | (lane << 5);   // ring entries: anchor_pos()
 
@@ -610,7 +629,16 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                 // drops "HTTP/1.1", "Mozilla/5.0", "Safari/537.36" style anchors). The drain checks the digits in between.
                 const uint32_t NV_D = plane_next_dword(cl.D, 0x80808080u), NV_T = plane_next_dword(cl.T, 0x80808080u);
                 const uint32_t lookahead = ahead<1>(cl.D, NV_D) & (ahead<2>(cl.T, NV_T) | ahead<3>(cl.T, NV_T) | ahead<4>(cl.T, NV_T));
+#ifdef MXY_V4_SECOND_DOT
+                // S: a dot that a digit and, 2..4 positions on, another dot follow. The first dot of a dotted quad is such a dot AND its
+                // second dot — 2..4 positions ahead — is one too (the third octet starts with a digit, the third dot follows within
+                // three more): drops three-part version strings ("curl/8.4.0", "requests/2.31.0") before they take a ring slot
+                const uint32_t S = cl.T & lookahead;
+                const uint32_t NV_S = plane_next_dword(S, 0x80808080u);
+                F4 = S & lookback & (ahead<2>(S, NV_S) | ahead<3>(S, NV_S) | ahead<4>(S, NV_S));
+#else
                 F4 = cl.T & lookback & lookahead;
+#endif
             }
             if (en_dom) {
                 // byte that can start a public suffix's last label at j, '.' at j-1 (what stands at j-2 is the validators' business)
