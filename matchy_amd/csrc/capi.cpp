@@ -253,10 +253,9 @@ void* matchy_amd_pinned_alloc(size_t bytes) {
 void matchy_amd_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
 int32_t matchy_amd_host_register(const void* ptr, size_t bytes) {
     if (!ptr || !bytes) return MATCHY_ERROR_INVALID_PARAM;
-    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return MATCHY_ERROR_IO; }
-    return MATCHY_SUCCESS;
+    return mxy::pins::add_caller(ptr, bytes) == 0 ? MATCHY_SUCCESS : MATCHY_ERROR_IO;
 }
-void matchy_amd_host_unregister(const void* ptr) { if (ptr) { (void)hipHostUnregister(const_cast<void*>(ptr)); (void)hipGetLastError(); } }
+void matchy_amd_host_unregister(const void* ptr) { if (ptr) mxy::pins::remove_caller(ptr); }
 int32_t matchy_amd_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;

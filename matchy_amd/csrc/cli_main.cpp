@@ -430,9 +430,14 @@ struct MatchPipeline {
                 cv_space.notify_one();
             }
             Done d;
-            matchy_scanner_t* sc = get_scanner();
-            if (sc) run_batch(sc, b, d, pin);
-            else { d.input = b.input; d.ok = false; }
+            {
+                // the reader pinned the batch's pages ahead of the scan (b.reg): unpinned on EVERY way out of the batch — a failed
+                // scan and a scanner that could not be created included — before release_mappings() unmaps the file
+                struct Unpin { Batch& b; ~Unpin() { if (b.reg) { matchy_amd_host_unregister(b.reg); b.reg = nullptr; } } } unpin{b};
+                matchy_scanner_t* sc = get_scanner();
+                if (sc) run_batch(sc, b, d, pin);
+                else { d.input = b.input; d.ok = false; }
+            }
             std::lock_guard<std::mutex> lk(mu);
             done.emplace(b.seq, std::move(d));
             cv_done.notify_all();
@@ -469,11 +474,11 @@ bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t
     int fd = path == "-" ? 0 : open(path.c_str(), O_RDONLY);
     if (fd < 0) { fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), strerror(errno)); return false; }
     struct stat sb;
-    // Regular files: batches are byte ranges cut at newlines (the cuts are found by reading a few KiB around each nominal end); the
-    // worker that takes a batch reads its range with pread into its own page-locked buffer, from which the DMA engine feeds the GPU
-    // at the bus rate. No mapping: no page tables to build per batch and to tear down per file (a mapped 54 GB input cost 0.3 s of
-    // munmap alone), and with several workers the kernel-side copies of the ranges run side by side (tools/ubench/h2d_rate2.cpp: 8
-    // readers 40-45 GB/s). MATCHY_AMD_MMAP=1 maps the file instead (batches are views of the mapping, pinned per batch).
+    // Regular files are MAPPED by default (further down: batches are views of the mapping, the reader thread pins each batch's pages
+    // ahead of its scan). MATCHY_AMD_PREAD=1 opts into the alternative below, built and measured in round 3 (29 GB/s with four workers
+    // against 42-46 mapped): batches are byte ranges cut at newlines (the cuts are found by reading a few KiB around each nominal
+    // end) and the worker that takes a batch reads its range with pread into its own page-locked buffer — no page tables to build per
+    // batch or to tear down per file, but a kernel-side copy at ~10 GB/s per thread in front of every transfer.
     if (!gz && fd != 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && getenv("MATCHY_AMD_PREAD") && !getenv("MATCHY_AMD_NO_MMAP")) {
         const size_t size = (size_t)sb.st_size;
         std::vector<uint8_t> probe(65536);

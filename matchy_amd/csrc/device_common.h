@@ -281,17 +281,31 @@ __device__ inline bool d_valid_utf8(const uint8_t* s, uint32_t n) {
 // Byte-class masks of 8 log bytes at once (SWAR; bit 7 of each byte of the result is the class bit, all other bits 0).
 // Every addend keeps each byte below 0x100, so no carry crosses a byte.
 struct ByteMasks { uint64_t dc, dot, dash, high; };
-__device__ __forceinline__ ByteMasks domain_masks(uint64_t x) {
-    constexpr uint64_t H = 0x8080808080808080ull, L7 = 0x7F7F7F7F7F7F7F7Full;
-    const uint64_t t = x & L7, l = t | 0x2020202020202020ull;
-    const uint64_t dig = (t + 0x5050505050505050ull) & ~(t + 0x4646464646464646ull);   // '0'..'9'
-    const uint64_t alp = (l + 0x1F1F1F1F1F1F1F1Full) & ~(l + 0x0505050505050505ull);   // 'a'..'z' after case folding
-    const uint64_t ndot = (t ^ 0x2E2E2E2E2E2E2E2Eull) + L7, ndash = (t ^ 0x2D2D2D2D2D2D2D2Dull) + L7;  // bit 7 set iff different
-    ByteMasks m;
+// The class arithmetic keeps every byte lane below 0x100, so no carry ever crosses a byte — nor the middle of a 64-bit word: the two
+// halves are computed on their own with 32-bit adds. (Written on uint64_t the compiler emits v_add_co / v_addc_co pairs, a carry chain
+// through VCC that costs twice as much on the vector pipe; it also fuses a 64-bit expression that merely spells the two halves back
+// into that form, hence the separate function.)
+struct ByteMasks32 { uint32_t dc, dot, dash, high; };
+__device__ __forceinline__ ByteMasks32 domain_masks32(uint32_t x) {
+    constexpr uint32_t H = 0x80808080u, L7 = 0x7F7F7F7Fu;
+    const uint32_t t = x & L7, l = t | 0x20202020u;
+    const uint32_t dig = (t + 0x50505050u) & ~(t + 0x46464646u);   // '0'..'9'
+    const uint32_t alp = (l + 0x1F1F1F1Fu) & ~(l + 0x05050505u);   // 'a'..'z' after case folding
+    const uint32_t ndot = (t ^ 0x2E2E2E2Eu) + L7, ndash = (t ^ 0x2D2D2D2Du) + L7;  // bit 7 set iff different
+    ByteMasks32 m;
     m.high = x & H;
     m.dot = ~ndot & ~x & H;
     m.dash = ~ndash & ~x & H;
     m.dc = (((dig | alp) & ~x) | m.dot | m.dash | m.high) & H;  // DOMAIN_CHAR_LOOKUP (ext:1597-1629)
+    return m;
+}
+__device__ __forceinline__ ByteMasks domain_masks(uint64_t x) {
+    const ByteMasks32 lo = domain_masks32((uint32_t)x), hi = domain_masks32((uint32_t)(x >> 32));
+    ByteMasks m;
+    m.dc = (uint64_t)lo.dc | ((uint64_t)hi.dc << 32);
+    m.dot = (uint64_t)lo.dot | ((uint64_t)hi.dot << 32);
+    m.dash = (uint64_t)lo.dash | ((uint64_t)hi.dash << 32);
+    m.high = (uint64_t)lo.high | ((uint64_t)hi.high << 32);
     return m;
 }
 

@@ -203,31 +203,55 @@ void DeviceDb::upload(const DbImage& img, int dev) {
         bool want24 = img.node_count >= 4096;
         if (const char* e = getenv("MATCHY_AMD_L24")) want24 = atoi(e) != 0 && img.node_count > 0;
         std::vector<uint32_t> bm(1u << 19, 0u);
+        // The tables are accelerators, not requirements: when their memory cannot be had (a smaller GPU, a process that holds several
+        // databases) the open degrades — no leaf tables (undecided /24s continue at their node: the reference's walk), then no /24
+        // table at all (16-level table + walk, below) — instead of failing. The leaf tables take at most a quarter of what is free.
+        bool have24 = false;
         if (want24) {
-            ip_l24.alloc((size_t)1 << 24);
-            ip_bm24.alloc(bm.size());
-            DevBuf<uint32_t> ctr;
-            ctr.alloc(2);
-            MXY_HIP(hipMemset(ctr.p, 0, 8));
-            launch_ip_l24(ip_nodes.p, img.node_count, v4_start, ip_l24.p, ip_bm24.p, ctr.p, nullptr);
-            uint32_t undecided = 0;
-            MXY_HIP(hipMemcpy(&undecided, ctr.p, 4, hipMemcpyDeviceToHost));
-            size_t cap_leaf = ((size_t)16 << 30) / (256 * sizeof(uint2));
-            if (const char* e = getenv("MATCHY_AMD_LEAF_MB")) cap_leaf = ((size_t)atoll(e) << 20) / (256 * sizeof(uint2));
-            const size_t n_leaf = std::min<size_t>(undecided, cap_leaf);
-            if (n_leaf) {
-                ip_leaf.alloc(n_leaf * 256);
+            try {
+                ip_l24.alloc((size_t)1 << 24);
+                ip_bm24.alloc(bm.size());
+                DevBuf<uint32_t> ctr;
+                ctr.alloc(2);
+                MXY_HIP(hipMemset(ctr.p, 0, 8));
+                launch_ip_l24(ip_nodes.p, img.node_count, v4_start, ip_l24.p, ip_bm24.p, ctr.p, nullptr);
+                uint32_t undecided = 0;
+                MXY_HIP(hipMemcpy(&undecided, ctr.p, 4, hipMemcpyDeviceToHost));
+                size_t cap_leaf = ((size_t)16 << 30) / (256 * sizeof(uint2));
+                size_t mem_free = 0, mem_total = 0;
+                if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) cap_leaf = std::min(cap_leaf, mem_free / 4 / (256 * sizeof(uint2)));
+                else (void)hipGetLastError();
+                if (const char* e = getenv("MATCHY_AMD_LEAF_MB")) cap_leaf = ((size_t)atoll(e) << 20) / (256 * sizeof(uint2));
+                size_t n_leaf = std::min<size_t>(undecided, cap_leaf);
                 DevBuf<uint32_t> leaf_node;
-                leaf_node.alloc(n_leaf);
-                launch_ip_leaf(ip_nodes.p, img.node_count, ip_l24.p, ctr.p + 1, (uint32_t)n_leaf, leaf_node.p, ip_leaf.p, nullptr);
-                MXY_HIP(hipDeviceSynchronize());   // leaf_node is released below
-                view.ip_leaf = ip_leaf.p;
-                bytes_uploaded += n_leaf * 256 * sizeof(uint2);
+                if (n_leaf) {
+                    try {
+                        ip_leaf.alloc(n_leaf * 256);
+                        leaf_node.alloc(n_leaf);
+                    } catch (const HipError&) {
+                        (void)hipGetLastError();
+                        ip_leaf.free();
+                        n_leaf = 0;   // the /24 entries of the undecided prefixes stay "continue at node"
+                    }
+                }
+                if (n_leaf) {
+                    launch_ip_leaf(ip_nodes.p, img.node_count, ip_l24.p, ctr.p + 1, (uint32_t)n_leaf, leaf_node.p, ip_leaf.p, nullptr);
+                    MXY_HIP(hipDeviceSynchronize());   // leaf_node is released below
+                    view.ip_leaf = ip_leaf.p;
+                    bytes_uploaded += n_leaf * 256 * sizeof(uint2);
+                }
+                view.ip_l24 = ip_l24.p;
+                bytes_uploaded += ((size_t)1 << 24) * sizeof(uint2);
+                MXY_HIP(hipMemcpy(bm.data(), ip_bm24.p, bm.size() * 4, hipMemcpyDeviceToHost));   // for the statistics below
+                have24 = true;
+            } catch (const HipError&) {
+                (void)hipGetLastError();
+                ip_l24.free(); ip_leaf.free(); ip_bm24.free();
+                view.ip_l24 = nullptr; view.ip_leaf = nullptr;
+                std::fill(bm.begin(), bm.end(), 0u);
             }
-            view.ip_l24 = ip_l24.p;
-            bytes_uploaded += ((size_t)1 << 24) * sizeof(uint2);
-            MXY_HIP(hipMemcpy(bm.data(), ip_bm24.p, bm.size() * 4, hipMemcpyDeviceToHost));   // for the statistics below
-        } else {
+        }
+        if (!have24) {
             if (img.node_count > 0) {
                 auto set_range = [&](uint32_t first, uint32_t count) {
                     for (uint32_t v = first; v < first + count;) {
@@ -1036,6 +1060,17 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         if (profile_ && expect_chains_) MXY_HIP(hipEventRecord(ev_[4], stream));
         expect_chains_ = 0;   // a rescan sets it again; the spill pass below runs on this stream
         wait_stream(stream, last_fork_);
+        if (host_slices_[0].error & 8u) {
+            // k_finish gave up polling for the side chains (they are slow, not lost): the counters it copied are a snapshot and the
+            // device copies were left alone. Join the side streams here, then take the counters again without a poll.
+            counters_clean_ = false;
+            if (trace) fprintf(stderr, "[matchy_amd] k_finish gave up polling for the side chains: joining the side streams on the host\n");
+            if (aux_stream_) MXY_HIP(hipStreamSynchronize(aux_stream_));
+            if (aux2_stream_) MXY_HIP(hipStreamSynchronize(aux2_stream_));
+            if (dom_stream_) MXY_HIP(hipStreamSynchronize(dom_stream_));
+            launch_finish(counters_.p, host_slices_, ns, 0u, stream);
+            wait_stream(stream, false);
+        }
         counters_clean_ = true;
         // slice 0 holds n_final / n_final_ids of all slices; statistics are summed
         ScanCounters& c = host_counters_;
@@ -1115,7 +1150,6 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     const ScanCounters& c = host_counters_;
     if (c.error & 1) throw HipError{"scan: a candidate matches more than 65535 glob patterns (the hit record counts pattern ids in 16 bits)"};
     if (c.error & 4) throw HipError{"scan: a candidate is longer than 16 MiB (24-bit length field)"};
-    if (c.error & 8) throw HipError{"scan: a side stream of the forked scan did not finish (k_finish timed out waiting for it)"};
     const double t_counters = since();
     if (trace) {
         ScanCounters t = host_slices_[0];
@@ -1310,16 +1344,12 @@ void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_
         static const bool no_reg = getenv("MATCHY_AMD_NO_REGISTER") != nullptr;
         if (!no_reg && n >= ((size_t)4 << 20)) {
             const uintptr_t a = ((uintptr_t)src + 4095) & ~(uintptr_t)4095, b = ((uintptr_t)src + n) & ~(uintptr_t)4095;
-            // pinned already (hipHostMalloc, or registered by the caller: matchy_amd_host_register on the whole pages)? asked for the
-            // first whole page: the bytes in front of it may belong to a neighbour's page
-            hipPointerAttribute_t attr;
-            const bool known = b > a && hipPointerGetAttributes(&attr, (const void*)a) == hipSuccess && attr.type != hipMemoryTypeUnregistered;
-            (void)hipGetLastError();
-            if (known) { reg_lo = (const uint8_t*)a; reg_len = b - a; }
-            else if (b > a && hipHostRegister((void*)a, b - a, hipHostRegisterDefault) == hipSuccess) { reg_lo = (const uint8_t*)a; reg_len = b - a; mine = true; }
-            (void)hipGetLastError();
+            // pins::acquire: the whole range is covered by a pin of this library (the caller's, or another scanner's transient one —
+            // its count goes up, so it stays pinned until this copy is done too), or it is pinned now. Anything else (memory someone
+            // else pinned, a partial overlap, a failed registration) takes the one plain copy below.
+            if (b > a && pins::acquire(a, b)) { reg_lo = (const uint8_t*)a; reg_len = b - a; mine = true; }
         }
-        struct Unreg { const uint8_t* p; ~Unreg() { if (p) (void)hipHostUnregister((void*)p); } } unreg{mine ? reg_lo : nullptr};
+        struct Unreg { uintptr_t a, b; ~Unreg() { if (b > a) pins::release(a, b); } } unreg{mine ? (uintptr_t)reg_lo : 0, mine ? (uintptr_t)reg_lo + reg_len : 0};
         const double t_reg = ms_since(th0);
         if (reg_lo) {
             const size_t head = (size_t)(reg_lo - src), tail = n - head - reg_len;
@@ -1354,5 +1384,56 @@ void Scanner::scan_host(const uint8_t* data, size_t len, bool lookup, bool want_
     } while (pos < len);
     out.cands.swap(all_cands);
 }
+
+namespace pins {
+namespace {
+struct Entry { uintptr_t a, b; int refs; bool caller; };
+std::mutex g_mutex;
+std::vector<Entry> g_entries;
+}  // namespace
+bool acquire(uintptr_t a, uintptr_t b) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (Entry& e : g_entries) {
+        if (e.a <= a && b <= e.b) { ++e.refs; return true; }
+        if (a < e.b && e.a < b) return false;   // partial overlap with a pinned range: registering would fail, a pinned-path copy would run over unpinned pages
+    }
+    const hipError_t err = hipHostRegister((void*)a, b - a, hipHostRegisterDefault);
+    if (err != hipSuccess) { (void)hipGetLastError(); return false; }   // pinned by someone else (hipHostMalloc, a foreign registration) or not pinnable
+    g_entries.push_back(Entry{a, b, 1, false});
+    return true;
+}
+void release(uintptr_t a, uintptr_t b) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (size_t i = 0; i < g_entries.size(); ++i) {
+        Entry& e = g_entries[i];
+        if (!(e.a <= a && b <= e.b) || e.refs <= 0) continue;
+        if (--e.refs == 0 && !e.caller) {
+            (void)hipHostUnregister((void*)e.a);
+            (void)hipGetLastError();
+            g_entries.erase(g_entries.begin() + (long)i);
+        }
+        return;
+    }
+}
+int add_caller(const void* ptr, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    g_entries.push_back(Entry{(uintptr_t)ptr, (uintptr_t)ptr + bytes, 1, true});   // the caller's own reference
+    return 0;
+}
+void remove_caller(const void* ptr) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (size_t i = 0; i < g_entries.size(); ++i) {
+        if (g_entries[i].a != (uintptr_t)ptr || !g_entries[i].caller) continue;
+        // the caller says the range is no longer in use (it must not unregister under its own scans): drop it whatever the count
+        (void)hipHostUnregister(const_cast<void*>(ptr));
+        (void)hipGetLastError();
+        g_entries.erase(g_entries.begin() + (long)i);
+        return;
+    }
+    (void)hipHostUnregister(const_cast<void*>(ptr));   // not registered through this library: as before
+    (void)hipGetLastError();
+}
+}  // namespace pins
 
 }  // namespace mxy

@@ -112,6 +112,21 @@ struct ScanOutput {
     uint64_t by_type[IT_COUNT] = {0};
 };
 
+// Process-wide registry of the host ranges this library pinned (hipHostRegister): the caller's (matchy_amd_host_register, kept until
+// matchy_amd_host_unregister) and the transient ones Scanner::scan_host pins around its copies. Reference-counted, so that a range two
+// scanners copy from at the same time is unpinned when the LAST copy is done — never under a DMA another thread has in flight — and a
+// range is only ever treated as pinned when an entry of the registry covers ALL of it. Memory pinned by someone else (hipHostMalloc,
+// a foreign hipHostRegister) is not in the registry: scan_host copies from it with one plain hipMemcpyAsync and leaves the choice of
+// path to the runtime, which knows.
+namespace pins {
+// returns true when [a, b) is pinned for the caller until release(a, b): covered by an entry (its count goes up) or registered now.
+bool acquire(uintptr_t a, uintptr_t b);
+void release(uintptr_t a, uintptr_t b);
+// caller-owned entries (matchy_amd_host_register / _unregister); 0 = success
+int add_caller(const void* ptr, size_t bytes);
+void remove_caller(const void* ptr);
+}
+
 // A scan session: owns the per-launch work buffers on one device. Not thread-safe; create one per thread/stream.
 class Scanner {
 public:

@@ -426,17 +426,26 @@ __device__ bool val_ipv6_win(const uint8_t* win, uint32_t p2, uint32_t& start, u
 // E-mail (ext:891-950, 1182-1196). Both scans go a word at a time over long runs (a multi-megabyte local part is one
 // lane's work): the rules need the class of each byte, "two dots in a row" and "any letter", all of which the SWAR masks give.
 struct LocalMasks { uint64_t loc, dot, alp; };
-__device__ __forceinline__ LocalMasks email_local_masks(uint64_t x) {
-    constexpr uint64_t H = 0x8080808080808080ull, L7 = 0x7F7F7F7F7F7F7F7Full;
-    const uint64_t t = x & L7, l = t | 0x2020202020202020ull;
-    const uint64_t dig = (t + 0x5050505050505050ull) & ~(t + 0x4646464646464646ull);
-    const uint64_t alp = (l + 0x1F1F1F1F1F1F1F1Full) & ~(l + 0x0505050505050505ull);
-    const uint64_t ndot = (t ^ 0x2E2E2E2E2E2E2E2Eull) + L7, ndash = (t ^ 0x2D2D2D2D2D2D2D2Dull) + L7;
-    const uint64_t nus = (t ^ 0x5F5F5F5F5F5F5F5Full) + L7, npl = (t ^ 0x2B2B2B2B2B2B2B2Bull) + L7;
-    LocalMasks m;
+struct LocalMasks32 { uint32_t loc, dot, alp; };
+__device__ __forceinline__ LocalMasks32 email_local_masks32(uint32_t x) {   // 32-bit halves: see domain_masks32
+    constexpr uint32_t H = 0x80808080u, L7 = 0x7F7F7F7Fu;
+    const uint32_t t = x & L7, l = t | 0x20202020u;
+    const uint32_t dig = (t + 0x50505050u) & ~(t + 0x46464646u);
+    const uint32_t alp = (l + 0x1F1F1F1Fu) & ~(l + 0x05050505u);
+    const uint32_t ndot = (t ^ 0x2E2E2E2Eu) + L7, ndash = (t ^ 0x2D2D2D2Du) + L7;
+    const uint32_t nus = (t ^ 0x5F5F5F5Fu) + L7, npl = (t ^ 0x2B2B2B2Bu) + L7;
+    LocalMasks32 m;
     m.dot = ~ndot & ~x & H;
     m.alp = alp & ~x & H;
     m.loc = (dig | alp | ~ndot | ~ndash | ~nus | ~npl) & ~x & H;   // is_email_local_char (ext:1644)
+    return m;
+}
+__device__ __forceinline__ LocalMasks email_local_masks(uint64_t x) {
+    const LocalMasks32 lo = email_local_masks32((uint32_t)x), hi = email_local_masks32((uint32_t)(x >> 32));
+    LocalMasks m;
+    m.loc = (uint64_t)lo.loc | ((uint64_t)hi.loc << 32);
+    m.dot = (uint64_t)lo.dot | ((uint64_t)hi.dot << 32);
+    m.alp = (uint64_t)lo.alp | ((uint64_t)hi.alp << 32);
     return m;
 }
 // State of the leftward scan over the local part: s = its current start, prev = the last byte consumed.

@@ -10,6 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 GOLD = Path(__file__).parent / "golden"
+ROOT = Path(__file__).resolve().parent.parent
 
 
 @pytest.fixture(scope="module")
@@ -114,29 +115,22 @@ def test_extractor_segment_and_block_edges(gpu_extractor, oracle):
             assert norm(gpu_extractor.extract_from_chunk(buf)) == norm(oracle.extract(buf)), (pl, pad)
 
 
-def _scan_both(M, oracle, blob, text):
-    db = M.Database(blob)
-    sc = M.Scanner(db)
-    res = sc.scan(text)
-    got_hits = res.hits()
-    got_lines = res.ndjson(text, source="t.log")
-    got_stats = (res.lines, res.candidates)
-    res.close()
-    if text:
-        # the same bytes through the device-resident entry: that one runs the independent parts of a scan on three streams
-        # (the host-buffer entry above stays on one), and both must agree hit for hit
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        dptr = ctypes.c_void_p()
-        assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(len(text) + 64)) == 0
-        assert hip.hipMemcpy(dptr, bytes(text), ctypes.c_size_t(len(text)), 1) == 0
+def _device_entries(sc, text, got_hits, got_lines, got_stats, slices=(2, 5)):
+    """The same bytes through the device-resident entries of an existing scanner — forked (independent parts of a scan on several
+    streams), sliced, submitted / waited, and with compact IPv4 records — against the results of the host-buffer entry."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    dptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(len(text) + 64)) == 0
+    assert hip.hipMemcpy(dptr, bytes(text), ctypes.c_size_t(len(text)), 1) == 0
+    try:
         rd = sc.scan_device(dptr.value, len(text), fetch_mode=3)
         assert (rd.lines, rd.candidates) == got_stats
         assert rd.hits() == got_hits
         rd.close()
         # ... and cut into slices (the tail of one slice beside the streaming pass of the next; cuts on 8 KiB multiples, not
         # on newlines): same counters, same records
-        for ns in (2, 5):
+        for ns in slices:
             if len(text) >= ns * 8192:
                 sc.set_slices(ns)
                 rs = sc.scan_device(dptr.value, len(text), fetch_mode=3)
@@ -150,6 +144,7 @@ def _scan_both(M, oracle, blob, text):
         # through submit / wait (one stream)
         key = lambda h: (h["start"], h["end"], h["type"], h["kind"])
         n_v4 = sum(1 for h in got_hits if h["type"] == "IPv4")
+        want_sorted = sorted(got_hits, key=key)
         for how in ("forked", "sliced", "submitted"):
             if how == "sliced":
                 if len(text) < 3 * 8192:
@@ -162,10 +157,25 @@ def _scan_both(M, oracle, blob, text):
                 rc = sc.scan_device(dptr.value, len(text), fetch_mode=9)
             sc.set_slices(0)
             assert (rc.lines, rc.candidates, rc.n_hits, rc.n_ip4_hits) == (*got_stats, len(got_hits), n_v4), how
-            assert sorted(rc.hits(), key=key) == sorted(got_hits, key=key), how
-            assert sorted(rc.ndjson(text, source="t.log")) == sorted(got_lines), how
+            assert sorted(rc.hits(), key=key) == want_sorted, how
+            if got_lines is not None:
+                assert sorted(rc.ndjson(text, source="t.log")) == sorted(got_lines), how
             rc.close()
+    finally:
+        sc.set_slices(0)
         hip.hipFree(dptr)
+
+
+def _scan_both(M, oracle, blob, text):
+    db = M.Database(blob)
+    sc = M.Scanner(db)
+    res = sc.scan(text)
+    got_hits = res.hits()
+    got_lines = res.ndjson(text, source="t.log")
+    got_stats = (res.lines, res.candidates)
+    res.close()
+    if text:
+        _device_entries(sc, text, got_hits, got_lines, got_stats)
     sc.close(); db.close()
     odb = oracle.Database(blob)
     want_hits, want_lines, st = odb.scan(text, source="t.log")
@@ -348,6 +358,98 @@ def test_concurrent_queries_and_scans(M, oracle):
         th.join(timeout=300)
     assert not errors, errors[:5]
     db.close()
+
+
+def test_concurrent_forked_device_scans(M, oracle):
+    """Four threads, each with its OWN scanner, twenty device-resident scans apiece at the same time (the reference's workers
+    run concurrently: processing/parallel.rs:594-704). `matchy_scanner_scan_device` always forks — side streams per scanner, and a
+    k_finish that polls a counter bumped by kernels in other hardware queues — so several forked scans in flight share the
+    runtime's few hardware queues: every scan must still return exactly the oracle's records, and quickly (a k_finish that
+    starves a chain it is waiting for would sit out its poll time-out: seconds per scan)."""
+    import ctypes
+    import threading
+    import time
+    from tools import synth
+    cfg = synth.config("c4/10")   # globs: the early glob pass and the undecided domains' chain are side streams too
+    blob = synth.build_db(cfg)
+    db = M.Database(blob)
+    odb = oracle.Database(blob)
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_threads, n_scans, n_batches = 4, 20, 5
+    logs = [[synth.make_log(cfg, 40000 * (t * n_batches + b), 20000 + 1000 * b) for b in range(n_batches)] for t in range(n_threads)]
+    want = [[odb.scan(l, want_json=False) for l in per] for per in logs]
+    dptrs = [[ctypes.c_void_p() for _ in per] for per in logs]
+    for per, dp in zip(logs, dptrs):
+        for l, d in zip(per, dp):
+            assert hip.hipMalloc(ctypes.byref(d), ctypes.c_size_t(len(l) + 64)) == 0
+            assert hip.hipMemcpy(d, l, ctypes.c_size_t(len(l)), 1) == 0
+    errors = []
+    start = threading.Barrier(n_threads)
+
+    def worker(t):
+        try:
+            sc = M.Scanner(db)
+            start.wait(timeout=60)
+            for k in range(n_scans):
+                b = k % n_batches
+                r = sc.scan_device(dptrs[t][b].value, len(logs[t][b]), fetch_mode=3)
+                w_hits, _, st = want[t][b]
+                if (r.lines, r.candidates) != (st.lines, st.candidates) or r.hits() != w_hits:
+                    errors.append((t, k, "records differ"))
+                r.close()
+            sc.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, "exception", repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    t0 = time.time()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    took = time.time() - t0
+    for dp in dptrs:
+        for d in dp:
+            hip.hipFree(d)
+    db.close()
+    assert not errors, errors[:5]
+    assert not any(th.is_alive() for th in threads)
+    # 80 scans of ~4 MB: a few milliseconds each even when the streams of four forked scans collide in the hardware queues
+    assert took < 20.0, took
+
+
+def test_finish_poll_gives_the_join_back_to_the_host(M, oracle):
+    """k_finish polls for the side chains of a forked scan; when it gives up (here: at once, MATCHY_AMD_FINISH_POLL_US=0 in a child
+    process) the scan must not fail or lose records: the host joins the side streams and takes the counters again."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, sys
+sys.path.insert(0, %r)
+import matchy_amd as M
+from tools import synth
+from oracle import oracle as orc
+orc.build()
+cfg = synth.config("c4/10")
+blob = synth.build_db(cfg)
+log = synth.make_log(cfg, 0, 30000)
+db = M.Database(blob); sc = M.Scanner(db)
+hip = ctypes.CDLL("libamdhip64.so")
+d = ctypes.c_void_p()
+assert hip.hipMalloc(ctypes.byref(d), ctypes.c_size_t(len(log) + 64)) == 0
+assert hip.hipMemcpy(d, log, ctypes.c_size_t(len(log)), 1) == 0
+want, _, st = orc.Database(blob).scan(log, want_json=False)
+for rep in range(5):
+    r = sc.scan_device(d.value, len(log), fetch_mode=3)
+    assert (r.lines, r.candidates) == (st.lines, st.candidates), rep
+    assert r.hits() == want, rep
+    r.close()
+print("OK")
+""" % str(ROOT)
+    env = dict(os.environ, MATCHY_AMD_FINISH_POLL_US="0", MATCHY_AMD_TRACE="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-2000:]
+    assert "joining the side streams on the host" in p.stderr, p.stderr[-2000:]
 
 
 def _long_domain_runs(seed, count=700):

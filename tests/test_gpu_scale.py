@@ -356,30 +356,48 @@ def test_config5_full_database(M, oracle):
     sc.close(); db.close()
 
 
-@pytest.mark.parametrize("cfgname", ["c3", "c4"])
+@pytest.mark.parametrize("cfgname", ["c3", "c3b", "c4"])
 def test_full_database_multi_batch(M, oracle, cfgname):
-    """BASELINE configs[2] (1 M domain / hash literals) and configs[3] (100 K indicators incl. 10 K globs) at full database size:
-    three consecutive batches of the log through one scanner (buffers and lists are reused between batches), each against the
-    oracle."""
+    """BASELINE configs[2] (1 M domain / hash literals; c3b: the same keys written `glob:` = 1 M Aho-Corasick literals with substring
+    semantics) and configs[3] (100 K indicators incl. 10 K globs) at full database size. Three consecutive batches of the log through
+    one scanner's host-buffer entry (buffers and lists are reused between batches), each against the oracle; then the first batch
+    (300 K lines) and a HASH-DENSE batch (two or three file hashes per line: more than 256 K long-token anchors, the point where the
+    lean lookup pass keeps the automaton walk instead of handing unwalked candidates to the glob pass) through every device-resident
+    entry — forked with the early glob pass and the undecided domains' chain on their own streams, sliced, submitted, compact records —
+    against the same oracle results."""
     from tools import synth
+    from tests.test_gpu_parity import _device_entries
     cfg = synth.config(cfgname)
     blob = synth.build_db(cfg)
     db = M.Database(blob)
     sc = M.Scanner(db)
     odb = oracle.Database(blob)
-    per = 250000
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    per = 300000
     total = 0
+    first = None
     for bi in range(3):
         log = synth.make_log(cfg, bi * per, per if bi != 1 else per // 3)   # a short batch in the middle
         res = sc.scan(log)
         hits = res.hits()
         stats = (res.lines, res.candidates)
         res.close()
-        want, _, st = odb.scan(log, threads=min(len(os.sched_getaffinity(0)), 16), cache=0, want_json=False)
+        want, _, st = odb.scan(log, threads=threads, cache=0, want_json=False)
         assert stats == (st.lines, st.candidates)
         assert hits == want
         total += len(want)
+        if bi == 0:
+            first = (log, want, stats)
     assert total > 1000
+    _device_entries(sc, first[0], first[1], None, first[2], slices=(3,))
+    dense = synth.make_log(cfg, 7_000_000, 300000, shape="hash-dense")
+    want, _, st = odb.scan(dense, threads=threads, cache=0, want_json=False)
+    assert st.candidates > 600000 and len(want) > 1000
+    res = sc.scan(dense)
+    assert (res.lines, res.candidates) == (st.lines, st.candidates)
+    assert res.hits() == want
+    res.close()
+    _device_entries(sc, dense, want, None, (st.lines, st.candidates), slices=(3,))
     sc.close(); db.close()
 
 

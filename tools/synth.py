@@ -66,6 +66,8 @@ def lib():
         L = C.CDLL(str(LIB))
         L.synth_log.argtypes = [C.POINTER(Cfg), C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]
         L.synth_log.restype = C.c_size_t
+        L.synth_log_shape.argtypes = [C.POINTER(Cfg), C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]
+        L.synth_log_shape.restype = C.c_size_t
         L.synth_ioc_feed.argtypes = [C.POINTER(Cfg), C.c_int, C.c_void_p, C.c_void_p]
         L.synth_ioc_feed.restype = C.c_longlong
         for f in (L.synth_ioc_key, L.synth_ioc_data):
@@ -75,20 +77,25 @@ def lib():
     return _lib
 
 
-def make_log(cfg: Cfg, first_line: int, n_lines: int) -> bytes:
+# log shapes (tools/synthgen.cpp gen_shape): name -> id; "skewed-halves" takes the period in lines as `shape_param`
+SHAPES = {"nginx": 0, "jsonl-app": 1, "ip-dense": 2, "url-heavy": 3, "hash-dense": 4, "skewed-halves": 5}
+
+
+def make_log(cfg: Cfg, first_line: int, n_lines: int, shape: str = "nginx", shape_param: int = 0) -> bytes:
     L = lib()
-    cap = n_lines * 320 + 1024
+    sid = SHAPES[shape]
+    cap = n_lines * 360 + 1024
     buf = C.create_string_buffer(cap)
-    n = L.synth_log(C.byref(cfg), first_line, n_lines, buf, cap)
+    n = L.synth_log_shape(C.byref(cfg), sid, shape_param, first_line, n_lines, buf, cap)
     if n > cap:
         buf = C.create_string_buffer(n)
-        n = L.synth_log(C.byref(cfg), first_line, n_lines, buf, n)
+        n = L.synth_log_shape(C.byref(cfg), sid, shape_param, first_line, n_lines, buf, n)
     return buf.raw[:n]
 
 
-def make_log_into(cfg: Cfg, first_line: int, n_lines: int, ptr: int, cap: int) -> int:
+def make_log_into(cfg: Cfg, first_line: int, n_lines: int, ptr: int, cap: int, shape: str = "nginx", shape_param: int = 0) -> int:
     """Generate straight into caller memory (e.g. a pinned torch tensor). Returns bytes written (or needed)."""
-    return lib().synth_log(C.byref(cfg), first_line, n_lines, ptr, cap)
+    return lib().synth_log_shape(C.byref(cfg), SHAPES[shape], shape_param, first_line, n_lines, ptr, cap)
 
 
 KINDS = (("ip", 0, "n_ip"), ("cidr", 1, "n_cidr"), ("domain", 2, "n_dom"), ("hash", 3, "n_hash"), ("glob", 4, "n_glob"))

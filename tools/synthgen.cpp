@@ -177,6 +177,144 @@ void gen_line(const Cfg& c, uint64_t L, std::string& out) {
     out += "\"\n";
 }
 
+// ---- other log shapes (bench.py --log-shape, BASELINE.md: a scan engine's number is only as good as its worst common input).
+// Every line is still a pure function of (seed, line index); database indicators are planted at the same per-mille rate.
+void planted_or_benign_ip(const Cfg& c, uint64_t h, std::string& out) {
+    const uint32_t n_ipdb = c.n_ip + c.n_cidr;
+    if ((uint32_t)(h % 1000) < c.hit_permille && c.n_ip) ioc_key(c, 0, (uint32_t)((h >> 12) % c.n_ip), out);
+    else if ((uint32_t)(h % 1000) < c.hit_permille && n_ipdb) {
+        std::string k;
+        ioc_key(c, 1, (uint32_t)((h >> 12) % c.n_cidr), k);
+        unsigned a, b, cc, d, p;
+        sscanf(k.c_str(), "%u.%u.%u.%u/%u", &a, &b, &cc, &d, &p);
+        ipv4_str((a << 24) | (b << 16) | (cc << 8) | d, out);
+    } else ipv4_str(public_v4(splitmix64(0x77ull ^ ((h >> 12) % 1000000))), out);
+}
+void planted_or_benign_domain(const Cfg& c, uint64_t h, std::string& out) {
+    const uint32_t pick = (uint32_t)(h % 1000), half = c.hit_permille / 2 ? c.hit_permille / 2 : 1;
+    if (pick < half && c.n_dom) ioc_key(c, 2, (uint32_t)((h >> 12) % c.n_dom), out);
+    else if (pick < 2 * half && c.n_glob) {
+        std::string g;
+        ioc_key(c, 4, (uint32_t)((h >> 12) % c.n_glob), g);
+        out += std::string(WORDS[(h >> 50) & 31]) + g.substr(1);
+    } else {
+        const uint64_t d = splitmix64(0x99ull ^ ((h >> 12) % 200000));
+        if ((d >> 30) & 1) out += ((d >> 31) & 1) ? "www." : "cdn-assets.";
+        out += std::string("site") + std::to_string((unsigned)(d % 200000)) + "." + TLDS[(d >> 20) % 20];
+    }
+}
+void planted_or_random_hash(const Cfg& c, uint64_t h, int nchars, std::string& out) {
+    if ((uint32_t)(h % 1000) < c.hit_permille && c.n_hash) ioc_key(c, 3, (uint32_t)((h >> 12) % c.n_hash), out);
+    else hex_of(splitmix64(h ^ 0xABCDull), nchars, out);
+}
+void iso_time(uint64_t L, std::string& out) {
+    const uint64_t sec = L / 50;
+    char ts[64];
+    snprintf(ts, sizeof(ts), "2026-01-%02uT%02u:%02u:%02u.%03uZ", (unsigned)(1 + (sec / 86400) % 28), (unsigned)((sec / 3600) % 24), (unsigned)((sec / 60) % 60),
+             (unsigned)(sec % 60), (unsigned)((L % 50) * 20));
+    out += ts;
+}
+// 1: application log as JSON lines (structured fields, quoted strings, few dots outside timestamps / addresses)
+void gen_jsonl(const Cfg& c, uint64_t L, std::string& out) {
+    static const char* LEVEL[4] = {"info", "info", "warn", "error"};
+    static const char* SVC[8] = {"auth", "billing", "search", "gateway", "mailer", "orders", "profile", "ingest"};
+    const uint64_t h = splitmix64(c.seed ^ (0x1111ull << 48) ^ L), h2 = splitmix64(h), h3 = splitmix64(h2);
+    out += "{\"ts\":\"";
+    iso_time(L, out);
+    out += std::string("\",\"level\":\"") + LEVEL[h & 3] + "\",\"service\":\"" + SVC[(h >> 2) & 7] + "\",\"client_ip\":\"";
+    planted_or_benign_ip(c, h2, out);
+    out += "\",\"host\":\"";
+    planted_or_benign_domain(c, h3, out);
+    out += "\",\"user\":\"";
+    if ((h >> 8) % 4 == 0) { out += std::string(WORDS[(h >> 12) & 31]) + "." + WORDS[(h >> 17) & 31] + "@"; planted_or_benign_domain(c, splitmix64(h3), out); }
+    else out += std::string("u") + std::to_string((unsigned)((h >> 12) % 1000000));
+    out += std::string("\",\"msg\":\"") + WORDS[(h2 >> 20) & 31] + " " + WORDS[(h2 >> 25) & 31] + " " + WORDS[(h2 >> 30) & 31] + " took " + std::to_string((unsigned)((h2 >> 35) % 5000)) + "ms\",\"trace_id\":\"";
+    hex_of(h3, 32, out);
+    out += std::string("\",\"status\":") + std::to_string(200 + (unsigned)((h3 >> 40) % 4) * 100) + "}\n";
+}
+// 2: firewall / flow log: several addresses per line, hardly anything else
+void gen_ip_dense(const Cfg& c, uint64_t L, std::string& out) {
+    const uint64_t h = splitmix64(c.seed ^ (0x2222ull << 48) ^ L);
+    char b[96];
+    snprintf(b, sizeof(b), "Jan %2u %02u:%02u:%02u fw7 kernel: ACCEPT IN=eth%u OUT=eth%u ", (unsigned)(1 + (L / 4320000) % 28), (unsigned)((L / 180000) % 24),
+             (unsigned)((L / 3000) % 60), (unsigned)((L / 50) % 60), (unsigned)(h & 3), (unsigned)((h >> 2) & 3));
+    out += b;
+    uint64_t g = h;
+    out += "SRC="; planted_or_benign_ip(c, g = splitmix64(g), out);
+    out += " DST="; planted_or_benign_ip(c, g = splitmix64(g), out);
+    out += " NAT="; planted_or_benign_ip(c, g = splitmix64(g), out);
+    out += ",";     planted_or_benign_ip(c, g = splitmix64(g), out);
+    snprintf(b, sizeof(b), " LEN=%u TTL=%u PROTO=TCP SPT=%u DPT=%u via ", (unsigned)(40 + (h >> 8) % 1400), (unsigned)(32 + (h >> 20) % 96), (unsigned)(1024 + (h >> 28) % 60000), (unsigned)((h >> 44) % 1024));
+    out += b;
+    planted_or_benign_ip(c, g = splitmix64(g), out);
+    out += " ";
+    planted_or_benign_ip(c, g = splitmix64(g), out);
+    if ((h >> 60) == 0) { snprintf(b, sizeof(b), " fe80::%x 2001:db8:%x::%x", (unsigned)(h >> 12) & 0xFFFF, (unsigned)(h >> 20) & 0xFFFF, (unsigned)((h >> 36) & 0xFFFF) | 1u); out += b; }
+    out += "\n";
+}
+// 3: proxy log with long URLs: many host names and file names with extensions per line
+void gen_url_heavy(const Cfg& c, uint64_t L, std::string& out) {
+    const uint64_t h = splitmix64(c.seed ^ (0x3333ull << 48) ^ L);
+    char b[64];
+    snprintf(b, sizeof(b), "%llu.%03u %6u ", (unsigned long long)(1767225600ull + L / 50), (unsigned)((L % 50) * 20), (unsigned)(h % 900000));
+    out += b;
+    uint64_t g = h;
+    planted_or_benign_ip(c, g = splitmix64(g), out);
+    out += " TCP_MISS/200 GET https://";
+    planted_or_benign_domain(c, g = splitmix64(g), out);
+    path_of(g >> 7, out);
+    out += "?ref=http://";
+    planted_or_benign_domain(c, g = splitmix64(g), out);
+    path_of(g >> 9, out);
+    out += "&img=https://static.";
+    planted_or_benign_domain(c, g = splitmix64(g), out);
+    out += std::string("/") + WORDS[(g >> 40) & 31] + "_" + WORDS[(g >> 45) & 31] + ".min.js&next=";
+    planted_or_benign_domain(c, g = splitmix64(g), out);
+    out += "/index.html - DIRECT/";
+    planted_or_benign_domain(c, g = splitmix64(g), out);
+    out += " text/html\n";
+}
+// 4: endpoint-detection style log: two or three file hashes per line
+void gen_hash_dense(const Cfg& c, uint64_t L, std::string& out) {
+    const uint64_t h = splitmix64(c.seed ^ (0x4444ull << 48) ^ L);
+    iso_time(L, out);
+    out += std::string(" host-") + std::to_string((unsigned)(h % 5000)) + " proc=" + WORDS[(h >> 13) & 31] + ".exe pid=" + std::to_string((unsigned)((h >> 18) % 65536)) + " sha256=";
+    uint64_t g = h;
+    planted_or_random_hash(c, g = splitmix64(g), 64, out);
+    out += " md5=";
+    planted_or_random_hash(c, g = splitmix64(g), 32, out);
+    if ((h >> 40) & 1) { out += " sha1="; planted_or_random_hash(c, g = splitmix64(g), 40, out); }
+    out += std::string(" path=C:/Users/") + WORDS[(h >> 41) & 31] + "/AppData/" + WORDS[(h >> 46) & 31] + "/" + WORDS[(h >> 51) & 31] + ".dll parent=";
+    hex_of(splitmix64(g), 16, out);   // 16 hex digits: too short for any hash type
+    out += "\n";
+}
+// 5: skewed halves: of every `period` lines the first half is prose without a dot, a colon or a digit run (nothing to extract:
+// the streaming pass runs its front end only), the second half is the address-dense shape — statically assigned equal
+// segments then finish at very different times
+void gen_skewed(const Cfg& c, uint64_t L, uint64_t period, std::string& out) {
+    if (period < 2) period = 2;
+    if (L % period >= period / 2) { gen_ip_dense(c, L, out); return; }
+    const uint64_t h = splitmix64(c.seed ^ (0x5555ull << 48) ^ L);
+    uint64_t g = h;
+    const int words = 18 + (int)(h & 15);
+    for (int k = 0; k < words; ++k) {
+        if ((k & 7) == 0) g = splitmix64(g);
+        if (k) out.push_back(' ');
+        out += WORDS[(g >> (5 * (k & 7))) & 31];
+    }
+    out += "\n";
+}
+void gen_shape(const Cfg& c, int shape, uint64_t param, uint64_t L, std::string& out) {
+    switch (shape) {
+        case 1: gen_jsonl(c, L, out); break;
+        case 2: gen_ip_dense(c, L, out); break;
+        case 3: gen_url_heavy(c, L, out); break;
+        case 4: gen_hash_dense(c, L, out); break;
+        case 5: gen_skewed(c, L, param, out); break;
+        default: gen_line(c, L, out); break;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -198,6 +336,20 @@ size_t synth_log(const synth_cfg_t* cfg, uint64_t first, uint64_t n, uint8_t* ou
     }
     return pos;
 }
+// The same for another log shape: 0 nginx (synth_log), 1 jsonl-app, 2 ip-dense, 3 url-heavy, 4 hash-dense, 5 skewed-halves (param = period in lines)
+size_t synth_log_shape(const synth_cfg_t* cfg, int shape, uint64_t param, uint64_t first, uint64_t n, uint8_t* out, size_t cap) {
+    Cfg c = to_cfg(cfg);
+    size_t pos = 0;
+    std::string line;
+    for (uint64_t L = first; L < first + n; ++L) {
+        line.clear();
+        gen_shape(c, shape, param, L, line);
+        if (pos + line.size() <= cap) memcpy(out + pos, line.data(), line.size());
+        pos += line.size();
+    }
+    return pos;
+}
+
 size_t synth_ioc_key(const synth_cfg_t* cfg, int kind, uint32_t i, char* out, size_t cap) {
     std::string s;
     ioc_key(to_cfg(cfg), kind, i, s);
