@@ -343,6 +343,58 @@ int32_t matchy_amd_host_register(const void *ptr, size_t bytes);
 void matchy_amd_host_unregister(const void *ptr);
 /* HIP devices visible to the process (0 when there is none); `matchy match --devices all` */
 int32_t matchy_amd_device_count(void);
+/* Host topology for multi-GPU scatter / gather (every GPU is fed from host memory over its own PCIe link, and on a
+ * two-socket node the H2D rate depends on which socket the feeding thread runs on). NUMA node of a device's PCI function
+ * (hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<id>/numa_node; -1 = the platform does not say), and binding of the CALLING thread to
+ * the CPUs of that node (sched_setaffinity within the thread's current mask; returns the CPUs it may run on afterwards, 0 = unchanged).
+ * matchy_amd_numa_cpus is the mapping itself over any sysfs root (tests): CPUs near `pci_bus_id`, count returned, first `cap` stored. */
+int32_t matchy_amd_device_numa_node(int32_t device);
+int32_t matchy_amd_bind_thread_to_device(int32_t device);
+int32_t matchy_amd_numa_cpus(const char *sysfs_root, const char *pci_bus_id, int32_t *out_cpus, size_t cap);
+
+/* ---- Multi-device scanner (additive). The reader -> workers -> ordered gather of the reference's process_files_parallel
+ * (crates/matchy/src/processing/parallel.rs:494-505; workers :594-704) behind the C ABI: the host submits newline-aligned batches,
+ * one worker thread per entry of `devices` (an entry may repeat: several batches of one GPU in flight) scans them with a scanner of
+ * its own, bound to the NUMA node of its GPU, and the host takes the results back in SUBMISSION order. Line blocks are independent
+ * and the database is replicated per device: no collective; counters are summed by the caller. */
+typedef struct matchy_multi_scanner_t matchy_multi_scanner_t;
+typedef struct matchy_multi_batch_t {
+  size_t seq;                  /* submission index */
+  int32_t status;              /* MATCHY_SUCCESS or the error of this batch (text: matchy_amd_last_error) */
+  matchy_scan_result_t result; /* canonical order, offsets relative to `data`; owned by the taker: matchy_scan_result_free */
+  const uint8_t *data;
+  size_t len;
+  void *tag;                   /* as submitted (matchy_multi_scanner_scan_file: the batch's offset in the file) */
+  void *payload;               /* what the batch hook returned for this batch, or NULL */
+  size_t worker;               /* index into the device list of the worker that scanned it */
+} matchy_multi_batch_t;
+typedef struct matchy_multi_totals_t { uint64_t batches, bytes, lines, candidates, matches; } matchy_multi_totals_t;
+/* Called on the WORKER thread right after a batch's scan (per-hit work such as rendering runs in parallel there); the
+ * returned pointer travels with the batch as matchy_multi_batch_t.payload. */
+typedef void *(*matchy_multi_batch_fn)(void *user, size_t worker, const matchy_scanner_t *scanner, const matchy_scan_result_t *result,
+                                       const uint8_t *data, size_t len, void *tag);
+/* Called on the gathering thread, batches in order; non-zero stops the scan and is returned. */
+typedef int32_t (*matchy_multi_ordered_fn)(void *user, const matchy_multi_batch_t *batch);
+/* devices NULL / n_devices 0 = the handle's default device once. extract_flags as matchy_scanner_create. NULL on failure. */
+matchy_multi_scanner_t *matchy_multi_scanner_create(const matchy_t *db, uint32_t extract_flags, const int32_t *devices, size_t n_devices);
+void matchy_multi_scanner_free(matchy_multi_scanner_t *ms);
+size_t matchy_multi_scanner_workers(const matchy_multi_scanner_t *ms);
+/* The scanner of a worker (NULL until that worker has seen a batch; worker 0's exists from the start): for matchy_scan_hit_to_json. */
+const matchy_scanner_t *matchy_multi_scanner_worker_scanner(const matchy_multi_scanner_t *ms, size_t worker);
+void matchy_multi_scanner_set_batch_hook(matchy_multi_scanner_t *ms, matchy_multi_batch_fn fn, void *user);
+/* Queue one batch (it should end at a line end; len < 4 GiB). The bytes stay the caller's and must remain valid until the batch has
+ * been taken with _next. Blocks while one batch per worker is already waiting. pinned_range: NULL, or the page range the caller
+ * registered for this batch with matchy_amd_host_register — the worker unregisters it after the scan. */
+int32_t matchy_multi_scanner_submit(matchy_multi_scanner_t *ms, const uint8_t *data, size_t len, void *tag, const void *pinned_range);
+/* The next batch in submission order (blocks until it is done): 1 = *out filled, 0 = nothing pending, < 0 = error. */
+int32_t matchy_multi_scanner_next(matchy_multi_scanner_t *ms, matchy_multi_batch_t *out);
+/* One buffer through all workers, cut at newlines into pieces of batch_bytes (0 = chosen from len and the worker count), merged into
+ * ONE result with offsets into `data`: the same records matchy_scanner_scan returns for these bytes, whatever the device list. */
+int32_t matchy_multi_scanner_scan(matchy_multi_scanner_t *ms, const uint8_t *data, size_t len, size_t batch_bytes, matchy_scan_result_t *out);
+/* One input file: a regular file is mapped (its batches are cut, pre-faulted and pinned by a reader thread), "-" / a pipe is read.
+ * `fn` (may be NULL) sees every batch in file order on the calling thread, tag = offset of the batch in the input; totals may be NULL. */
+int32_t matchy_multi_scanner_scan_file(matchy_multi_scanner_t *ms, const char *path, size_t batch_bytes, matchy_multi_ordered_fn fn,
+                                       void *user, matchy_multi_totals_t *totals);
 /* Deterministic builds for tests: fixes the build_epoch metadata value. */
 int32_t matchy_builder_set_build_epoch(matchy_builder_t *b, uint64_t epoch);
 

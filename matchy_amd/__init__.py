@@ -43,6 +43,10 @@ EXPORTED_SYMBOLS = [
     "matchy_scanner_wait", "matchy_scanner_set_slices", "matchy_scanner_last_slices", "matchy_scan_result_on_device",
     "matchy_amd_ac_dfa_states", "matchy_amd_suffix_filter", "matchy_amd_pinned_alloc", "matchy_amd_pinned_free",
     "matchy_amd_host_register", "matchy_amd_host_unregister",
+    "matchy_amd_device_numa_node", "matchy_amd_bind_thread_to_device", "matchy_amd_numa_cpus",
+    "matchy_multi_scanner_create", "matchy_multi_scanner_free", "matchy_multi_scanner_workers", "matchy_multi_scanner_worker_scanner",
+    "matchy_multi_scanner_set_batch_hook", "matchy_multi_scanner_submit", "matchy_multi_scanner_next", "matchy_multi_scanner_scan",
+    "matchy_multi_scanner_scan_file",
 ]
 
 
@@ -98,6 +102,18 @@ class _ScanResult(C.Structure):
 
 
 _lib = None
+
+
+class _MultiBatch(C.Structure):
+    _fields_ = [("seq", C.c_size_t), ("status", C.c_int32), ("result", _ScanResult), ("data", C.c_void_p), ("len", C.c_size_t),
+                ("tag", C.c_void_p), ("payload", C.c_void_p), ("worker", C.c_size_t)]
+
+
+class _MultiTotals(C.Structure):
+    _fields_ = [("batches", C.c_uint64), ("bytes", C.c_uint64), ("lines", C.c_uint64), ("candidates", C.c_uint64), ("matches", C.c_uint64)]
+
+
+_MULTI_ORDERED_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(_MultiBatch))
 
 
 def lib():
@@ -173,6 +189,18 @@ def lib():
         "matchy_free_entry_data_list": (None, [C.POINTER(_EntryDataList)]),
         "matchy_validate": (C.c_int32, [cp, C.c_int32, C.POINTER(vp)]),
         "matchy_builder_set_schema": (C.c_int32, [vp, cp]),
+        "matchy_amd_device_count": (C.c_int32, []),
+        "matchy_amd_device_numa_node": (C.c_int32, [C.c_int32]),
+        "matchy_amd_bind_thread_to_device": (C.c_int32, [C.c_int32]),
+        "matchy_amd_numa_cpus": (C.c_int32, [cp, cp, C.POINTER(C.c_int32), C.c_size_t]),
+        "matchy_multi_scanner_create": (vp, [vp, C.c_uint32, C.POINTER(C.c_int32), C.c_size_t]),
+        "matchy_multi_scanner_free": (None, [vp]),
+        "matchy_multi_scanner_workers": (C.c_size_t, [vp]),
+        "matchy_multi_scanner_worker_scanner": (vp, [vp, C.c_size_t]),
+        "matchy_multi_scanner_submit": (C.c_int32, [vp, vp, C.c_size_t, vp, vp]),
+        "matchy_multi_scanner_next": (C.c_int32, [vp, C.POINTER(_MultiBatch)]),
+        "matchy_multi_scanner_scan": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(_ScanResult)]),
+        "matchy_multi_scanner_scan_file": (C.c_int32, [vp, cp, C.c_size_t, _MULTI_ORDERED_FN, vp, C.POINTER(_MultiTotals)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -524,3 +552,72 @@ class Scanner:
             self.close()
         except Exception:
             pass
+
+
+class _WorkerScanner:
+    """the scanner of one worker of a MultiScanner, as far as ScanResult needs it (matchy_scan_hit_to_json)"""
+
+    def __init__(self, h):
+        self._h = h
+
+
+class MultiScanner:
+    """One scan session over several devices (matchy_multi_scanner_*): the reader -> per-device workers -> ordered gather of the
+    reference's process_files_parallel (processing/parallel.rs:494-505) behind the C ABI. `devices` may repeat an ordinal (several
+    batches of one GPU in flight)."""
+
+    def __init__(self, db: Database, devices=(0,), extract_flags=0):
+        self._db = db
+        arr = (C.c_int32 * len(devices))(*devices)
+        self._h = lib().matchy_multi_scanner_create(db.handle, extract_flags, arr, len(devices))
+        if not self._h:
+            raise RuntimeError("matchy_multi_scanner_create failed: " + last_error())
+        self.workers = lib().matchy_multi_scanner_workers(self._h)
+
+    def scan(self, data: bytes, batch_bytes: int = 0) -> ScanResult:
+        """one buffer through all workers; the merged result has offsets into `data` (= Scanner.scan of the same bytes)"""
+        raw = _ScanResult()
+        rc = lib().matchy_multi_scanner_scan(self._h, bytes(data), len(data), batch_bytes, C.byref(raw))
+        if rc != 0:
+            raise RuntimeError(f"matchy_multi_scanner_scan failed ({rc}): " + last_error())
+        return ScanResult(_WorkerScanner(lib().matchy_multi_scanner_worker_scanner(self._h, 0)), raw)
+
+    def scan_file(self, path: str, batch_bytes: int = 0, on_batch=None):
+        """scan one file (or "-"); on_batch(offset, nbytes, hits, lines, candidates) is called per batch in file order. Returns the totals."""
+        L = lib()
+        me = self
+
+        def cb(_user, bp):
+            b = bp.contents
+            if on_batch is not None:
+                r = ScanResult(_WorkerScanner(L.matchy_multi_scanner_worker_scanner(me._h, b.worker)), b.result)
+                try:
+                    on_batch(int(b.tag or 0), int(b.len), r.hits(), int(b.result.lines), int(b.result.candidates))
+                finally:
+                    r._raw = None   # the library releases the result when the callback returns
+            return 0
+
+        fn = _MULTI_ORDERED_FN(cb)
+        tot = _MultiTotals()
+        rc = L.matchy_multi_scanner_scan_file(self._h, os.fsencode(path), batch_bytes, fn, None, C.byref(tot))
+        if rc != 0:
+            raise RuntimeError(f"matchy_multi_scanner_scan_file failed ({rc}): " + last_error())
+        return dict(batches=tot.batches, bytes=tot.bytes, lines=tot.lines, candidates=tot.candidates, matches=tot.matches)
+
+    def close(self):
+        if self._h:
+            lib().matchy_multi_scanner_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def numa_cpus(sysfs_root: str, pci_bus_id: str):
+    """CPUs on the NUMA node of a PCI device under any sysfs root (matchy_amd_numa_cpus: the mapping the workers bind with)"""
+    out = (C.c_int32 * 4096)()
+    n = lib().matchy_amd_numa_cpus(os.fsencode(sysfs_root), pci_bus_id.encode(), out, 4096)
+    return [out[i] for i in range(max(0, min(n, 4096)))]

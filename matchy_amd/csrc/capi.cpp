@@ -16,6 +16,19 @@
 #include "db_builder.h"
 #include "db_image.h"
 #include "engine.h"
+#include "host_topology.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <thread>
 #include "netaddr.h"
 
 #include <list>
@@ -864,6 +877,306 @@ char* matchy_scan_hit_to_json(const matchy_scanner_t* s, const matchy_scan_resul
     o += ",\"source\":"; json_escape(source ? source : "-", o);
     o += ",\"timestamp\":\"0.000\"}";
     return strdup(o.c_str());
+}
+
+
+// ------------------------------------------------------------------------------------------------ multi-device scanner
+// The reader -> per-device workers -> ordered gather of `matchy match` (reference: process_files_parallel,
+// crates/matchy/src/processing/parallel.rs:494-505 and its workers :594-704) behind the C ABI: the host submits newline-aligned
+// batches, one worker thread per device entry scans them with a scanner of its own (host-buffer entry: the batch is pinned for its copy,
+// results come back in canonical order), and the host takes the results back IN SUBMISSION ORDER. No data-path collective: line blocks
+// are independent (N4), the database is replicated per device, the counters are summed by the caller.
+}  // extern "C"
+
+namespace {
+struct MultiJob { size_t seq; const uint8_t* data; size_t len; void* tag; const void* pinned; };
+struct MultiDone { int32_t status = MATCHY_SUCCESS; matchy_scan_result_t res{}; const uint8_t* data = nullptr; size_t len = 0; void* tag = nullptr; void* payload = nullptr; size_t worker = 0; };
+struct MultiScanner {
+    const matchy_t* db = nullptr;
+    uint32_t flags = 0;
+    std::vector<int> devices;
+    std::vector<matchy_scanner_t*> scanners;
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done, cv_space;
+    std::deque<MultiJob> q;
+    std::map<size_t, MultiDone> done;
+    size_t submitted = 0, taken = 0, max_q = 2;
+    bool closing = false;
+    matchy_multi_batch_fn hook = nullptr;
+    void* hook_user = nullptr;
+    std::string first_error;   // of a worker (scanner creation, scan): reported through matchy_amd_last_error by next()
+
+    void worker(size_t w) {
+        // this thread faults its batches' pages in, pins them and queues their copies: on the NUMA node of its GPU
+        static const bool no_bind = getenv("MATCHY_AMD_NO_NUMA_BIND") != nullptr;
+        if (!no_bind) (void)matchy_amd_bind_thread_to_device(devices[w]);
+        for (;;) {
+            MultiJob j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return closing || !q.empty(); });
+                if (q.empty()) return;
+                j = q.front();
+                q.pop_front();
+                cv_space.notify_one();
+            }
+            MultiDone d;
+            d.data = j.data; d.len = j.len; d.tag = j.tag; d.worker = w;
+            if (!scanners[w]) scanners[w] = matchy_scanner_create(db, flags, devices[w]);
+            std::string err;
+            if (!scanners[w]) { d.status = MATCHY_ERROR_IO; err = std::string("multi scanner: no scanner on device ") + std::to_string(devices[w]) + ": " + matchy_amd_last_error(); }
+            else if (j.len) {
+                d.status = matchy_scanner_scan(scanners[w], j.data, j.len, &d.res);
+                if (d.status != MATCHY_SUCCESS) err = matchy_amd_last_error();
+            }
+            if (d.status == MATCHY_SUCCESS && hook) d.payload = hook(hook_user, w, scanners[w], &d.res, j.data, j.len, j.tag);
+            if (j.pinned) matchy_amd_host_unregister(j.pinned);   // behind the hook: the unpin of this batch then runs beside the next worker's copy, not in front of this one's per-hit work
+            std::lock_guard<std::mutex> lk(mu);
+            if (!err.empty() && first_error.empty()) first_error = err;
+            done.emplace(j.seq, d);
+            cv_done.notify_all();
+        }
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int32_t matchy_amd_device_numa_node(int32_t device) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return mxy::numa_node_of_pci("/sys", bus);
+}
+int32_t matchy_amd_bind_thread_to_device(int32_t device) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return mxy::bind_calling_thread(mxy::cpus_near_pci("/sys", bus));
+}
+int32_t matchy_amd_numa_cpus(const char* sysfs_root, const char* pci_bus_id, int32_t* out, size_t cap) {
+    if (!sysfs_root || !pci_bus_id) return -1;
+    const std::vector<int> cpus = mxy::cpus_near_pci(sysfs_root, pci_bus_id);
+    for (size_t i = 0; i < cpus.size() && i < cap; ++i) out[i] = cpus[i];
+    return (int32_t)cpus.size();
+}
+
+matchy_multi_scanner_t* matchy_multi_scanner_create(const matchy_t* db, uint32_t extract_flags, const int32_t* devices, size_t n_devices) {
+    if (!db) return nullptr;
+    auto ms = std::make_unique<MultiScanner>();
+    ms->db = db; ms->flags = extract_flags;
+    if (!devices || !n_devices) ms->devices.push_back(reinterpret_cast<const Db*>(db)->default_device);
+    else for (size_t i = 0; i < n_devices; ++i) { if (devices[i] < 0) { set_error("matchy_multi_scanner_create: negative device"); return nullptr; } ms->devices.push_back(devices[i]); }
+    ms->scanners.assign(ms->devices.size(), nullptr);
+    ms->max_q = ms->devices.size() + 1;
+    // the first scanner now, so that a database or device that cannot be used fails here; the others are created by their workers
+    // when the first batch reaches them (a small input never pays for scanners it does not use)
+    ms->scanners[0] = matchy_scanner_create(db, extract_flags, ms->devices[0]);
+    if (!ms->scanners[0]) return nullptr;
+    MultiScanner* raw = ms.get();
+    for (size_t w = 0; w < ms->devices.size(); ++w) ms->workers.emplace_back([raw, w] { raw->worker(w); });
+    return reinterpret_cast<matchy_multi_scanner_t*>(ms.release());
+}
+void matchy_multi_scanner_free(matchy_multi_scanner_t* h) {
+    if (!h) return;
+    MultiScanner* ms = reinterpret_cast<MultiScanner*>(h);
+    { std::lock_guard<std::mutex> lk(ms->mu); ms->closing = true; ms->cv_work.notify_all(); }
+    for (auto& t : ms->workers) t.join();
+    for (auto& kv : ms->done) matchy_scan_result_free(&kv.second.res);   // results nobody took
+    for (auto* sc : ms->scanners) if (sc) matchy_scanner_free(sc);
+    delete ms;
+}
+size_t matchy_multi_scanner_workers(const matchy_multi_scanner_t* h) { return h ? reinterpret_cast<const MultiScanner*>(h)->devices.size() : 0; }
+const matchy_scanner_t* matchy_multi_scanner_worker_scanner(const matchy_multi_scanner_t* h, size_t worker) {
+    const MultiScanner* ms = reinterpret_cast<const MultiScanner*>(h);
+    return ms && worker < ms->scanners.size() ? ms->scanners[worker] : nullptr;
+}
+void matchy_multi_scanner_set_batch_hook(matchy_multi_scanner_t* h, matchy_multi_batch_fn fn, void* user) {
+    if (!h) return;
+    MultiScanner* ms = reinterpret_cast<MultiScanner*>(h);
+    std::lock_guard<std::mutex> lk(ms->mu);
+    ms->hook = fn; ms->hook_user = user;
+}
+int32_t matchy_multi_scanner_submit(matchy_multi_scanner_t* h, const uint8_t* data, size_t len, void* tag, const void* pinned_range) {
+    if (!h || (!data && len) || len > 0xFFFFFFFFull) return MATCHY_ERROR_INVALID_PARAM;
+    MultiScanner* ms = reinterpret_cast<MultiScanner*>(h);
+    std::unique_lock<std::mutex> lk(ms->mu);
+    ms->cv_space.wait(lk, [&] { return ms->q.size() < ms->max_q; });
+    ms->q.push_back(MultiJob{ms->submitted++, data, len, tag, pinned_range});
+    ms->cv_work.notify_one();
+    return MATCHY_SUCCESS;
+}
+int32_t matchy_multi_scanner_next(matchy_multi_scanner_t* h, matchy_multi_batch_t* out) {
+    if (!h || !out) return MATCHY_ERROR_INVALID_PARAM;
+    MultiScanner* ms = reinterpret_cast<MultiScanner*>(h);
+    std::unique_lock<std::mutex> lk(ms->mu);
+    if (ms->taken == ms->submitted) return 0;   // nothing pending
+    ms->cv_done.wait(lk, [&] { return ms->done.count(ms->taken) != 0; });
+    const MultiDone d = ms->done[ms->taken];
+    ms->done.erase(ms->taken);
+    out->seq = ms->taken++;
+    out->status = d.status; out->result = d.res; out->data = d.data; out->len = d.len; out->tag = d.tag; out->payload = d.payload; out->worker = d.worker;
+    if (d.status != MATCHY_SUCCESS) set_error(ms->first_error.empty() ? "multi scanner: a batch failed" : ms->first_error);
+    return 1;
+}
+
+// One buffer through all workers: cut at newlines into pieces (batch_bytes each; 0 = the buffer spread twice over the workers, at
+// least 4 MiB and at most 256 MiB a piece), results merged into ONE result with offsets into `data` — what matchy_scanner_scan
+// returns for the same bytes, whatever the device list.
+int32_t matchy_multi_scanner_scan(matchy_multi_scanner_t* h, const uint8_t* data, size_t len, size_t batch_bytes, matchy_scan_result_t* out) {
+    if (!h || !out || (!data && len) || len > 0xFFFFFFFFull) return MATCHY_ERROR_INVALID_PARAM;
+    MultiScanner* ms = reinterpret_cast<MultiScanner*>(h);
+    { std::lock_guard<std::mutex> lk(ms->mu); if (ms->taken != ms->submitted) { set_error("matchy_multi_scanner_scan: batches of an earlier submit are still pending"); return MATCHY_ERROR_INVALID_PARAM; } }
+    if (!batch_bytes) {
+        batch_bytes = (len + 2 * ms->devices.size() - 1) / (2 * ms->devices.size());
+        batch_bytes = std::min<size_t>(std::max<size_t>(batch_bytes, (size_t)4 << 20), (size_t)256 << 20);
+    }
+    auto in = std::make_unique<ScanResultInternal>();
+    uint64_t lines = 0, cands = 0;
+    int32_t status = MATCHY_SUCCESS;
+    std::string err;
+    auto take = [&](bool all) {
+        for (;;) {
+            { std::lock_guard<std::mutex> lk(ms->mu); if (ms->taken == ms->submitted) return; if (!all && !ms->done.count(ms->taken)) return; }
+            matchy_multi_batch_t b;
+            if (matchy_multi_scanner_next(h, &b) != 1) return;
+            if (b.status != MATCHY_SUCCESS) { if (status == MATCHY_SUCCESS) { status = b.status; err = matchy_amd_last_error(); } }
+            else {
+                const uint32_t base = (uint32_t)(b.data - data), id_shift = (uint32_t)in->ids.size();
+                for (size_t i = 0; i < b.result.n_hits; ++i) {
+                    matchy_scan_hit_t x = b.result.hits[i];
+                    x.start += base;
+                    if (x.kind == 3) x.value += id_shift;
+                    in->hits.push_back(x);
+                }
+                in->ids.insert(in->ids.end(), b.result.pattern_ids, b.result.pattern_ids + b.result.n_ids);
+                in->offs.insert(in->offs.end(), b.result.data_offsets, b.result.data_offsets + b.result.n_ids);
+                lines += b.result.lines; cands += b.result.candidates;
+            }
+            matchy_scan_result_free(&b.result);
+        }
+    };
+    for (size_t pos = 0; pos < len;) {
+        size_t end = std::min(len, pos + batch_bytes);
+        if (end < len) {   // newline-aligned cut; a line longer than the piece extends it to that line's end
+            const void* nl = memrchr(data + pos, '\n', end - pos);
+            if (nl) end = (size_t)((const uint8_t*)nl - data) + 1;
+            else { const void* fw = memchr(data + end, '\n', len - end); end = fw ? (size_t)((const uint8_t*)fw - data) + 1 : len; }
+        }
+        matchy_multi_scanner_submit(h, data + pos, end - pos, nullptr, nullptr);
+        pos = end;
+        take(false);
+    }
+    take(true);
+    if (status != MATCHY_SUCCESS) { set_error(err); return status; }
+    memset(out, 0, sizeof(*out));
+    out->lines = lines; out->candidates = cands; out->bytes = len;
+    out->n_hits = in->hits.size(); out->n_ids = in->ids.size();
+    out->hits = in->hits.data(); out->pattern_ids = in->ids.data(); out->data_offsets = in->offs.data();
+    out->_internal = in.release();
+    return MATCHY_SUCCESS;
+}
+
+// A regular file (mapped; a reader thread cuts it into newline-aligned batches, faults their pages in, pins them and submits them) or a
+// stream ("-" = stdin, a pipe: read into buffers of batch_bytes). `fn` is called on the calling thread for every batch IN FILE ORDER
+// with the batch's result and its offset in the file (batch->tag); the result is released when fn returns. Compressed inputs are the
+// caller's business (decompress and matchy_multi_scanner_submit: `matchy match` does that for .gz). Returns 0, or the first error.
+int32_t matchy_multi_scanner_scan_file(matchy_multi_scanner_t* h, const char* path, size_t batch_bytes, matchy_multi_ordered_fn fn, void* user, matchy_multi_totals_t* totals) {
+    if (!h || !path) return MATCHY_ERROR_INVALID_PARAM;
+    MultiScanner* ms = reinterpret_cast<MultiScanner*>(h);
+    { std::lock_guard<std::mutex> lk(ms->mu); if (ms->taken != ms->submitted) { set_error("matchy_multi_scanner_scan_file: batches of an earlier submit are still pending"); return MATCHY_ERROR_INVALID_PARAM; } }
+    if (!batch_bytes) batch_bytes = (size_t)256 << 20;
+    if (batch_bytes > 0xF0000000ull) batch_bytes = 0xF0000000ull;
+    const bool is_stdin = strcmp(path, "-") == 0;
+    const int fd = is_stdin ? 0 : open(path, O_RDONLY);
+    if (fd < 0) { set_error(std::string("matchy_multi_scanner_scan_file: cannot open ") + path + ": " + strerror(errno)); return MATCHY_ERROR_FILE_NOT_FOUND; }
+    struct stat sb;
+    const bool regular = !is_stdin && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0;
+    void* map = MAP_FAILED;
+    size_t map_len = 0;
+    if (regular) { map_len = (size_t)sb.st_size; map = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0); }
+    std::atomic<bool> reader_ok{true}, stop{false}, reader_finished{false};
+    const bool mapped = map != MAP_FAILED;
+    std::thread reader([&] {
+        struct Finished { std::atomic<bool>& f; ~Finished() { f = true; } } fin{reader_finished};
+        if (mapped) {
+            (void)madvise(map, map_len, MADV_SEQUENTIAL);
+            const uint8_t* base = (const uint8_t*)map;
+            for (size_t pos = 0; pos < map_len && !stop;) {
+                size_t end = std::min(map_len, pos + batch_bytes);
+                if (end < map_len) {
+                    const void* nl = memrchr(base + pos, '\n', end - pos);
+                    if (nl) end = (size_t)((const uint8_t*)nl - base) + 1;
+                    else { const void* fw = memchr(base + end, '\n', map_len - end); end = fw ? (size_t)((const uint8_t*)fw - base) + 1 : map_len; }
+                }
+                const uint8_t* p = base + pos;
+                const size_t n = end - pos;
+                const void* pinned = nullptr;
+                if (n >= ((size_t)4 << 20)) {
+                    const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, z = ((uintptr_t)p + n) & ~(uintptr_t)4095;
+#ifdef MADV_POPULATE_READ
+                    (void)madvise((void*)((uintptr_t)p & ~(uintptr_t)4095), (uintptr_t)p + n - ((uintptr_t)p & ~(uintptr_t)4095), MADV_POPULATE_READ);
+#endif
+                    if (z > a && matchy_amd_host_register((const void*)a, z - a) == MATCHY_SUCCESS) pinned = (const void*)a;
+                }
+                matchy_multi_scanner_submit(h, p, n, (void*)(uintptr_t)pos, pinned);
+                pos = end;
+            }
+            return;
+        }
+        // stream: read batch_bytes, cut at the last newline, carry the rest into the next buffer; a submitted buffer belongs to the
+        // gathering thread, which frees it when its batch has been handed to the callback
+        size_t cap = batch_bytes + 16, have = 0;
+        uint64_t off = 0;
+        uint8_t* buf = (uint8_t*)malloc(cap);
+        if (!buf) { reader_ok = false; return; }
+        for (;;) {
+            if (have == cap - 16) { cap *= 2; uint8_t* nb = (uint8_t*)realloc(buf, cap); if (!nb) { reader_ok = false; break; } buf = nb; }
+            const ssize_t r = read(fd, buf + have, std::min(cap - 16 - have, (size_t)1 << 30));
+            if (r < 0) { if (errno == EINTR) continue; reader_ok = false; break; }
+            have += (size_t)r;
+            const bool eof = r == 0;
+            if (!eof && have < batch_bytes) continue;
+            size_t cut = have;
+            if (!eof) { const void* nl = memrchr(buf, '\n', have); if (!nl) continue; cut = (size_t)((const uint8_t*)nl - buf) + 1; }
+            uint8_t* nxt = nullptr;
+            const size_t rest = have - cut;
+            if (!eof) { nxt = (uint8_t*)malloc(std::max(batch_bytes, rest) + 16); if (!nxt) { reader_ok = false; break; } memcpy(nxt, buf + cut, rest); }
+            if (cut) matchy_multi_scanner_submit(h, buf, cut, (void*)(uintptr_t)off, nullptr);
+            else free(buf);
+            off += cut;
+            buf = nxt; cap = std::max(batch_bytes, rest) + 16; have = rest;
+            if (eof || stop) break;
+        }
+        if (buf) free(buf);
+    });
+    // the calling thread gathers in order while the reader is still submitting
+    int32_t status = MATCHY_SUCCESS;
+    std::string err;
+    matchy_multi_totals_t t{};
+    for (;;) {
+        matchy_multi_batch_t b;
+        int32_t r = matchy_multi_scanner_next(h, &b);
+        if (r == 0) {
+            if (!reader_finished) { std::this_thread::sleep_for(std::chrono::microseconds(200)); continue; }   // between two submits
+            r = matchy_multi_scanner_next(h, &b);   // the reader has submitted its last batch: anything still pending?
+            if (r == 0) break;
+        }
+        if (r != 1) { if (status == MATCHY_SUCCESS) { status = r; err = "matchy_multi_scanner_scan_file: gather failed"; } break; }
+        if (b.status != MATCHY_SUCCESS) { if (status == MATCHY_SUCCESS) { status = b.status; err = matchy_amd_last_error(); stop = true; } }
+        else {
+            t.batches += 1; t.bytes += b.len; t.lines += b.result.lines; t.candidates += b.result.candidates; t.matches += b.result.n_hits + b.result.n_ip4_hits;
+            if (fn && status == MATCHY_SUCCESS) { const int32_t fr = fn(user, &b); if (fr != 0) { status = fr; err = "matchy_multi_scanner_scan_file: the batch callback asked to stop"; stop = true; } }
+        }
+        matchy_scan_result_free(&b.result);
+        if (!mapped) free(const_cast<uint8_t*>(b.data));
+    }
+    reader.join();
+    if (map != MAP_FAILED) munmap(map, map_len);
+    if (!is_stdin) close(fd);
+    if (totals) *totals = t;
+    if (!reader_ok && status == MATCHY_SUCCESS) { status = MATCHY_ERROR_IO; err = std::string("matchy_multi_scanner_scan_file: reading ") + path + " failed"; }
+    if (status != MATCHY_SUCCESS) set_error(err);
+    return status;
 }
 
 }  // extern "C"

@@ -21,6 +21,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -283,9 +284,11 @@ struct Totals {
 };
 
 // ---- `matchy match`: reader -> batches -> one worker per device entry -> ordered printer
-// The reader cuts every input into newline-aligned batches (FileReader::next_batch, processing/mod.rs:206-251) and hands
-// them out in sequence; every worker owns one scanner (= one GPU stream and its buffers) on its device; the printer
-// emits the rendered batches in sequence order, so the output is the same for every device list (line blocks
+// The pipeline itself is the library's (matchy_multi_scanner_*: one worker thread and scanner per device entry, batches handed out in
+// sequence, results taken back in sequence — processing/parallel.rs:494-505 behind the C ABI). What stays here is what belongs to
+// the command line: the reader cuts every input into newline-aligned batches (FileReader::next_batch, processing/mod.rs:206-251;
+// regular files are mapped, .gz / stdin are read), the batch hook renders a batch's matches on the worker that scanned it, and the
+// printer emits the rendered batches in sequence order, so the output is the same for every device list (line blocks
 // are independent, the database is replicated, the host gathers the hit records and sums the counters; no collective).
 // bytes without the value-initialisation of std::vector (a 256 MiB batch buffer would be zeroed before every read)
 struct RawBuf {
@@ -299,52 +302,35 @@ struct RawBuf {
         p = std::move(q); cap = n;
     }
 };
-// `ptr` points into `own` (inputs that are read: stdin, .gz) or into a file mapping that outlives the pipeline
-// ... or names a byte range of an open regular file (`fd` >= 0): the worker that takes the batch reads the range into its own pinned buffer
-struct Batch { size_t seq = 0, input = 0; RawBuf own; const uint8_t* ptr = nullptr; size_t len = 0; bool mapped = false; int fd = -1; off_t off = 0;
+// `ptr` points into `own` (inputs that are read: stdin, .gz) or into a file mapping that outlives the batch
+struct Batch { size_t input = 0; RawBuf own; const uint8_t* ptr = nullptr; size_t len = 0; bool mapped = false;
                const void* reg = nullptr; };   // reg: page range of a mapped batch the reader pinned ahead of the scan (unpinned by the worker)
-// Page-locked buffer of one worker (matchy_amd_pinned_alloc): file ranges are read into it with pread and reach the device by DMA
-struct PinnedBuf {
-    uint8_t* p = nullptr;
-    size_t cap = 0;
-    uint8_t* need(size_t n) {
-        if (cap < n) {
-            matchy_amd_pinned_free(p);
-            cap = n + n / 8 + 4096;
-            p = (uint8_t*)matchy_amd_pinned_alloc(cap);
-            if (!p) cap = 0;
-        }
-        return p;
-    }
-    ~PinnedBuf() { matchy_amd_pinned_free(p); }
-    PinnedBuf() = default;
-    PinnedBuf(const PinnedBuf&) = delete;
-    PinnedBuf& operator=(const PinnedBuf&) = delete;
-};
 struct Done { std::string out; Totals t; bool ok = true; size_t input = 0; };
 
 struct MatchPipeline {
+    matchy_multi_scanner_t* ms = nullptr;
     std::mutex mu;
-    std::condition_variable cv_work, cv_done, cv_space;
-    std::deque<Batch> q;
-    std::map<size_t, Done> done;
-    size_t max_q = 2, submitted = 0;
-    bool closed = false;
+    size_t submitted = 0;
+    std::atomic<bool> reader_done{false};
     bool json = true;
     std::vector<std::string> sources;
 
+    // the batch goes to the library's queue; its Batch object travels as the tag and comes back with the result
     size_t submit(Batch&& b) {
-        std::unique_lock<std::mutex> lk(mu);
-        cv_space.wait(lk, [&] { return q.size() < max_q; });
-        const size_t seq = b.seq = submitted++;
-        q.push_back(std::move(b));
-        cv_work.notify_one();
+        Batch* hb = new Batch(std::move(b));
+        size_t seq;
+        { std::lock_guard<std::mutex> lk(mu); seq = submitted++; }
+        if (matchy_multi_scanner_submit(ms, hb->ptr, hb->len, hb, hb->reg) != MATCHY_SUCCESS) {
+            // not queued (cannot happen for batches below 4 GiB): the printer never sees it
+            fprintf(stderr, "[ERROR] batch of %zu bytes rejected: %s\n", hb->len, matchy_amd_last_error());
+            if (hb->reg) matchy_amd_host_unregister(hb->reg);
+            delete hb;
+        }
         return seq;
     }
     // Mapped inputs: the mapping of a file is released by the printer as soon as the file's last batch has been printed — the
     // page tables of a file of gigabytes take tens of milliseconds to tear down, and that runs beside the scans of the next
     // files instead of behind the last one.
-    std::vector<int> open_fds;   // regular files whose ranges are read by the workers (closed by the caller when the pipeline has drained)
     struct Mapping { void* p; size_t len; size_t last_seq; bool released; };
     std::vector<Mapping> mappings;   // guarded by mu
     void add_mapping(void* p, size_t len, size_t last_seq) { std::lock_guard<std::mutex> lk(mu); mappings.push_back({p, len, last_seq, false}); }
@@ -356,51 +342,13 @@ struct MatchPipeline {
         }
         for (const Mapping& m : go) munmap(m.p, m.len);
     }
-    void close() { std::lock_guard<std::mutex> lk(mu); closed = true; cv_work.notify_all(); cv_done.notify_all(); }
-
-    // scan one batch and render its matches
-    void run_batch(matchy_scanner_t* sc, Batch& b, Done& d, PinnedBuf& pin) {
-        d.input = b.input;
-        if (!b.len) return;
-        static const bool trace = getenv("MATCHY_AMD_TRACE") != nullptr;
-        const auto t0 = std::chrono::steady_clock::now();
-        auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-        if (b.fd >= 0) {   // a range of a regular file: into this worker's pinned buffer
-            uint8_t* dst = pin.need(b.len);
-            size_t have = 0;
-            while (dst && have < b.len) {
-                const ssize_t r = pread(b.fd, dst + have, b.len - have, b.off + (off_t)have);
-                if (r < 0 && errno == EINTR) continue;
-                if (r <= 0) break;
-                have += (size_t)r;
-            }
-            if (!dst || have != b.len) {
-                fprintf(stderr, "[ERROR] Failed to read %s: %s\n", sources[b.input].c_str(), dst ? (have < b.len ? "file shrank or read error" : "") : matchy_amd_last_error());
-                d.ok = false;
-                return;
-            }
-            b.ptr = dst;
-        }
-#ifdef MADV_POPULATE_READ
-        if (b.mapped && !b.reg) {   // pre-fault the batch's pages in one call (in the worker: the workers run side by side)
-            const uintptr_t a = (uintptr_t)b.ptr & ~(uintptr_t)4095;
-            (void)madvise((void*)a, (uintptr_t)b.ptr + b.len - a, MADV_POPULATE_READ);
-        }
-#endif
-        const double t_pop = ms();
-        matchy_scan_result_t r;
-        memset(&r, 0, sizeof(r));
-        if (matchy_scanner_scan(sc, b.ptr, b.len, &r) != MATCHY_SUCCESS) {
-            fprintf(stderr, "[ERROR] scan failed: %s\n", matchy_amd_last_error());
-            d.ok = false;
-            return;
-        }
-        const double t_scan = ms();
+    // what one batch contributes to the output: counters, and (json) its matches rendered — on the worker thread that scanned it
+    void render(const matchy_scanner_t* sc, const matchy_scan_result_t& r, const uint8_t* data, size_t len, size_t input, Done& d) {
+        d.input = input;
         Totals& t = d.t;
-        t.lines += r.lines; t.candidates += r.candidates; t.bytes += b.len; t.matches += r.n_hits;
+        t.lines += r.lines; t.candidates += r.candidates; t.bytes += len; t.matches += r.n_hits;
         // lines with matches: hits come sorted by offset; a new line starts when a '\n' lies between two hit starts
-        const uint8_t* data = b.ptr;
-        const std::string& source = sources[b.input];
+        const std::string& source = sources[input];
         size_t prev = (size_t)-1;
         for (size_t i = 0; i < r.n_hits; ++i) {
             const size_t s = (size_t)r.hits[i].start;
@@ -411,114 +359,66 @@ struct MatchPipeline {
                 if (line) { d.out += line; d.out.push_back('\n'); matchy_free_string(line); }
             }
         }
-        const double t_loop = ms();
-        if (b.reg) { matchy_amd_host_unregister(b.reg); b.reg = nullptr; }
-        matchy_scan_result_free(&r);
-        if (trace) fprintf(stderr, "[matchy] batch %zu B: pre-fault %.3f ms, scan %.3f ms, hits loop %.3f ms, free %.3f ms\n", b.len, t_pop, t_scan - t_pop, t_loop - t_scan, ms() - t_loop);
     }
-    template <class GetScanner>
-    void worker(GetScanner get_scanner) {   // get_scanner(): this worker's scanner, created at its first batch
-        PinnedBuf pin;
-        for (;;) {
-            Batch b;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [&] { return closed || !q.empty(); });
-                if (q.empty()) return;
-                b = std::move(q.front());
-                q.pop_front();
-                cv_space.notify_one();
-            }
-            Done d;
-            {
-                // the reader pinned the batch's pages ahead of the scan (b.reg): unpinned on EVERY way out of the batch — a failed
-                // scan and a scanner that could not be created included — before release_mappings() unmaps the file
-                struct Unpin { Batch& b; ~Unpin() { if (b.reg) { matchy_amd_host_unregister(b.reg); b.reg = nullptr; } } } unpin{b};
-                matchy_scanner_t* sc = get_scanner();
-                if (sc) run_batch(sc, b, d, pin);
-                else { d.input = b.input; d.ok = false; }
-            }
-            std::lock_guard<std::mutex> lk(mu);
-            done.emplace(b.seq, std::move(d));
-            cv_done.notify_all();
+    static void* batch_hook(void* user, size_t, const matchy_scanner_t* sc, const matchy_scan_result_t* r, const uint8_t* data, size_t len, void* tag) {
+        MatchPipeline* pl = (MatchPipeline*)user;
+        Done* d = new Done();
+        pl->render(sc, *r, data, len, ((const Batch*)tag)->input, *d);
+        return d;
+    }
+    // scan one batch on the calling thread and render its matches (--follow: one scanner, batches as they appear)
+    void run_batch(matchy_scanner_t* sc, Batch& b, Done& d) {
+        d.input = b.input;
+        if (!b.len) return;
+        matchy_scan_result_t r;
+        memset(&r, 0, sizeof(r));
+        if (matchy_scanner_scan(sc, b.ptr, b.len, &r) != MATCHY_SUCCESS) {
+            fprintf(stderr, "[ERROR] scan failed: %s\n", matchy_amd_last_error());
+            d.ok = false;
+            return;
         }
+        render(sc, r, b.ptr, b.len, b.input, d);
+        matchy_scan_result_free(&r);
     }
-    // prints in sequence order until `closed` and everything submitted has been printed
+    // takes the batches back in sequence order and prints them, until the reader is done and nothing is pending
     void printer(Totals& total, std::vector<char>& input_failed) {
-        size_t next = 0;
         for (;;) {
-            Done d;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_done.wait(lk, [&] { return done.count(next) || (closed && next == submitted); });
-                if (!done.count(next)) return;
-                d = std::move(done[next]);
-                done.erase(next);
+            matchy_multi_batch_t b;
+            int32_t r = matchy_multi_scanner_next(ms, &b);
+            if (r == 0) {
+                if (!reader_done) { std::this_thread::sleep_for(std::chrono::microseconds(200)); continue; }   // between two submits
+                r = matchy_multi_scanner_next(ms, &b);
+                if (r == 0) return;
             }
-            ++next;
-            release_mappings(next);
-            if (!d.out.empty()) fwrite(d.out.data(), 1, d.out.size(), stdout);
-            total.lines += d.t.lines; total.lines_with_matches += d.t.lines_with_matches; total.matches += d.t.matches;
-            total.candidates += d.t.candidates; total.bytes += d.t.bytes;
-            if (!d.ok) input_failed[d.input] = 1;
+            if (r != 1) { fprintf(stderr, "[ERROR] gathering results failed: %s\n", matchy_amd_last_error()); return; }
+            Batch* hb = (Batch*)b.tag;
+            Done* d = (Done*)b.payload;
+            if (b.status != MATCHY_SUCCESS) {
+                fprintf(stderr, "[ERROR] scan failed: %s\n", matchy_amd_last_error());
+                input_failed[hb->input] = 1;
+            } else if (d) {
+                if (!d->out.empty()) fwrite(d->out.data(), 1, d->out.size(), stdout);
+                total.lines += d->t.lines; total.lines_with_matches += d->t.lines_with_matches; total.matches += d->t.matches;
+                total.candidates += d->t.candidates; total.bytes += d->t.bytes;
+            }
+            matchy_scan_result_free(&b.result);
+            delete d;
+            delete hb;   // frees an owned (read) batch's bytes; a mapped batch's pages go with its file's mapping
+            release_mappings(b.seq + 1);
         }
     }
 };
 
 // Inputs ending in .gz (case-insensitive) are decompressed on the fly like the reference's file reader does
 // (crates/matchy/src/file_reader.rs:45-75, by extension); "-" is stdin. Regular files are mapped and their batches are
-// views of the mapping (no copy on the host; each worker pre-faults its batch's pages). Returns false when
-// the input could not be read. Mappings go to `maps` and are released by the caller after the pipeline has drained.
+// views of the mapping (no copy on the host; this thread pre-faults and pins each batch's pages ahead of its scan;
+// MATCHY_AMD_NO_MMAP=1 reads them like a stream instead). Returns false when the input could not be read. Mappings are
+// released by the printer as their files complete.
 bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t batch_bytes) {
     const bool gz = ends_with_ci(path, ".gz");
     int fd = path == "-" ? 0 : open(path.c_str(), O_RDONLY);
     if (fd < 0) { fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), strerror(errno)); return false; }
     struct stat sb;
-    // Regular files are MAPPED by default (further down: batches are views of the mapping, the reader thread pins each batch's pages
-    // ahead of its scan). MATCHY_AMD_PREAD=1 opts into the alternative below, built and measured in round 3 (29 GB/s with four workers
-    // against 42-46 mapped): batches are byte ranges cut at newlines (the cuts are found by reading a few KiB around each nominal
-    // end) and the worker that takes a batch reads its range with pread into its own page-locked buffer — no page tables to build per
-    // batch or to tear down per file, but a kernel-side copy at ~10 GB/s per thread in front of every transfer.
-    if (!gz && fd != 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && getenv("MATCHY_AMD_PREAD") && !getenv("MATCHY_AMD_NO_MMAP")) {
-        const size_t size = (size_t)sb.st_size;
-        std::vector<uint8_t> probe(65536);
-        // offset just behind the last '\n' in [lo, hi), or (size_t)-1
-        auto last_newline = [&](size_t lo, size_t hi) -> size_t {
-            while (hi > lo) {
-                const size_t n = std::min(probe.size(), hi - lo);
-                const ssize_t r = pread(fd, probe.data(), n, (off_t)(hi - n));
-                if (r != (ssize_t)n) return (size_t)-1;
-                const void* nl = memrchr(probe.data(), '\n', n);
-                if (nl) return hi - n + (size_t)((const uint8_t*)nl - probe.data()) + 1;
-                hi -= n;
-            }
-            return (size_t)-1;
-        };
-        auto next_newline = [&](size_t lo) -> size_t {   // offset just behind the first '\n' at or after lo, or size
-            while (lo < size) {
-                const size_t n = std::min(probe.size(), size - lo);
-                const ssize_t r = pread(fd, probe.data(), n, (off_t)lo);
-                if (r != (ssize_t)n) return size;
-                const void* nl = memchr(probe.data(), '\n', n);
-                if (nl) return lo + (size_t)((const uint8_t*)nl - probe.data()) + 1;
-                lo += n;
-            }
-            return size;
-        };
-        { std::lock_guard<std::mutex> lk(pl.mu); pl.open_fds.push_back(fd); }
-        for (size_t pos = 0; pos < size;) {
-            size_t end = std::min(size, pos + batch_bytes);
-            if (end < size) {   // newline-aligned cut; a line longer than the batch extends it to that line's end
-                const size_t cut = last_newline(pos, end);
-                end = cut != (size_t)-1 ? cut : next_newline(end);
-            }
-            Batch b;
-            b.input = input; b.fd = fd; b.off = (off_t)pos; b.len = end - pos;
-            pl.submit(std::move(b));
-            pos = end;
-        }
-        return true;
-    }
     if (!gz && fd != 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && !getenv("MATCHY_AMD_NO_MMAP")) {
         const size_t size = (size_t)sb.st_size;
         void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -649,8 +549,7 @@ void follow_inputs(MatchPipeline& pl, matchy_scanner_t* sc, const std::vector<st
             any = true;
             b.ptr = b.own.data(); b.len = have;
             Done d;
-            PinnedBuf unused;   // follow batches are read into `own`
-            pl.run_batch(sc, b, d, unused);
+            pl.run_batch(sc, b, d);
             if (!d.out.empty()) {
                 // this batch's records carry the current time
                 char ts[48];
@@ -776,19 +675,22 @@ int cmd_match(int argc, char** argv) {
         std::string err;
         if (!parse_extractors(extractors, auto_mask, mask, err)) { fprintf(stderr, "Error: %s\n", err.c_str()); matchy_close(db); return 1; }
     }
-    // the first scanner now (it also serves --follow); the others are created by their worker threads when the first batch reaches
-    // them (a small input never pays for scanners it does not use)
-    std::vector<matchy_scanner_t*> scanners(devs.size(), nullptr);
-    scanners[0] = matchy_scanner_create(db, mask, devs[0]);
-    if (!scanners[0]) {
+    // The pipeline: one worker and scanner per device entry inside the library (the first scanner is created here and now, so a device
+    // that cannot be used fails the command; the others when the first batch reaches their workers — a small input never pays for
+    // scanners it does not use)
+    std::vector<int32_t> dev32(devs.begin(), devs.end());
+    matchy_multi_scanner_t* ms = matchy_multi_scanner_create(db, mask, dev32.data(), dev32.size());
+    if (!ms) {
         fprintf(stderr, "Error: Failed to create the GPU scanner on device %d: %s\n", devs[0], matchy_amd_last_error());
         matchy_close(db);
         return 1;
     }
-    if (trace) fprintf(stderr, "[matchy] first of %zu scanner(s) created after %.1f ms\n", scanners.size(), since0());
+    const size_t n_scanners = devs.size();
+    if (trace) fprintf(stderr, "[matchy] first of %zu scanner(s) created after %.1f ms\n", n_scanners, since0());
     MatchPipeline pl;
+    pl.ms = ms;
     pl.json = format == "json";
-    pl.max_q = scanners.size() + 1;
+    matchy_multi_scanner_set_batch_hook(ms, &MatchPipeline::batch_hook, &pl);
     std::vector<std::string> paths;
     bool stdin_seen = false;
     for (size_t i = 1; i < pos.size(); ++i) {
@@ -801,27 +703,21 @@ int cmd_match(int argc, char** argv) {
     }
     Totals t;
     std::vector<char> input_failed(paths.size(), 0);
-    std::vector<std::thread> workers;
-    for (size_t w = 0; w < scanners.size(); ++w)
-        workers.emplace_back([&pl, &scanners, &devs, db, mask, w] {
-            pl.worker([&]() -> matchy_scanner_t* {
-                if (!scanners[w]) scanners[w] = matchy_scanner_create(db, mask, devs[w]);
-                if (!scanners[w]) fprintf(stderr, "[ERROR] Failed to create the GPU scanner on device %d: %s\n", devs[w], matchy_amd_last_error());
-                return scanners[w];
-            });
-        });
+    std::vector<char> read_failed(paths.size(), 0);   // written by this thread only (input_failed belongs to the printer until it is joined)
     std::thread printer([&] { pl.printer(t, input_failed); });
     for (size_t i = 0; i < paths.size(); ++i)
-        if (!read_input(pl, i, paths[i], batch_bytes)) input_failed[i] = 1;
-    pl.close();
-    for (auto& w : workers) w.join();
-    pl.close();   // wake the printer once more now that every batch is in `done`
+        if (!read_input(pl, i, paths[i], batch_bytes)) read_failed[i] = 1;
+    pl.reader_done = true;
     printer.join();
+    for (size_t i = 0; i < paths.size(); ++i) if (read_failed[i]) input_failed[i] = 1;
     fflush(stdout);
     if (trace) fprintf(stderr, "[matchy] all batches done after %.1f ms\n", since0());
     pl.release_mappings((size_t)-1);
-    for (int fd : pl.open_fds) close(fd);
-    if (follow) follow_inputs(pl, scanners[0], paths, stats, t);
+    if (follow) {
+        matchy_scanner_t* fsc = matchy_scanner_create(db, mask, devs[0]);
+        if (!fsc) fprintf(stderr, "Error: Failed to create the GPU scanner on device %d: %s\n", devs[0], matchy_amd_last_error());
+        else { follow_inputs(pl, fsc, paths, stats, t); matchy_scanner_free(fsc); }
+    }
     size_t failed = 0;
     for (char f : input_failed) failed += f != 0;
     const size_t processed = paths.size() - failed;
@@ -842,10 +738,10 @@ int cmd_match(int argc, char** argv) {
         fprintf(stderr, "[INFO] Query rate: %.0f queries/s\n", secs > 0 ? (double)t.candidates / secs : 0.0);
         std::string dl;
         for (int d : devs) { if (!dl.empty()) dl += ","; dl += std::to_string(d); }
-        fprintf(stderr, "\n[INFO] === Devices ===\n[INFO] HIP devices: %s (%zu scanner%s, batches of %zu MiB)\n", dl.c_str(), scanners.size(),
-                scanners.size() == 1 ? "" : "s", batch_bytes >> 20);
+        fprintf(stderr, "\n[INFO] === Devices ===\n[INFO] HIP devices: %s (%zu scanner%s, batches of %zu MiB)\n", dl.c_str(), n_scanners,
+                n_scanners == 1 ? "" : "s", batch_bytes >> 20);
     }
-    for (auto* sc : scanners) if (sc) matchy_scanner_free(sc);
+    matchy_multi_scanner_free(ms);
     matchy_close(db);
     if (trace) fprintf(stderr, "[matchy] cleaned up after %.1f ms\n", since0());
     if (failed) { fprintf(stderr, "Error: %zu file(s) failed to process\n", failed); return 1; }

@@ -452,6 +452,65 @@ print("OK")
     assert "joining the side streams on the host" in p.stderr, p.stderr[-2000:]
 
 
+def test_multi_device_scanner_matches_the_single_scanner(M, oracle, tmp_path):
+    """matchy_multi_scanner_*: the reader -> per-device workers -> ordered gather behind the C ABI (processing/parallel.rs:494-505).
+    The same GPU listed three times: a buffer (merged result = the oracle's records with absolute offsets, for several piece sizes),
+    a file (batches in file order, offsets rebased by the batch's position) and a pipe."""
+    from tools import synth
+    cfg = synth.config("c4/10")
+    blob = synth.build_db(cfg)
+    db = M.Database(blob)
+    odb = oracle.Database(blob)
+    log = synth.make_log(cfg, 0, 60000)
+    want, _, st = odb.scan(log, want_json=False)
+    assert len(want) > 500
+    ms = M.MultiScanner(db, devices=(0, 0, 0))
+    assert ms.workers == 3
+    for bb in (0, 1 << 20, 300000, len(log) * 2):
+        r = ms.scan(log, batch_bytes=bb)
+        assert (r.lines, r.candidates) == (st.lines, st.candidates), bb
+        assert r.hits() == want, bb
+        r.close()
+    r = ms.scan(b"")
+    assert r.hits() == [] and r.lines == 0
+    r.close()
+    # a file: batches come back in file order whatever worker scanned them
+    path = tmp_path / "access.log"
+    path.write_bytes(log)
+    got, offsets = [], []
+
+    def on_batch(off, n, hits, lines, cands):
+        offsets.append((off, n))
+        for h in hits:
+            h = dict(h); h["start"] += off; h["end"] += off
+            got.append(h)
+
+    tot = ms.scan_file(str(path), batch_bytes=1 << 20, on_batch=on_batch)
+    assert offsets == sorted(offsets) and len(offsets) >= 8 and sum(n for _, n in offsets) == len(log)
+    assert all(log[o + n - 1:o + n] == b"\n" for o, n in offsets)
+    assert got == want
+    assert (tot["lines"], tot["candidates"], tot["matches"], tot["bytes"]) == (st.lines, st.candidates, len(want), len(log))
+    # a pipe (read, not mapped)
+    import threading
+    rd, wr = os.pipe()
+
+    def feed():
+        with os.fdopen(wr, "wb") as f:
+            f.write(log)
+
+    th = threading.Thread(target=feed)
+    th.start()
+    got.clear(); offsets.clear()
+    tot = ms.scan_file(f"/proc/self/fd/{rd}", batch_bytes=1 << 20, on_batch=on_batch)
+    th.join()
+    os.close(rd)
+    assert got == want and tot["lines"] == st.lines
+    # a missing file is an error, not an empty scan
+    with pytest.raises(RuntimeError):
+        ms.scan_file(str(tmp_path / "nope.log"))
+    ms.close(); db.close()
+
+
 def _long_domain_runs(seed, count=700):
     """Runs of 40..3000 domain characters: many labels, dashes beside dots at every alignment, empty labels, high bytes."""
     rng = random.Random(seed)

@@ -55,3 +55,27 @@ def test_xxh64_every_length_against_the_xxhash_module(tmp_path):
         n = int(n)
         assert int(h, 16) == xxhash.xxh64(data[:n], seed=0).intdigest(), n
         assert int(hf, 16) == xxhash.xxh64(lower(data[:n]), seed=0).intdigest(), n
+
+
+def test_numa_mapping_of_a_gpu_to_its_cpus(tmp_path):
+    """hipDeviceGetPCIBusId -> numa_node -> cpulist: the mapping the workers of the multi-device scanner and the ranks of bench.py
+    bind their threads with, over a made-up sysfs tree (no GPU, no HIP call)."""
+    import matchy_amd as M
+    root = tmp_path / "sys"
+    for bus, node in (("0000:c1:00.0", "1"), ("0000:05:00.0", "0"), ("0000:e9:00.0", "-1")):
+        d = root / "bus" / "pci" / "devices" / bus
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(node + "\n")
+    for node, cpus in ((0, "0-3,96-99\n"), (1, "48-50, 144,146-147\n")):
+        d = root / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus)
+    assert M.numa_cpus(str(root), "0000:05:00.0") == [0, 1, 2, 3, 96, 97, 98, 99]
+    assert M.numa_cpus(str(root), "0000:C1:00.0") == [48, 49, 50, 144, 146, 147]   # HIP prints the bus id in either case
+    assert M.numa_cpus(str(root), "0000:e9:00.0") == []    # the platform does not say: the thread is left alone
+    assert M.numa_cpus(str(root), "0000:77:00.0") == []    # unknown device
+    # malformed lists end where they stop making sense
+    (root / "devices" / "system" / "node" / "node0" / "cpulist").write_text("5-2,9\n")
+    assert M.numa_cpus(str(root), "0000:05:00.0") == []
+    (root / "devices" / "system" / "node" / "node0" / "cpulist").write_text("1,3-4,x\n")
+    assert M.numa_cpus(str(root), "0000:05:00.0") == [1, 3, 4]

@@ -10,7 +10,7 @@ if not os.path.exists("/tmp/c2.log"):
             f.write(synth.make_log(cfg, a, 1_000_000))
 open("/tmp/small.log", "wb").write(open("/tmp/c2.log", "rb").read(1_000_000))
 size = os.path.getsize("/tmp/c2.log")
-cli = "matchy_amd/bin/matchy"
+cli = os.environ.get("MATCHY_CLI", "matchy_amd/bin/matchy")
 def run(files, jobs):
     t = time.time()
     r = subprocess.run([cli, "match", "/tmp/c2.mxy"] + files + ["-j", jobs, "--batch-bytes", str(256 << 20), "--format", "summary", "-s"],
