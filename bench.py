@@ -200,6 +200,10 @@ def main():
                     "(default 100 M lines of --config c4 = BASELINE configs[3])")
     ap.add_argument("--batch-lines", type=int, default=10_000_000, help="strong scaling: lines per batch (a batch must stay below 2 GiB; the default is the weak line's batch)")
     ap.add_argument("--e2e-batches", type=int, default=4, help="strong scaling: batches per rank kept in pinned host memory for the end-to-end measurement")
+    ap.add_argument("--log-shape", default="nginx", choices=["nginx", "jsonl-app", "ip-dense", "url-heavy", "hash-dense", "skewed-halves"],
+                    help="shape of the synthetic log (tools/synthgen.cpp): nginx = the BASELINE workload; the others answer 'what does the number do on other "
+                         "input' (BASELINE.md §3). skewed-halves: the first half of every rank's block is prose with nothing to extract, the second half is ip-dense")
+    ap.add_argument("--no-scatter-gather", action="store_true", help="skip the one-process scatter / gather leg (matchy_multi_scanner over all GPUs of the job)")
     args = ap.parse_args()
     if args.scaling == "strong":
         if "--lines" not in " ".join(sys.argv):
@@ -256,6 +260,16 @@ def main():
     from matchy_amd import sharding
     from tools import synth
 
+    # This rank feeds its GPU from host memory (the upload of the batch, the end-to-end legs): it runs on the CPUs of the GPU's NUMA node —
+    # sched_setaffinity in this process (matchy_amd_bind_thread_to_device), never an exec — so that the pages it touches and pins are local
+    # to the socket the GPU hangs off (two-socket 8-GPU nodes: SURVEY §8e caveat).
+    numa = None
+    if not rehearse:
+        ML = M.lib()
+        cpus_before = len(os.sched_getaffinity(0))
+        numa = {"node": int(ML.matchy_amd_device_numa_node(local_rank)), "cpus_bound": int(ML.matchy_amd_bind_thread_to_device(local_rank)),
+                "cpus_before": cpus_before}
+
     cfg = synth.config(args.config)
     base_name = args.config.split("/")[0]
     cfg_index = {"c1": 0, "c2": 1, "c3": 2, "c3b": 2, "c4": 3, "c5": 4}[base_name]
@@ -269,13 +283,19 @@ def main():
         scanner.set_slices(args.slices)
 
     # ---- synthetic batch: this rank's line block, generated on the host, uploaded once
+    shape = args.log_shape
+    if shape != "nginx":
+        # other shapes have other line lengths: as many lines as keep the batch near the nginx batch's size and below the 2 GiB launch limit
+        probe = len(synth.make_log(cfg, 0, 5000, shape, 10000)) + len(synth.make_log(cfg, 5000, 5000, shape, 10000))
+        args.lines = min(args.lines, int(1.85e9 / (probe / 10000.0)))
+    shape_param = args.lines if shape == "skewed-halves" else 0   # period = the rank's block: first half sparse, second half dense
     first_line = sharding.block_for_rank(rank, world, args.lines).first_line
     cap = args.lines * 200 + (1 << 20)
     host = torch.empty(cap, dtype=torch.uint8)
-    nbytes = synth.make_log_into(cfg, first_line, args.lines, host.data_ptr(), cap)
+    nbytes = synth.make_log_into(cfg, first_line, args.lines, host.data_ptr(), cap, shape, shape_param)
     if nbytes > cap:
         host = torch.empty(nbytes, dtype=torch.uint8)
-        nbytes = synth.make_log_into(cfg, first_line, args.lines, host.data_ptr(), nbytes)
+        nbytes = synth.make_log_into(cfg, first_line, args.lines, host.data_ptr(), nbytes, shape, shape_param)
     if nbytes >= 0x7FFF0000:
         raise SystemExit("batch exceeds the 2 GiB single-launch limit; lower --lines")
     dlog = torch.empty(nbytes + 64, dtype=torch.uint8, device=dev)
@@ -472,6 +492,54 @@ def main():
                       "same_counts": bool(e2e_counts == (counts[0], counts[2]))}
         del pinned
 
+    # ---- one-process scatter / gather over every GPU of the job (north_star: line blocks sharded across the GPUs of one node by the
+    # host, no collective): rank 0 drives matchy_multi_scanner_* — one worker thread per device entry, each bound to its GPU's NUMA
+    # node — with ONE job of `world` blocks in pinned host memory, cut into newline-aligned 256 MiB batches that are handed out in
+    # sequence and gathered in sequence, results (canonical-order records) in host memory. value = job bytes / wall time of the
+    # best of three passes. The other ranks wait at the barrier (their GPUs are driven by rank 0's workers meanwhile). Every block
+    # is this rank's 10 M lines again: generating `world` different blocks would take longer than the driver's run, and the
+    # mechanics — H2D per device, scan, ordered gather — do not depend on the bytes.
+    scatter_gather = None
+    if not args.no_scatter_gather:
+        barrier()
+        if rank == 0:
+            import numpy as np
+            pinned = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            pinned.copy_(host[:nbytes])
+            hv = host[:nbytes].numpy()
+            cuts = [0]
+            step_b = 256 << 20
+            while cuts[-1] + step_b < nbytes:
+                want = cuts[-1] + step_b
+                back = np.flatnonzero(hv[want - (1 << 16):want] == 10)
+                cuts.append(want - (1 << 16) + int(back[-1]) + 1 if len(back) else want)
+            cuts.append(nbytes)
+            pieces = [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
+            devs = ([0] * world if rehearse else list(range(world))) * 2   # two scanners per GPU: one copies while the other post-processes
+            ms = M.MultiScanner(db, devices=devs, extract_flags=args.extract_flags)
+            times, sg_counts = [], None
+            for rep in range(4):
+                tsg = time.perf_counter()
+                tl = tc = th = 0
+                n_sub = 0
+                for blk in range(world):
+                    for off, n in pieces:
+                        ms.submit_ptr(pinned.data_ptr() + off, n, tag=blk)
+                        n_sub += 1
+                for _ in range(n_sub):
+                    b = ms.next()
+                    tl += b["lines"]; tc += b["candidates"]; th += b["n_hits"]
+                times.append(time.perf_counter() - tsg)
+                sg_counts = (tl, tc, th)
+            ms.close()
+            best = min(times[1:])
+            scatter_gather = {"value": round(world * nbytes / best / 1e9, 2), "unit": "GB/s", "ms": round(best * 1e3, 2), "job_bytes": world * nbytes,
+                              "devices": devs, "batches": len(pieces) * world,
+                              "entry": "matchy_multi_scanner_submit / _next: one process, pinned host memory -> per-device H2D -> scan -> records gathered in submission order",
+                              "same_counts": bool(sg_counts == (world * counts[0], world * counts[1], world * counts[2]))}
+            del pinned
+        barrier()
+
     cpu = None
     cpu_t1 = None
     parity = None
@@ -489,7 +557,8 @@ def main():
         odb = oracle.Database(blob)
         cores = min(len(os.sched_getaffinity(0)), 16)  # GPU box share: 16 host cores per GPU
         ohits, _, st = odb.scan(sample, threads=cores, cache=10000, want_json=False)
-        cpu = {"value": round(len(sample) / st.seconds / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
+        cpu = {"value": round(len(sample) / st.seconds / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port", "host_cpus": os.cpu_count(),
+               "affinity_cpus": len(os.sched_getaffinity(0)),
                "sample": f"first {n_cpu_lines} lines ({len(sample)} B) of the same log, {cores} threads, 256 KiB newline-aligned chunks, LRU 10000",
                "lines_per_s": round(st.lines / st.seconds, 1)}
         # the same path on ONE core (T = all cores and T = 1), on a tenth of the sample
@@ -526,7 +595,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{cfg_index}]{cfg_note}: {cfg.n_ip + cfg.n_cidr + cfg.n_dom + cfg.n_hash + cfg.n_glob} mixed IoCs "
                                    f"({cfg.n_ip} IPv4 + {cfg.n_cidr} CIDR + {cfg.n_dom} domains + {cfg.n_hash} hashes + {cfg.n_glob} globs), "
-                                   f"{args.lines} nginx-style lines per GPU",
+                                   f"{args.lines} {'nginx-style' if shape == 'nginx' else shape + '-shaped'} lines per GPU",
+                       "log_shape": shape,
                        "lines_per_gpu": args.lines, "bytes_per_gpu": nbytes, "sharding": "line-block per GPU, DB replicated, no collective"},
             "lines_per_s": round(total_lines / (elapsed / args.steps), 1),
             "candidates_per_step": agg["candidates"],
@@ -537,7 +607,7 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "kernel_ms_note": "HIP-event intervals on the scan's stream: k_anchor alone (it also looks the sparse IPv4 candidates up), then everything "
                               "behind it as one interval (k_validate_dom -> k_lookup on the scan's stream; tokens / IPv6 / e-mail, the undecided domains "
-                              "and k_rare with their own lookups on three side streams); per-kernel durations: profiles/r03_bench_c2_summary.txt, r03_step_timeline.txt",
+                              "and k_rare with their own lookups on three side streams); per-kernel durations: profiles/r04_bench_c2_summary.txt, r04_step_timeline.txt",
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "peak_measured": peak_measured, "peak_measured_note": "device-to-device copy of 1 GiB in this run, read + write bytes / time",
                          "traffic": traffic, "kernel": dom_name, "algorithmic_bytes_per_launch": nbytes, "traffic_source": tr_note},
@@ -546,6 +616,8 @@ def main():
             "cpu_baseline": cpu,
             "cpu_baseline_t1": cpu_t1,
             "end_to_end": end_to_end,
+            "scatter_gather": scatter_gather,
+            "numa": numa,
             "device_results": device_results,
             "pipelined": pipelined,
             "parity_vs_oracle": parity,

@@ -582,6 +582,28 @@ class MultiScanner:
             raise RuntimeError(f"matchy_multi_scanner_scan failed ({rc}): " + last_error())
         return ScanResult(_WorkerScanner(lib().matchy_multi_scanner_worker_scanner(self._h, 0)), raw)
 
+    def submit_ptr(self, host_ptr: int, nbytes: int, tag: int = 0):
+        """queue one newline-aligned batch that lives at a host address (e.g. a pinned torch tensor); take it back with next()"""
+        rc = lib().matchy_multi_scanner_submit(self._h, host_ptr, nbytes, tag, None)
+        if rc != 0:
+            raise RuntimeError(f"matchy_multi_scanner_submit failed ({rc}): " + last_error())
+
+    def next(self, want_hits=False):
+        """the next batch in submission order: dict(seq, tag, worker, lines, candidates, n_hits[, hits]) or None when nothing is pending"""
+        b = _MultiBatch()
+        rc = lib().matchy_multi_scanner_next(self._h, C.byref(b))
+        if rc == 0:
+            return None
+        if rc != 1 or b.status != 0:
+            raise RuntimeError(f"matchy_multi_scanner_next failed ({rc}, batch status {b.status}): " + last_error())
+        out = dict(seq=b.seq, tag=int(b.tag or 0), worker=b.worker, lines=int(b.result.lines), candidates=int(b.result.candidates),
+                   n_hits=int(b.result.n_hits + b.result.n_ip4_hits), nbytes=int(b.len))
+        r = ScanResult(_WorkerScanner(lib().matchy_multi_scanner_worker_scanner(self._h, b.worker)), b.result)
+        if want_hits:
+            out["hits"] = r.hits()
+        r.close()
+        return out
+
     def scan_file(self, path: str, batch_bytes: int = 0, on_batch=None):
         """scan one file (or "-"); on_batch(offset, nbytes, hits, lines, candidates) is called per batch in file order. Returns the totals."""
         L = lib()

@@ -95,31 +95,72 @@ struct ChunkWriter {
     }
 };
 
+// What an unused slot of a reserved chunk holds: every consumer of these lists skips it (Candidate: len_type 0xFFFFFFFF; anchors:
+// kind 0xFF; work-list indices: 0xFFFFFFFF).
+template <class T> __device__ __forceinline__ T list_sentinel();
+template <> __device__ __forceinline__ Candidate list_sentinel<Candidate>() { return Candidate{0u, 0xFFFFFFFFu, 0u, 0u}; }
+template <> __device__ __forceinline__ RareAnchor list_sentinel<RareAnchor>() { return RareAnchor{0xFFFFFFFFu, 0xFFu}; }
+template <> __device__ __forceinline__ uint32_t list_sentinel<uint32_t>() { return 0xFFFFFFFFu; }
+template <> __device__ __forceinline__ uint2 list_sentinel<uint2>() { return make_uint2(0xFFFFFFFFu, 0xFFu); }
+
 // Writer for the sparse lists (rare anchors, long tokens, heavy tokens, prefiltered candidates): entries collect in a 64-slot LDS buffer of the wave
 // and leave together — one atomic per flush for exactly the entries there are, so these lists carry no per-wave padding
 // (with ~10 000 producer waves a 64-slot chunk per wave was mostly padding, which the consumers dragged through their
 // loops) and appends that carry one or two entries do not pay an atomic round trip each.
+// ... WHILE THEY ARE SPARSE. On input of another shape the same list is dense (two file hashes per log line: 18 M tokens, every one a
+// candidate), and one returning atomic per 64 entries from thousands of waves on ONE counter — atomics on one line are served one after
+// the other, ~12 ns each — was the whole kernel (278 K atomics = 3.3 of k_validate's 3.6 ms, profiles/r04_log_shapes.txt). So the
+// reservation grows with the wave's own history: its first four flushes reserve what they carry, the next twelve a chunk of 256 slots,
+// later ones a chunk of 2048 that the following flushes fill without an atomic; what a wave leaves unused of its last chunk is set to
+// list_sentinel<T>() by flush() — the call at the end of a wave's work.
 template <class T, uint32_t CAP = 64>
 struct BufferedWriter {
     T* buf;              // CAP entries of LDS owned by this wave
     uint32_t cnt = 0;    // wave-uniform
     uint32_t total = 0;  // entries appended by this wave
+    uint32_t base = 0xFFFFFFFFu, used = 0, ccap = 0, flushes = 0;   // the wave's current chunk (wave-uniform)
     __device__ __forceinline__ explicit BufferedWriter(T* lds) : buf(lds) {}
+    __device__ __forceinline__ void pad_rest(T* out, uint32_t cap) {
+        if (base == 0xFFFFFFFFu) return;
+        for (uint32_t k = used + lane_id(); k < ccap; k += 64) if (base + k < cap) out[base + k] = list_sentinel<T>();
+        used = ccap;
+    }
+    // slots for n entries: from the current chunk, or from a new reservation; returns the first slot
+    __device__ __forceinline__ uint32_t reserve(uint32_t n, T* out, uint32_t cap, uint32_t* counter) {
+        if (base == 0xFFFFFFFFu || used + n > ccap) {
+            pad_rest(out, cap);
+            const uint32_t chunk = flushes < 4 ? n : (flushes < 16 ? 256u : 2048u);
+            ccap = chunk < n ? n : chunk;
+            uint32_t b = 0;
+            if (lane_id() == 0) b = atomicAdd(counter, ccap);
+            base = __builtin_amdgcn_readfirstlane(b);
+            used = 0;
+        }
+        ++flushes;
+        const uint32_t at = base + used;
+        used += n;
+        return at;
+    }
+    // the staged entries leave (called by append when the stage is full)
+    template <class F>
+    __device__ __forceinline__ void drain_then(T* out, uint32_t cap, uint32_t* counter, F&& after) {
+        if (cnt == 0) return;
+        const uint32_t b = reserve(cnt, out, cap, counter);
+        __builtin_amdgcn_wave_barrier();
+        if (lane_id() < cnt && b + lane_id() < cap) out[b + lane_id()] = buf[lane_id()];
+        after(b, cnt);
+        __builtin_amdgcn_wave_barrier();
+        cnt = 0;
+    }
+    // END of the wave's work on this list: staged entries out, the unused rest of its last chunk marked
     __device__ __forceinline__ void flush(T* out, uint32_t cap, uint32_t* counter) {
         flush_then(out, cap, counter, [](uint32_t, uint32_t) {});
     }
     // `after(b, n)` is called by the whole wave once the n staged entries have been written to out[b, b + n) (they are still in buf)
     template <class F>
     __device__ __forceinline__ void flush_then(T* out, uint32_t cap, uint32_t* counter, F&& after) {
-        if (cnt == 0) return;
-        uint32_t b = 0;
-        if (lane_id() == 0) b = atomicAdd(counter, cnt);
-        b = __builtin_amdgcn_readfirstlane(b);
-        __builtin_amdgcn_wave_barrier();
-        if (lane_id() < cnt && b + lane_id() < cap) out[b + lane_id()] = buf[lane_id()];
-        after(b, cnt);
-        __builtin_amdgcn_wave_barrier();
-        cnt = 0;
+        drain_then(out, cap, counter, after);
+        pad_rest(out, cap);
     }
     // all lanes of the (converged) wave call this
     __device__ __forceinline__ void append(bool emit, const T& v, T* out, uint32_t cap, uint32_t* counter) {
@@ -128,15 +169,13 @@ struct BufferedWriter {
         const uint32_t n = (uint32_t)__popcll(m);
         const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
         if (CAP < 64 && n > CAP) {
-            // more entries than the staging buffer holds (dense phases): they leave directly, one atomic for all of them
-            uint32_t b = 0;
-            if (lane_id() == 0) b = atomicAdd(counter, n);
-            b = __builtin_amdgcn_readfirstlane(b);
+            // more entries than the staging buffer holds (dense phases): they leave directly, through the same chunks
+            const uint32_t b = reserve(n, out, cap, counter);
             if (emit && b + rank < cap) out[b + rank] = v;
             total += n;
             return;
         }
-        if (cnt + n > CAP) flush(out, cap, counter);
+        if (cnt + n > CAP) drain_then(out, cap, counter, [](uint32_t, uint32_t) {});
         if (emit) buf[cnt + rank] = v;
         cnt += n;
         total += n;
@@ -149,7 +188,7 @@ struct BufferedWriter {
         if (m == 0) return;
         const uint32_t n = (uint32_t)__popcll(m);
         const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
-        if (cnt + n > CAP) flush_then(out, cap, counter, after);
+        if (cnt + n > CAP) drain_then(out, cap, counter, after);
         if (emit) buf[cnt + rank] = v;
         cnt += n;
         total += n;

@@ -578,6 +578,15 @@ void grid_multipliers(bool filter_ac, int (&gm)[3]) {
 }
 }  // namespace
 
+// workgroups for a list kernel: the default while the previous scan's list was short, else one workgroup per `per_wg` entries of it,
+// at most max_per_cu per CU (workgroups beyond the end of a list leave at once)
+int Scanner::grid_for(uint32_t n_hint, uint32_t per_wg, int dflt, int max_per_cu) const {
+    static const bool fixed = getenv("MATCHY_AMD_FIXED_GRIDS") != nullptr;
+    if (fixed) return dflt;
+    const uint64_t want = ((uint64_t)n_hint + per_wg - 1) / per_wg;
+    return (int)std::max<uint64_t>((uint64_t)dflt, std::min<uint64_t>(want, (uint64_t)n_cu_ * (uint64_t)max_per_cu));
+}
+
 // Kernel parameters of slice `sl` for the byte range [lo, hi) of the batch (hi = len + 1 for the range that ends the batch).
 // The lists and counters are the slice's own; the final record arrays (and the counters that hand out their slots: slice 0's)
 // are shared by all slices.
@@ -890,13 +899,13 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         if (rare_own) {
             TokParams tt = t1;
             tt.vmode = 4u;
-            launch_validate_misc(tt, view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);   // 6 KB of LDS, workgroups beyond the list leave at once
+            launch_validate_misc(tt, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_tok, 1024, std::max(1, n_cu_ / 2), 8), aux2_stream_);   // 6 KB of LDS, workgroups beyond the list leave at once
             if (!ev_v1_) MXY_HIP(hipEventCreateWithFlags(&ev_v1_, hipEventDisableTiming));
             MXY_HIP(hipEventRecord(ev_v1_, aux2_stream_));
             t1.vmode = 1u;
         }
-        // beside k_validate_dom: half the CUs, so that kernel keeps most of its resident waves
-        launch_validate_misc(t1, view, misc_wgs > 0 ? misc_wgs : std::max(1, n_cu_ / 2), aux2_stream_);
+        // beside k_validate_dom: half the CUs, so that kernel keeps most of its resident waves (more when the previous batch's lists were long)
+        launch_validate_misc(t1, view, misc_wgs > 0 ? misc_wgs : grid_for(rare_own ? hint_.n_rare : std::max(hint_.n_rare, hint_.n_tok), 1024, std::max(1, n_cu_ / 2), 8), aux2_stream_);
         // Split lists: the side chains do not join the scan's stream through events — the last kernel of each (a k_lookup launch) reports
         // its end in ScanCounters::chains_done, which k_finish polls (arrive_chain 1: third stream, 2: k_rare's, 3: the fourth stream)
         static const bool env_join = getenv("MATCHY_AMD_EVENT_JOIN") != nullptr;
@@ -905,7 +914,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         if (L.split_misc) {
             LookupParams lm = L.lm;
             if (arrive && (rare_own || !rare_possible)) { lm.arrive_chain = 1; lm.arrive = counters_.p; ++chains; }
-            launch_lookup(lm, view, std::max(1, n_cu_ / 2), aux2_stream_);
+            launch_lookup(lm, view, grid_for(hint_.n_cand_m, 512, std::max(1, n_cu_ / 2), 4), aux2_stream_);
         }
         if (rare_possible) {   // one wave per SIMD (297 VGPRs)
             TokParams tr = t1;
@@ -913,11 +922,11 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
             if (L.split_misc) { tr.cands = work_[0].cands_r.p; tr.cand_cap = (uint32_t)work_[0].cands_r.n; tr.n_cand = &counters_.p->n_cand_r; }
             hipStream_t rs = rare_own ? aux_stream_ : aux2_stream_;
             if (rare_own) MXY_HIP(hipStreamWaitEvent(aux_stream_, ev_v1_, 0));
-            launch_rare(tr, view, n_cu_ * 4, rs);
+            launch_rare(tr, view, grid_for(hint_.n_heavy, 128, n_cu_ * 4, 16), rs);
             if (L.split_misc) {
                 LookupParams lr = L.lr;
                 if (arrive) { lr.arrive_chain = rare_own ? 2u : 1u; lr.arrive = counters_.p; ++chains; }
-                launch_lookup(lr, view, std::max(1, n_cu_ / 8), rs);
+                launch_lookup(lr, view, grid_for(hint_.n_cand_r, 512, std::max(1, n_cu_ / 8), 4), rs);
             }
             if (rare_own && !arrive) MXY_HIP(hipEventRecord(ev_join_, aux_stream_));
         }
@@ -944,7 +953,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
                 // one workgroup per CU: every workgroup ends with a pair of returning atomics on the two record counters, and with 512
                 // of them those queue up behind each other (64 / 128 / 192 / 256 / 512 workgroups: tail 0.236 / 0.218 / 0.217 / 0.218 / 0.227 ms;
                 // not fewer than one per CU: a database that most names hit makes this the kernel with the work)
-                launch_lookup(lpm, view, lp_wgs > 0 ? lp_wgs : n_cu_, dom_stream_);
+                launch_lookup(lpm, view, lp_wgs > 0 ? lp_wgs : grid_for(hint_.n_cand, 512, n_cu_, 4), dom_stream_);
             }
             if (arrive) expect_chains_ = chains;
             else {
@@ -953,8 +962,8 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
                 MXY_HIP(hipEventRecord(ev_join3_, dom_stream_));
             }
             t2.cands = work_[0].cands_d.p; t2.cand_cap = (uint32_t)work_[0].cands_d.n; t2.n_cand = &counters_.p->n_cand_d;
-            launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
-            launch_lookup(L.ld, view, std::max(1, n_cu_ / 8), stream);
+            launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_rare_dom, 512, n_cu_, 8), stream);
+            launch_lookup(L.ld, view, grid_for(hint_.n_cand_d, 512, std::max(1, n_cu_ / 8), 4), stream);
         } else {
             if (early_glob_) {
                 // Databases with globs keep one candidate list, but the candidates k_validate_dom flags for the glob pass — most of that
@@ -986,24 +995,24 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
                 if (glob_v2_aside_) {
                     MXY_HIP(hipStreamWaitEvent(aux_stream_, ev_dom_, 0));
                     t2.cands = work_[0].cands_d.p; t2.cand_cap = (uint32_t)work_[0].cands_d.n; t2.n_cand = &counters_.p->n_cand_d;
-                    launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, aux_stream_);
+                    launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_rare_dom, 512, n_cu_, 8), aux_stream_);
                     LookupParams ld = L.ld;
                     if (!env_join_g) { ld.arrive_chain = 2; ld.arrive = counters_.p; ++chains; }
-                    launch_lookup(ld, view, std::max(2, n_cu_ / 8), aux_stream_);
+                    launch_lookup(ld, view, grid_for(hint_.n_cand_d, 512, std::max(2, n_cu_ / 8), 4), aux_stream_);
                     if (env_join_g) MXY_HIP(hipEventRecord(ev_join_, aux_stream_));
                 }
                 expect_chains_ = chains;
             }
-            if (!(early_glob_ && glob_v2_aside_)) launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);
+            if (!(early_glob_ && glob_v2_aside_)) launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_rare_dom, 512, n_cu_, 8), stream);
             // no timing events inside the forked tail: every packet between two kernels of the chain is ~6-8 us of it, and with
             // kernels running side by side the intervals would not be kernel times anyway (ScanTiming: validate_ms = the whole tail)
             MXY_HIP(hipStreamWaitEvent(stream, ev_join2_, 0));
         }
     } else {
         launch_validate_dom(tp, view, n_cu_ * L.gm[1], stream);
-        launch_validate_misc(tp, view, misc_wgs > 0 ? misc_wgs : n_cu_, stream);   // vmode 3: every list
+        launch_validate_misc(tp, view, misc_wgs > 0 ? misc_wgs : grid_for(std::max(std::max(hint_.n_tok, hint_.n_rare), hint_.n_rare_dom), 1024, n_cu_, 8), stream);   // vmode 3: every list
         if (profile_) MXY_HIP(hipEventRecord(ev_[2], stream));
-        if (rare_possible) launch_rare(tp, view, n_cu_ * 4, stream);
+        if (rare_possible) launch_rare(tp, view, grid_for(hint_.n_heavy, 128, n_cu_ * 4, 16), stream);
         if (profile_) MXY_HIP(hipEventRecord(ev_[3], stream));
     }
     if (lookup) {
@@ -1146,6 +1155,16 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
         }
         if (compact_ && c.n_c4 > c4_.n) c4_.alloc(grown(c.n_c4));
         scan_device(last_ptr_, last_len_, last_lookup_, stream, last_mirror_, last_fork_, last_slices_, last_compact_);
+    }
+    {
+        ListHint hh;
+        for (int k = 0; k < ns; ++k) {
+            const ScanCounters& q = host_slices_[k];
+            hh.n_tok = std::max(hh.n_tok, q.n_tok); hh.n_rare = std::max(hh.n_rare, q.n_rare); hh.n_rare_dom = std::max(hh.n_rare_dom, q.n_rare_dom);
+            hh.n_heavy = std::max(hh.n_heavy, q.n_heavy); hh.n_cand = std::max(hh.n_cand, q.n_cand); hh.n_cand_m = std::max(hh.n_cand_m, q.n_cand_m);
+            hh.n_cand_r = std::max(hh.n_cand_r, q.n_cand_r); hh.n_cand_d = std::max(hh.n_cand_d, q.n_cand_d);
+        }
+        hint_ = hh;
     }
     const ScanCounters& c = host_counters_;
     if (c.error & 1) throw HipError{"scan: a candidate matches more than 65535 glob patterns (the hit record counts pattern ids in 16 bits)"};

@@ -213,6 +213,12 @@ private:
     bool glob_join3_ = false, glob_v2_aside_ = false;   // early glob pass joined by event (MATCHY_AMD_EVENT_JOIN); k_validate<2> and its lookups on the second stream
     bool early_glob_ = false;       // last scan_device: the glob pass over k_validate_dom's flagged candidates runs beside the lean pass
     uint32_t expect_chains_ = 0;    // side-stream chains of the last scan_device that report their end to k_finish (0: event joins)
+    // List sizes of the PREVIOUS scan of this scanner (fetch): the grids of the kernels behind the streaming pass are sized for the
+    // sparse lists of a web-server log — half a workgroup per CU for the long tokens, an eighth for some lookups — and a log of another
+    // shape (two file hashes per line: 18 M tokens) walked such a list with 500 iterations per lane. Batches of one input look alike,
+    // so the next scan's grids follow the last scan's counts (grid_for); the first scan of a scanner runs with the defaults.
+    struct ListHint { uint32_t n_tok = 0, n_rare = 0, n_rare_dom = 0, n_heavy = 0, n_cand = 0, n_cand_m = 0, n_cand_r = 0, n_cand_d = 0; } hint_;
+    int grid_for(uint32_t n_hint, uint32_t per_wg, int dflt, int max_per_cu) const;
     bool counters_clean_ = false;   // the device counter blocks are zero (k_finish of the last fetch left them so)
     int last_slices_ = 0;
     std::shared_ptr<const DbImage> img_;

@@ -127,30 +127,71 @@ __device__ __forceinline__ ColdDb cold_db() {   // k_anchor(TokParams, DevDb): t
     return (ColdDb)((const char __attribute__((address_space(4)))*)q + sizeof(TokParams));
 }
 
-// BufferedWriter (device_common.h) for k_anchor's two sparse lists, with the destination (list, capacity, counter) fetched from
-// the kernel arguments when a flush happens instead of being passed — and kept in scalar registers — at every append.
-// WHICH: 0 = rare anchors (IPv6 / e-mail), 1 = long tokens.
+// Writer for k_anchor's two sparse lists (WHICH: 0 = rare anchors: IPv6 / e-mail, 1 = long tokens), with the destination (list,
+// capacity, counter) fetched from the kernel arguments when a flush happens instead of being passed — and kept in scalar registers — at
+// every append. Entries collect in a small LDS stage of the wave and leave together.
+// SPARSE OR DENSE. In a web-server log a wave meets a handful of these anchors and every flush reserves exactly its entries with one
+// atomic: a list without padding. In an endpoint log with two file hashes per line, or an application log with a trace id per line, the
+// same scheme is one returning atomic per seven entries from each of 4096 waves on ONE counter — atomics on one line are served one
+// after the other, ~12 ns each: 2.2 M of them were 27 of the kernel's 28 ms on the hash-dense shape (profiles/r04_log_shapes.txt). So the
+// reservation grows with the wave's own history: the first two flushes reserve what they carry, the next six a chunk of 64 slots, every
+// later one a chunk of 512 that the following flushes fill without an atomic; what a wave leaves unused of its last chunk is marked with
+// the sentinel every consumer of these lists skips (kind 0xFF). The chunk state lives in the stage's last slot (LDS, read at a flush),
+// not in scalar registers.
+constexpr uint32_t SPARSE_STAGE = RARE_STAGE - 1;   // entries per flush; slot RARE_STAGE - 1 holds {chunk base, used | capacity << 12 | flushes << 24}
 template <int WHICH>
 struct SparseWriter {
-    uint2* buf;          // RARE_STAGE entries of LDS owned by this wave
+    uint2* buf;          // RARE_STAGE slots of LDS owned by this wave
     uint32_t cnt = 0;    // wave-uniform
-    __device__ __forceinline__ explicit SparseWriter(uint2* lds) : buf(lds) {}
+    __device__ __forceinline__ explicit SparseWriter(uint2* lds) : buf(lds) {
+        if (lane_id() == 0) buf[SPARSE_STAGE] = make_uint2(0xFFFFFFFFu, 0u);
+    }
     struct Dest { uint2* out; uint32_t cap; uint32_t* counter; };
     __device__ __forceinline__ static Dest dest() {
         const ColdTok kp = cold_tok();
         if (WHICH == 0) return Dest{reinterpret_cast<uint2*>(kp->rare), kp->rare_cap, &kp->counters->n_rare};
         return Dest{reinterpret_cast<uint2*>(kp->tok), kp->tok_cap, &kp->counters->n_tok};
     }
+    // slots for n entries (n <= 64): from the wave's current chunk, or from a new reservation; returns the first slot
+    __device__ __forceinline__ uint32_t reserve(const Dest& d, uint32_t n) {
+        __builtin_amdgcn_wave_barrier();
+        const uint2 st = buf[SPARSE_STAGE];
+        uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.x);
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.y);
+        uint32_t used = w & 0xFFFu, cap = (w >> 12) & 0xFFFu, flushes = w >> 24;
+        if (base == 0xFFFFFFFFu || used + n > cap) {
+            // the rest of the old chunk stays unused: sentinels
+            if (base != 0xFFFFFFFFu) for (uint32_t k = used + lane_id(); k < cap; k += 64) if (base + k < d.cap) d.out[base + k] = make_uint2(0xFFFFFFFFu, 0xFFu);
+            const uint32_t chunk = flushes < 2 ? n : (flushes < 8 ? 64u : 512u);
+            cap = chunk < n ? n : chunk;
+            uint32_t b = 0;
+            if (lane_id() == 0) b = atomicAdd(d.counter, cap);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            used = 0;
+        }
+        if (flushes < 255) ++flushes;
+        __builtin_amdgcn_wave_barrier();
+        if (lane_id() == 0) buf[SPARSE_STAGE] = make_uint2(base, (used + n) | (cap << 12) | (flushes << 24));
+        __builtin_amdgcn_wave_barrier();
+        return base + used;
+    }
     __device__ __forceinline__ void flush() {
         if (cnt == 0) return;
         const Dest d = dest();
-        uint32_t b = 0;
-        if (lane_id() == 0) b = atomicAdd(d.counter, cnt);
-        b = __builtin_amdgcn_readfirstlane(b);
-        __builtin_amdgcn_wave_barrier();
+        const uint32_t b = reserve(d, cnt);
         if (lane_id() < cnt && b + lane_id() < d.cap) d.out[b + lane_id()] = buf[lane_id()];
         __builtin_amdgcn_wave_barrier();
         cnt = 0;
+    }
+    // end of the wave's work: staged entries out, the unused rest of the last chunk marked
+    __device__ __forceinline__ void finish() {
+        flush();
+        __builtin_amdgcn_wave_barrier();
+        const uint2 st = buf[SPARSE_STAGE];
+        const uint32_t base = st.x, used = st.y & 0xFFFu, cap = (st.y >> 12) & 0xFFFu;
+        if (base == 0xFFFFFFFFu || used >= cap) return;
+        const Dest d = dest();
+        for (uint32_t k = used + lane_id(); k < cap; k += 64) if (base + k < d.cap) d.out[base + k] = make_uint2(0xFFFFFFFFu, 0xFFu);
     }
     // all lanes of the (converged) wave call this
     __device__ __forceinline__ void append(bool emit, const uint2& v) {
@@ -158,15 +199,13 @@ struct SparseWriter {
         if (m == 0) return;
         const uint32_t n = (uint32_t)__popcll(m);
         const uint32_t rank = mbcnt64(m);
-        if (n > RARE_STAGE) {   // more entries than the stage holds (dense phases): they leave directly, one atomic for all of them
+        if (n > SPARSE_STAGE) {   // more entries than the stage holds (dense phases): they leave directly, through the same chunks
             const Dest d = dest();
-            uint32_t b = 0;
-            if (lane_id() == 0) b = atomicAdd(d.counter, n);
-            b = __builtin_amdgcn_readfirstlane(b);
+            const uint32_t b = reserve(d, n);
             if (emit && b + rank < d.cap) d.out[b + rank] = v;
             return;
         }
-        if (cnt + n > RARE_STAGE) flush();
+        if (cnt + n > SPARSE_STAGE) flush();
         if (emit) buf[cnt + rank] = v;
         cnt += n;
     }
@@ -810,8 +849,8 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     }
     commit_v4<INL>(pend, cx, cw_cand, vl);
     if constexpr (INL) v4_lookup_flush(vl);
-    cw_misc.flush();
-    cw_tok.flush();
+    cw_misc.finish();
+    cw_tok.finish();
     // mark the unused tail of every open chunk
     cw_dom.pad_rest(p.dom_list, p.dom_cap);
     cw_cand.finish(p.cands_a, p.cand_a_cap, &p.counters->n_cand_a, Candidate{0u, 0xFFFFFFFFu, 0u, 0u});
