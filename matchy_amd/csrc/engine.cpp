@@ -307,14 +307,15 @@ void DeviceDb::upload(const DbImage& img, int dev) {
             while (bits < live * 64 && bits < ((size_t)1 << 31)) bits <<= 1;
             std::vector<uint32_t> bm(bits / 32, 0u);
             const uint32_t bmask = (uint32_t)(bits - 1);
-            // only names of <= 31 bytes are ever tested against the bitmap (k_validate_dom decides names that fit its
-            // 32-byte context; longer ones take the general path, which lists every valid name)
+            // names of <= 31 bytes are tested whole (k_validate_dom decides names that fit its 32-byte context; longer ones take
+            // the general path, which lists every valid name); keys of 32 bytes and more — file hashes — enter with their first 32
+            // bytes and their length (k_validate tests every hex token of a hash length that way before it lists it)
             for (const LitSlot& sl : slots) {
                 if (sl.str_off == 0xFFFFFFFFu || (size_t)sl.str_off + 2 > pv.size()) continue;
                 const size_t kl = (size_t)pv[sl.str_off] | ((size_t)pv[sl.str_off + 1] << 8);
-                if (kl > 31 || (size_t)sl.str_off + 2 + kl > pv.size()) continue;
+                if ((size_t)sl.str_off + 2 + kl > pv.size()) continue;
                 uint64_t lane[4] = {0, 0, 0, 0};
-                memcpy(lane, pv.data() + sl.str_off + 2, kl);
+                memcpy(lane, pv.data() + sl.str_off + 2, std::min<size_t>(kl, 32));
                 const uint32_t b = name_hash31(lane[0], lane[1], lane[2], lane[3], (uint32_t)kl) & bmask;
                 bm[b >> 5] |= 1u << (b & 31);
             }

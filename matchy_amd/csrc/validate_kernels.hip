@@ -1018,6 +1018,11 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     __shared__ RareAnchor wb_heavy[4][64];
     BufferedWriter<RareAnchor> hw(wb_heavy[threadIdx.x >> 6]);
     const uint32_t nt = TOK ? min(p.counters->n_tok, p.tok_cap) : 0u;
+    uint32_t unlisted_tok = 0;   // valid hashes this lane did not list: no literal key can be them (lit_bm)
+    // a hash can only hit through the literal table when the database has no glob section (with one, a substring literal or a glob may
+    // match it: every valid hash is listed); DevDb::lit_bm then also holds the keys of 32 bytes and more, hashed from their first 32
+    // bytes and their length
+    const bool tok_filter = p.filter_lit && !db.has_glob && db.lit_bm != nullptr;
     for (uint32_t base = blockIdx.x * blockDim.x; base < nt; base += stride) {
         const uint32_t i = base + threadIdx.x;
         RareAnchor ra{0, 0xFF};
@@ -1025,13 +1030,41 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         const bool live = (ra.len_kind & 0xFF) == RARE_TOK;
         const uint32_t tl = ra.len_kind >> 8;
         const uint8_t* s = lg.p + (live ? ra.pos : 0);
+        // The token's first 32 bytes (every token is at least 26 long; the bytes behind a short one belong to the log or to the 64
+        // bytes of padding behind it... a token that ends within 32 bytes of the buffer's end is read byte-wise) in ONE round trip:
+        // the prefix tests, the hex test of an MD5 and the bitmap hash all come out of these registers. One lane per token and a
+        // dependent 8-byte load per step made this loop a chain of round trips to HBM per token (18 M tokens of a hash-dense log: 3.6 ms).
+        uint64_t w[4] = {0, 0, 0, 0};
+        if (live) {
+            if (ra.pos + 32 <= lg.len) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) __builtin_memcpy(&w[k], s + 8 * k, 8);
+            } else {
+                for (uint32_t k = 0; k < 32 && ra.pos + k < lg.len; ++k) w[k >> 3] |= (uint64_t)s[k] << (8 * (k & 7));
+            }
+        }
+        const uint32_t c0 = (uint32_t)w[0] & 0xFF, c1 = (uint32_t)(w[0] >> 8) & 0xFF, c2 = (uint32_t)(w[0] >> 16) & 0xFF;
         // hashes: token length 32/40/64/96/128 and all hex (ext:1212-1250)
         {
             Candidate c{0, 0, 0, 0};
             bool emit = false;
             if (live && (p.flags & EX_HASHES)) {
                 const int ht = tl == 32 ? IT_MD5 : tl == 40 ? IT_SHA1 : tl == 64 ? IT_SHA256 : tl == 96 ? IT_SHA384 : tl == 128 ? IT_SHA512 : -1;
-                if (ht >= 0 && all_hex_wide(s, tl)) { c.start = ra.pos; c.len_type = tl | ((uint32_t)ht << 24); emit = true; }
+                if (ht >= 0) {
+                    bool hex = true;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hex = hex && hex4((uint32_t)w[k]) && hex4((uint32_t)(w[k] >> 32));
+                    if (hex && tl > 32) hex = all_hex_wide(s + 32, tl - 32);
+                    if (hex) {
+                        c.start = ra.pos; c.len_type = tl | ((uint32_t)ht << 24); emit = true;
+                        if (tok_filter) {
+                            uint64_t l0 = w[0], l1 = w[1], l2 = w[2], l3 = w[3];
+                            if (db.ci) { l0 = ascii_lower8(l0); l1 = ascii_lower8(l1); l2 = ascii_lower8(l2); l3 = ascii_lower8(l3); }
+                            const uint32_t b = name_hash31(l0, l1, l2, l3, tl) & db.lit_bm_mask;
+                            if (!((db.lit_bm[b >> 5] >> (b & 31)) & 1u)) { emit = false; ++unlisted_tok; }
+                        }
+                    }
+                }
             }
             cw.append(emit, c, p.cands, p.cand_cap, p.n_cand);
         }
@@ -1039,13 +1072,30 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         {
             uint32_t hk = 0;
             if (live && (p.flags & EX_BITCOIN) && tl >= 26 && tl <= 62) {
-                if (s[0] == 'b' && s[1] == 'c' && s[2] == '1') hk = HEAVY_BECH32;
-                else if (s[0] == '1' || s[0] == '3') hk = HEAVY_B58;
+                if (c0 == 'b' && c1 == 'c' && c2 == '1') hk = HEAVY_BECH32;
+                else if (c0 == '1' || c0 == '3') {
+                    // Base58Check starts with decoding, and decoding fails on a symbol outside the Bitcoin alphabet (bs58: lib.rs:1799-1822):
+                    // a token with '0', 'O', 'I' or 'l' in it — every second lower-case hex hash that starts with 1 or 3 — need not go to the
+                    // checksum kernel, whose waves would run the whole decode + double SHA-256 for the one lane in 64 that can pass.
+                    // The first 32 bytes are tested here (bytes behind a shorter token are masked out); k_rare decides the rest.
+                    auto has_byte = [](uint64_t x, uint32_t v) {   // bit 7 of every byte of x that equals v
+                        const uint64_t y = x ^ (0x0101010101010101ull * v);
+                        return ~(((y & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | y) & 0x8080808080808080ull;
+                    };
+                    uint64_t bad = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int rem = (int)tl - 8 * k;
+                        const uint64_t m = rem >= 8 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << (8 * rem)) - 1ull));
+                        bad |= (has_byte(w[k], '0') | has_byte(w[k], 'O') | has_byte(w[k], 'I') | has_byte(w[k], 'l')) & m;
+                    }
+                    if (!bad) hk = HEAVY_B58;
+                }
             }
             hw.append(hk != 0, RareAnchor{ra.pos, (tl << 8) | hk}, p.heavy, p.heavy_cap, &p.counters->n_heavy);
             hk = 0;
-            if (live && (p.flags & EX_ETHEREUM) && tl == 42 && s[0] == '0' && s[1] == 'x') hk = HEAVY_ETH;
-            if (live && (p.flags & EX_MONERO) && tl >= 90 && tl <= 110 && (s[0] == '4' || s[0] == '8')) hk = HEAVY_XMR;
+            if (live && (p.flags & EX_ETHEREUM) && tl == 42 && c0 == '0' && c1 == 'x') hk = HEAVY_ETH;
+            if (live && (p.flags & EX_MONERO) && tl >= 90 && tl <= 110 && (c0 == '4' || c0 == '8')) hk = HEAVY_XMR;
             hw.append(hk != 0, RareAnchor{ra.pos, (tl << 8) | hk}, p.heavy, p.heavy_cap, &p.counters->n_heavy);
         }
     }
@@ -1055,7 +1105,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     uint8_t* win = winbuf + (MISC ? threadIdx.x * 80 : 0);
     // two lists through the same code: k_anchor's rare anchors (vmode bit 0) and the domain anchors k_validate_dom left (bit 1);
     // the engine runs the first beside k_validate_dom on a stream of its own and the second behind it
-    uint32_t unlisted = 0;   // valid candidates this lane did not list (they cannot hit)
+    uint32_t unlisted = unlisted_tok;   // valid candidates this lane did not list (they cannot hit)
     for (uint32_t li = 0; li < 2; ++li) {
     if (!((VM >> li) & 1u)) continue;
     const RareAnchor* rlist = li ? p.rare_dom : p.rare;
