@@ -308,6 +308,11 @@ bool matchy_scan_result_on_device(const matchy_scan_result_t *result);
  * scanned bytes on the host. Returned string: matchy_free_string(). */
 char *matchy_scan_hit_to_json(const matchy_scanner_t *scanner, const matchy_scan_result_t *result, size_t i,
                               const uint8_t *text, const char *source);
+/* Every match of a result as NDJSON — the line matchy_scan_hit_to_json returns for each hit, in the order of the arrays (hits, then
+ * ip4_hits), '\n' behind every line — in one call: *out is a malloc'ed buffer of *out_len bytes (NUL behind them), released with
+ * matchy_free_string. The scanner caches the rendered data payloads by data offset (not thread-safe per scanner, like its scans). */
+int32_t matchy_scan_result_to_ndjson(matchy_scanner_t *scanner, const matchy_scan_result_t *result, const uint8_t *text,
+                                     const char *source, char **out, size_t *out_len);
 /* Per-kernel HIP-event timing of the last scan (recorded on the scan's stream):
  * out[0..4] = k_anchor, k_validate_dom + k_validate, k_rare, k_lookup (incl. writing the hit records), total (milliseconds).
  * matchy_scanner_scan_device runs the kernels behind k_anchor on three streams: then out[1] is that whole tail and out[2] = out[3] = 0. */
@@ -371,7 +376,7 @@ typedef struct matchy_multi_batch_t {
 typedef struct matchy_multi_totals_t { uint64_t batches, bytes, lines, candidates, matches; } matchy_multi_totals_t;
 /* Called on the WORKER thread right after a batch's scan (per-hit work such as rendering runs in parallel there); the
  * returned pointer travels with the batch as matchy_multi_batch_t.payload. */
-typedef void *(*matchy_multi_batch_fn)(void *user, size_t worker, const matchy_scanner_t *scanner, const matchy_scan_result_t *result,
+typedef void *(*matchy_multi_batch_fn)(void *user, size_t worker, matchy_scanner_t *scanner, const matchy_scan_result_t *result,
                                        const uint8_t *data, size_t len, void *tag);
 /* Called on the gathering thread, batches in order; non-zero stops the scan and is returned. */
 typedef int32_t (*matchy_multi_ordered_fn)(void *user, const matchy_multi_batch_t *batch);
@@ -379,8 +384,9 @@ typedef int32_t (*matchy_multi_ordered_fn)(void *user, const matchy_multi_batch_
 matchy_multi_scanner_t *matchy_multi_scanner_create(const matchy_t *db, uint32_t extract_flags, const int32_t *devices, size_t n_devices);
 void matchy_multi_scanner_free(matchy_multi_scanner_t *ms);
 size_t matchy_multi_scanner_workers(const matchy_multi_scanner_t *ms);
-/* The scanner of a worker (NULL until that worker has seen a batch; worker 0's exists from the start): for matchy_scan_hit_to_json. */
-const matchy_scanner_t *matchy_multi_scanner_worker_scanner(const matchy_multi_scanner_t *ms, size_t worker);
+/* The scanner of a worker (NULL until that worker has seen a batch; worker 0's exists from the start): for matchy_scan_hit_to_json /
+ * matchy_scan_result_to_ndjson of a batch that worker scanned (use it from one thread at a time). */
+matchy_scanner_t *matchy_multi_scanner_worker_scanner(const matchy_multi_scanner_t *ms, size_t worker);
 void matchy_multi_scanner_set_batch_hook(matchy_multi_scanner_t *ms, matchy_multi_batch_fn fn, void *user);
 /* Queue one batch (it should end at a line end; len < 4 GiB). The bytes stay the caller's and must remain valid until the batch has
  * been taken with _next. Blocks while one batch per worker is already waiting. pinned_range: NULL, or the page range the caller

@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
     "matchy_amd_device_numa_node", "matchy_amd_bind_thread_to_device", "matchy_amd_numa_cpus",
     "matchy_multi_scanner_create", "matchy_multi_scanner_free", "matchy_multi_scanner_workers", "matchy_multi_scanner_worker_scanner",
     "matchy_multi_scanner_set_batch_hook", "matchy_multi_scanner_submit", "matchy_multi_scanner_next", "matchy_multi_scanner_scan",
-    "matchy_multi_scanner_scan_file",
+    "matchy_multi_scanner_scan_file", "matchy_scan_result_to_ndjson",
 ]
 
 
@@ -168,6 +168,7 @@ def lib():
         "matchy_scanner_wait": (C.c_int32, [vp, C.POINTER(_ScanResult)]),
         "matchy_scan_result_free": (None, [C.POINTER(_ScanResult)]),
         "matchy_scan_hit_to_json": (vp, [vp, C.POINTER(_ScanResult), C.c_size_t, cp, cp]),
+        "matchy_scan_result_to_ndjson": (C.c_int32, [vp, C.POINTER(_ScanResult), cp, cp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "matchy_scanner_set_profile": (None, [vp, C.c_bool]),
         "matchy_amd_ac_dfa_states": (C.c_int32, [vp]),
         "matchy_amd_suffix_filter": (C.c_int32, [vp]),
@@ -467,6 +468,18 @@ class ScanResult:
         if not self._raw.hits and self._raw.n_hits:
             return []   # counters only
         return [_take_string(L.matchy_scan_hit_to_json(self._scanner._h, C.byref(self._raw), i, text, source.encode())) for i in range(n)]
+
+    def ndjson_text(self, text: bytes, source="-") -> bytes:
+        """all matches as one NDJSON text in one call (matchy_scan_result_to_ndjson: what `matchy match` prints)"""
+        L = lib()
+        out, n = C.c_void_p(), C.c_size_t()
+        rc = L.matchy_scan_result_to_ndjson(self._scanner._h, C.byref(self._raw), text, source.encode(), C.byref(out), C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"matchy_scan_result_to_ndjson failed ({rc}): " + last_error())
+        try:
+            return C.string_at(out.value, n.value)
+        finally:
+            L.matchy_free_string(out)
 
     def close(self):
         if self._raw is not None:

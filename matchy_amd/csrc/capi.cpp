@@ -105,6 +105,10 @@ struct MatchesInternal {
 struct ScannerH {
     const Db* db;
     std::unique_ptr<Scanner> sc;
+    // matchy_scan_result_to_ndjson: the JSON text of an entry's data by its data-section offset (indicator lists carry a few hundred
+    // distinct payloads for millions of hits: decoding the MMDB value and serialising it per hit was most of the rendering time)
+    std::unordered_map<uint32_t, std::string> json_of_data;
+    std::string json_source, json_source_of;   // the last source name, JSON-escaped
     // matchy_scanner_submit_device -> matchy_scanner_wait
     bool pending = false;
     size_t pending_len = 0;
@@ -880,6 +884,88 @@ char* matchy_scan_hit_to_json(const matchy_scanner_t* s, const matchy_scan_resul
 }
 
 
+// Every match of a result as NDJSON, one line per hit in the order of the arrays (hits, then compact IPv4 records) — the text
+// matchy_scan_hit_to_json returns for each, concatenated with '\n' behind every line — in ONE call and one allocation: the default output
+// of `matchy match` (match_processor/parallel.rs:297-369). Per scanner the rendered data payloads are cached by data offset and the
+// fixed parts of a line are appended as literals, so a line costs a few memcpy instead of a decode of the MMDB value, a dozen
+// std::string temporaries and a strdup: the renderer was what bounded the command line with --format json (~6 GB/s of log against
+// 40+ with --format summary).
+int32_t matchy_scan_result_to_ndjson(matchy_scanner_t* s, const matchy_scan_result_t* r, const uint8_t* text, const char* source, char** out, size_t* out_len) {
+    if (!s || !r || !out || !out_len || (!text && (r->n_hits || r->n_ip4_hits))) return MATCHY_ERROR_INVALID_PARAM;
+    if (matchy_scan_result_on_device(r)) { set_error("matchy_scan_result_to_ndjson: the records of this result are in device memory (MATCHY_SCAN_FETCH_DEVICE)"); return MATCHY_ERROR_INVALID_PARAM; }
+    ScannerH* sh = reinterpret_cast<ScannerH*>(s);
+    const DbImage& img = sh->sc->image();
+    const size_t n = (r->hits ? r->n_hits : 0) + (r->ip4_hits ? r->n_ip4_hits : 0);
+    if (sh->json_source_of != (source ? source : "-") || sh->json_source.empty()) {
+        sh->json_source_of = source ? source : "-";
+        sh->json_source.clear();
+        json_escape(sh->json_source_of, sh->json_source);
+    }
+    auto data_json = [&](uint32_t off) -> const std::string& {
+        auto it = sh->json_of_data.find(off);
+        if (it != sh->json_of_data.end()) return it->second;
+        if (sh->json_of_data.size() > (1u << 20)) sh->json_of_data.clear();   // a database with millions of distinct payloads: bounded
+        std::string js;
+        DataValue dv;
+        if (img.decode_data(off, dv)) to_json(dv, js); else js = "null";
+        return sh->json_of_data.emplace(off, std::move(js)).first->second;
+    };
+    std::string o;
+    o.reserve(n * 192 + 64);
+    char num[16];
+    auto append_uint = [&](unsigned v) { const int k = snprintf(num, sizeof(num), "%u", v); o.append(num, (size_t)k); };
+    // does the text need more than quotes around it? (extracted items are almost always plain ASCII without '"' or a backslash)
+    auto append_quoted = [&](const char* p, size_t len) {
+        bool plain = true;
+        for (size_t k = 0; k < len; ++k) { const unsigned char c = (unsigned char)p[k]; if (c < 0x20 || c == '"' || c == 0x5C || c >= 0x7F) { plain = false; break; } }
+        if (plain) { o.push_back('"'); o.append(p, len); o.push_back('"'); }
+        else json_escape(std::string(p, len), o);
+    };
+    for (size_t i = 0; i < n; ++i) {
+        const bool in_hits = r->hits && i < r->n_hits;
+        const matchy_scan_hit_t h = in_hits ? r->hits[i] : matchy_scan_ip4_hit_expand(r->ip4_hits[i - (r->hits ? r->n_hits : 0)]);
+        const uint32_t hlen = MATCHY_SCAN_HIT_LEN(h);
+        const char* mt = (const char*)text + h.start;
+        if (h.kind == 2) {
+            IpAddr ip;
+            o += "{\"cidr\":";
+            // format_cidr_into parses matched_text again (cli_utils.rs:113); it always parses for extracted IPs
+            if (parse_ip(mt, hlen, ip)) { const std::string c = format_cidr(ip, h.prefix_len); o.push_back('"'); o += c; o.push_back('"'); }
+            else { std::string c(mt, hlen); c += "/"; c += std::to_string((unsigned)h.prefix_len); json_escape(c, o); }
+            o += ",\"data\":";
+            o += data_json(h.value);
+            o += ",\"match_type\":\"ip\",\"matched_text\":";
+            append_quoted(mt, hlen);
+            o += ",\"prefix_len\":";
+            append_uint((unsigned)h.prefix_len);
+        } else {
+            o.push_back('{');
+            bool any = false;
+            for (uint32_t k = 0; k < h.n_ids; ++k) {
+                const int64_t off = r->data_offsets[h.value + k];
+                if (off < 0) continue;
+                o += any ? "," : "\"data\":[";
+                o += data_json((uint32_t)off);
+                any = true;
+            }
+            if (any) o += "],";
+            o += "\"match_type\":\"pattern\",\"matched_text\":";
+            append_quoted(mt, hlen);
+            o += ",\"pattern_count\":";
+            append_uint((unsigned)h.n_ids);
+        }
+        o += ",\"source\":";
+        o += sh->json_source;
+        o += ",\"timestamp\":\"0.000\"}\n";
+    }
+    char* buf = (char*)malloc(o.size() + 1);
+    if (!buf) { set_error("matchy_scan_result_to_ndjson: out of memory"); return MATCHY_ERROR_OUT_OF_MEMORY; }
+    memcpy(buf, o.data(), o.size());
+    buf[o.size()] = 0;
+    *out = buf; *out_len = o.size();
+    return MATCHY_SUCCESS;
+}
+
 // ------------------------------------------------------------------------------------------------ multi-device scanner
 // The reader -> per-device workers -> ordered gather of `matchy match` (reference: process_files_parallel,
 // crates/matchy/src/processing/parallel.rs:494-505 and its workers :594-704) behind the C ABI: the host submits newline-aligned
@@ -986,7 +1072,7 @@ void matchy_multi_scanner_free(matchy_multi_scanner_t* h) {
     delete ms;
 }
 size_t matchy_multi_scanner_workers(const matchy_multi_scanner_t* h) { return h ? reinterpret_cast<const MultiScanner*>(h)->devices.size() : 0; }
-const matchy_scanner_t* matchy_multi_scanner_worker_scanner(const matchy_multi_scanner_t* h, size_t worker) {
+matchy_scanner_t* matchy_multi_scanner_worker_scanner(const matchy_multi_scanner_t* h, size_t worker) {
     const MultiScanner* ms = reinterpret_cast<const MultiScanner*>(h);
     return ms && worker < ms->scanners.size() ? ms->scanners[worker] : nullptr;
 }

@@ -305,7 +305,24 @@ struct RawBuf {
 // `ptr` points into `own` (inputs that are read: stdin, .gz) or into a file mapping that outlives the batch
 struct Batch { size_t input = 0; RawBuf own; const uint8_t* ptr = nullptr; size_t len = 0; bool mapped = false;
                const void* reg = nullptr; };   // reg: page range of a mapped batch the reader pinned ahead of the scan (unpinned by the worker)
-struct Done { std::string out; Totals t; bool ok = true; size_t input = 0; };
+// what a batch contributes to the output: `text` / `text_len` is the buffer matchy_scan_result_to_ndjson returned (written to stdout as
+// it is and released by the printer: 200 bytes per match are not copied again on the way), `out` what --follow builds from it
+struct Done {
+    std::string out; char* text = nullptr; size_t text_len = 0; Totals t; bool ok = true; size_t input = 0;
+    Done() = default;
+    Done(const Done&) = delete;
+    Done& operator=(const Done&) = delete;
+    ~Done() { if (text) matchy_free_string(text); }
+};
+// all of a buffer to stdout, past stdio (a gigabyte of NDJSON per ten gigabytes of log need not pass through its buffer)
+static void write_all_stdout(const char* p, size_t n) {
+    fflush(stdout);
+    while (n) {
+        const ssize_t w = write(1, p, n);
+        if (w < 0) { if (errno == EINTR) continue; return; }
+        p += w; n -= (size_t)w;
+    }
+}
 
 struct MatchPipeline {
     matchy_multi_scanner_t* ms = nullptr;
@@ -343,7 +360,7 @@ struct MatchPipeline {
         for (const Mapping& m : go) munmap(m.p, m.len);
     }
     // what one batch contributes to the output: counters, and (json) its matches rendered — on the worker thread that scanned it
-    void render(const matchy_scanner_t* sc, const matchy_scan_result_t& r, const uint8_t* data, size_t len, size_t input, Done& d) {
+    void render(matchy_scanner_t* sc, const matchy_scan_result_t& r, const uint8_t* data, size_t len, size_t input, Done& d) {
         d.input = input;
         Totals& t = d.t;
         t.lines += r.lines; t.candidates += r.candidates; t.bytes += len; t.matches += r.n_hits;
@@ -354,13 +371,15 @@ struct MatchPipeline {
             const size_t s = (size_t)r.hits[i].start;
             if (prev == (size_t)-1 || memchr(data + prev, '\n', s - prev)) ++t.lines_with_matches;
             prev = s;
-            if (json) {
-                char* line = matchy_scan_hit_to_json(sc, &r, i, data, source.c_str());
-                if (line) { d.out += line; d.out.push_back('\n'); matchy_free_string(line); }
-            }
+        }
+        if (json && r.n_hits) {   // every match of the batch in one call (the scanner caches the rendered data payloads)
+            char* text = nullptr;
+            size_t n = 0;
+            if (matchy_scan_result_to_ndjson(sc, &r, data, source.c_str(), &text, &n) == MATCHY_SUCCESS) { d.text = text; d.text_len = n; }
+            else { fprintf(stderr, "[ERROR] rendering failed: %s\n", matchy_amd_last_error()); d.ok = false; }
         }
     }
-    static void* batch_hook(void* user, size_t, const matchy_scanner_t* sc, const matchy_scan_result_t* r, const uint8_t* data, size_t len, void* tag) {
+    static void* batch_hook(void* user, size_t, matchy_scanner_t* sc, const matchy_scan_result_t* r, const uint8_t* data, size_t len, void* tag) {
         MatchPipeline* pl = (MatchPipeline*)user;
         Done* d = new Done();
         pl->render(sc, *r, data, len, ((const Batch*)tag)->input, *d);
@@ -397,7 +416,7 @@ struct MatchPipeline {
                 fprintf(stderr, "[ERROR] scan failed: %s\n", matchy_amd_last_error());
                 input_failed[hb->input] = 1;
             } else if (d) {
-                if (!d->out.empty()) fwrite(d->out.data(), 1, d->out.size(), stdout);
+                if (d->text_len) write_all_stdout(d->text, d->text_len);
                 total.lines += d->t.lines; total.lines_with_matches += d->t.lines_with_matches; total.matches += d->t.matches;
                 total.candidates += d->t.candidates; total.bytes += d->t.bytes;
             }
@@ -550,6 +569,7 @@ void follow_inputs(MatchPipeline& pl, matchy_scanner_t* sc, const std::vector<st
             b.ptr = b.own.data(); b.len = have;
             Done d;
             pl.run_batch(sc, b, d);
+            if (d.text_len) d.out.assign(d.text, d.text_len);
             if (!d.out.empty()) {
                 // this batch's records carry the current time
                 char ts[48];

@@ -440,11 +440,7 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
                 keep = (mw.dot & below) == 0 && d_is_boundary(stop) && ((cx.bloom[bit >> 5] >> (bit & 31)) & (cx.bloom[bit2 >> 5] >> (bit2 & 31)) & 1);
             } else if (mw.dot) {
                 keep = false;         // 8 domain chars with a dot among them: a later dot owns the run
-#ifdef MXY_NO_LONG_LABEL
-            } else if (false) {
-#else
             } else if (j + 24 <= cx.res_hi) {
-#endif
                 // a label of 8+ bytes: usually not the last one ("www.examplesite.com" at 'e'). Look 16 bytes further: a
                 // dot before the first non-domain byte settles it; otherwise it stays undecided (long last label)
                 uint32_t more[4];
@@ -668,16 +664,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                 // drops "HTTP/1.1", "Mozilla/5.0", "Safari/537.36" style anchors). The drain checks the digits in between.
                 const uint32_t NV_D = plane_next_dword(cl.D, 0x80808080u), NV_T = plane_next_dword(cl.T, 0x80808080u);
                 const uint32_t lookahead = ahead<1>(cl.D, NV_D) & (ahead<2>(cl.T, NV_T) | ahead<3>(cl.T, NV_T) | ahead<4>(cl.T, NV_T));
-#ifdef MXY_V4_SECOND_DOT
-                // S: a dot that a digit and, 2..4 positions on, another dot follow. The first dot of a dotted quad is such a dot AND its
-                // second dot — 2..4 positions ahead — is one too (the third octet starts with a digit, the third dot follows within
-                // three more): drops three-part version strings ("curl/8.4.0", "requests/2.31.0") before they take a ring slot
-                const uint32_t S = cl.T & lookahead;
-                const uint32_t NV_S = plane_next_dword(S, 0x80808080u);
-                F4 = S & lookback & (ahead<2>(S, NV_S) | ahead<3>(S, NV_S) | ahead<4>(S, NV_S));
-#else
                 F4 = cl.T & lookback & lookahead;
-#endif
             }
             if (en_dom) {
                 // byte that can start a public suffix's last label at j, '.' at j-1 (what stands at j-2 is the validators' business)

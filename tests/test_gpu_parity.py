@@ -172,6 +172,9 @@ def _scan_both(M, oracle, blob, text):
     res = sc.scan(text)
     got_hits = res.hits()
     got_lines = res.ndjson(text, source="t.log")
+    # the batch renderer (one call, cached data payloads: what `matchy match` prints) gives the same lines, twice in a row
+    for _ in range(2):
+        assert res.ndjson_text(text, source="t.log") == "".join(l + "\n" for l in got_lines).encode()
     got_stats = (res.lines, res.candidates)
     res.close()
     if text:
