@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out/bd_$TAG
 mkdir -p $OUT
 export MATCHY_AMD_LIB=$PWD/matchy_amd/lib_ab/dbg.so MATCHY_AMD_PSL=$PWD/matchy_amd/data/psl.bin
 for D in "$@"; do
-  MATCHY_AMD_DEBUG=$D timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/d$D -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --pipelined 0 > $OUT/d$D.log 2>&1
+  MATCHY_AMD_DEBUG=$D timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/d$D -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --no-scatter-gather --pipelined 0 > $OUT/d$D.log 2>&1
   python3 - $OUT/d$D $D <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(list)
