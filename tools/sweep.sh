@@ -11,7 +11,7 @@ while IFS= read -r line; do
   name=${line%%:*}; spec=${line#*:}
   # spec = "VAR=value ... [:: bench args]"
   envs=${spec%%::*}; args=""; [[ "$spec" == *::* ]] && args="${spec#*::}"
-  ( eval "env $envs timeout -k 10 280 python bench.py --no-cpu --no-e2e --pipelined 0 --steps 30 --warmup 3 $args" ) > $O/$i.json 2> $O/$i.err
+  ( eval "env $envs timeout -k 10 280 python bench.py --no-cpu --no-e2e --no-scatter-gather --pipelined 0 --steps 30 --warmup 3 $args" ) > $O/$i.json 2> $O/$i.err
   python3 - "$name" $O/$i.json <<'PY'
 import json, sys
 try:
