@@ -162,7 +162,7 @@ struct SparseWriter {
         if (base == 0xFFFFFFFFu || used + n > cap) {
             // the rest of the old chunk stays unused: sentinels
             if (base != 0xFFFFFFFFu) for (uint32_t k = used + lane_id(); k < cap; k += 64) if (base + k < d.cap) d.out[base + k] = make_uint2(0xFFFFFFFFu, 0xFFu);
-            const uint32_t chunk = flushes < 2 ? n : (flushes < 8 ? 64u : 512u);
+            const uint32_t chunk = flushes < 4 ? n : (flushes < 32 ? 64u : 512u);
             cap = chunk < n ? n : chunk;
             uint32_t b = 0;
             if (lane_id() == 0) b = atomicAdd(d.counter, cap);
