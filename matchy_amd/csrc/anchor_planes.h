@@ -31,13 +31,29 @@ MXY_HD uint32_t bsel(uint32_t m, uint32_t x, uint32_t y) { return (x & m) | (y &
 // y & ~m
 MXY_HD uint32_t andn(uint32_t m, uint32_t y) { return y & ~m; }
 
-// 8 x 8 bit-matrix transpose of the four byte lanes of w[0..7] at once (three butterfly stages, v_lshl/v_lshr + v_bfi)
-MXY_HD void bit_transpose8(uint32_t (&w)[8]) {
+// 8 x 8 bit-matrix transpose of the four byte lanes of w[0..7] at once (three butterfly stages, v_lshl/v_lshr + v_bfi). In two parts
+// for k_anchor: the first stage reads the registers the block was loaded into and writes new ones, so the loads of the next block can be
+// issued into the old ones right behind it — with the whole transpose in place the block first had to be copied out of their way
+// (8 moves per block, and 4 wide ones back on the path without a next block).
 #define MXY_SWAP(a, b, s, m) { const uint32_t ta = bsel(m, w[a], w[b] << s), tb = bsel(m, w[a] >> s, w[b]); w[a] = ta; w[b] = tb; }
-    MXY_SWAP(0, 1, 1, 0x55555555u) MXY_SWAP(2, 3, 1, 0x55555555u) MXY_SWAP(4, 5, 1, 0x55555555u) MXY_SWAP(6, 7, 1, 0x55555555u)
+MXY_HD void bit_transpose8_first(const uint32_t (&in)[8], uint32_t (&w)[8]) {
+#pragma unroll
+    for (int a = 0; a < 8; a += 2) {
+        w[a] = bsel(0x55555555u, in[a], in[a + 1] << 1);
+        w[a + 1] = bsel(0x55555555u, in[a] >> 1, in[a + 1]);
+    }
+}
+MXY_HD void bit_transpose8_rest(uint32_t (&w)[8]) {
     MXY_SWAP(0, 2, 2, 0x33333333u) MXY_SWAP(1, 3, 2, 0x33333333u) MXY_SWAP(4, 6, 2, 0x33333333u) MXY_SWAP(5, 7, 2, 0x33333333u)
     MXY_SWAP(0, 4, 4, 0x0F0F0F0Fu) MXY_SWAP(1, 5, 4, 0x0F0F0F0Fu) MXY_SWAP(2, 6, 4, 0x0F0F0F0Fu) MXY_SWAP(3, 7, 4, 0x0F0F0F0Fu)
+}
 #undef MXY_SWAP
+MXY_HD void bit_transpose8(uint32_t (&w)[8]) {
+    uint32_t t[8];
+    bit_transpose8_first(w, t);
+    bit_transpose8_rest(t);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = t[q];
 }
 
 // Byte classes from the bit planes p[0] (bit 0 of every byte) .. p[7]. `tl_wide`: the public-suffix list in use has a last

@@ -612,39 +612,41 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
         uint32_t nx[8];
         load_block(seg_start, nx);
         for (uint32_t blk = seg_start; blk < seg_end; blk += BLK_BYTES) {
-            // ---- the prefetched block is taken HERE — waited for and moved to the registers the block is processed in — and not where
-            // it is first used, behind the drains below: the counter the wait uses (vmcnt) counts loads and stores alike, in order,
-            // so behind a drain it also sits out the latency of the stores (and the /24 bitmap load) that drain has issued a moment
-            // ago. 0.795 -> 0.766 ms. (A bare s_waitcnt here does not do it: the compiler still places its own in front of the
-            // register copy behind the drains. Moving the drains themselves — all of them in front of the prefetch, or the domain
-            // drain behind it — costs more instructions than the waits it saves: 0.772-0.803 ms.)
+            // ---- the prefetched block is taken HERE — the first stage of the bit transpose reads it, which is where the wait for its loads
+            // goes — and not where the window write needs it, behind the drains below: the counter the wait uses (vmcnt) counts loads and
+            // stores alike, in order, so behind a drain it also sits out the latency of the stores (and the /24 bitmap load) that drain has
+            // issued a moment ago. 0.795 -> 0.766 ms. The stage writes new registers (bit_transpose8_first): the raw bytes stay where they
+            // were loaded until the window has them, and the next block is then loaded into the same registers — no copies. (Moving the
+            // drains themselves — all of them in front of the prefetch, or the domain drain behind it — costs more instructions than the
+            // waits it saves: 0.772-0.803 ms.)
+            uint32_t w[8];
+            bit_transpose8_first(nx, w);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(nx[q]));
+            for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(w[q]));   // ... here, not sunk to the rest of the transpose behind the drains
             // ---- anchors whose look-back bytes are about to be overwritten in the raw window leave first
             if (blk >= seg_start + RAW_BYTES - BLK_BYTES) {
                 const uint32_t lim = blk - (RAW_BYTES - BLK_BYTES);   // entries of blocks <= lim expire
                 if (v4t != v4h && v4_old <= lim) { drain_v4<INL>(rv4, v4h, v4t, v4t - v4h, false, cx, pend, cw_cand, vl); v4_old = blk - BLK_BYTES; }
                 if (dt != dh && dom_old <= lim) { drain_dom(rdom, dh, dt, dt - dh, false, cx, cw_dom); dom_old = blk - BLK_BYTES; }
             }
-            // ---- this lane's 8 dwords: raw bytes into the window (natural byte order); prefetch the next block
-            uint32_t w[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) w[q] = nx[q];
-            if (blk + BLK_BYTES < seg_end) load_block(blk + BLK_BYTES, nx);
+            // ---- this lane's 8 dwords: raw bytes into the window (natural byte order)
             __builtin_amdgcn_wave_barrier();
             {
                 uint32_t* dst = &raw32[((blk & (RAW_BYTES - 1)) >> 2) + lane];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) dst[64 * q] = w[q];
-                if ((blk & (RAW_BYTES - 1)) == 0 && lane < RAW_MIRROR / 4) raw32[RAW_DW + lane] = w[0];   // mirror of the window's first bytes
+                for (int q = 0; q < 8; ++q) dst[64 * q] = nx[q];
+                if ((blk & (RAW_BYTES - 1)) == 0 && lane < RAW_MIRROR / 4) raw32[RAW_DW + lane] = nx[0];   // mirror of the window's first bytes
             }
             __builtin_amdgcn_wave_barrier();
+            // the next block, always: behind the last block of a segment this reads a block of the next segment or the padded end of the
+            // batch, and nobody looks at it (a conditional load would make the compiler keep the registers defined on the other path too)
+            load_block(blk + BLK_BYTES, nx);
             cx.res_hi = blk + BLK_BYTES;
             cx.res_lo = cx.res_hi - seg_start > RAW_BYTES ? cx.res_hi - RAW_BYTES : seg_start;
             __builtin_amdgcn_s_setprio(PRIO_BULK);   // transpose + class functions: independent instructions, they fill gaps
 
             // ---- bit planes and byte classes of the lane's 32 positions: bit t <-> position blk + 256 (t & 7) + 4 lane + (t >> 3)
-            bit_transpose8(w);
+            bit_transpose8_rest(w);
             const ClassPlanes cl = classify_planes(w, tl_wide);
             nl_count += __popc(cl.NL);
             __builtin_amdgcn_s_setprio(PRIO_CHAIN);  // from here on cross-lane steps, LDS and memory: see PRIO_CHAIN
