@@ -369,13 +369,12 @@ __device__ __forceinline__ void drain_v4(uint32_t* ring, uint32_t& head, uint32_
     // the 20 bytes around the dot come from the LDS window (positions >= len are staged as ' ', a boundary like the end of the
     // buffer); only anchors in the first bytes of a segment or at its very end (final drain) read the log itself
     const bool in_window = dot >= cx.res_lo + 4 && dot + 16 <= cx.res_hi;
-    uint32_t s = 0, e = 0, a = 0;
-    bool ok = false;
-    if (go && in_window) {
-        uint32_t w[5];
-        raw_read<5>(cx.raw32, dot - 4, w);
-        ok = d_ipv4_lean(w, cx.ctab, dot, s, e, a);
-    }
+    // every lane parses the 20 bytes at its window address, wanted or not (one definition of s / e / a instead of zeroed registers
+    // merged on every path); lanes without an anchor in the window drop the result
+    uint32_t s, e, a;
+    uint32_t w[5];
+    raw_read<5>(cx.raw32, dot - 4, w);
+    bool ok = d_ipv4_lean(w, cx.ctab, dot, s, e, a) && go && in_window;
     if (__ballot(go && !in_window)) {
         if (go && !in_window) ok = val_ipv4(LogView{p.log, p.len}, dot, s, e, a);
     }
@@ -400,10 +399,6 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
     __builtin_amdgcn_s_setprio(PRIO_DRAIN);
     __builtin_amdgcn_wave_barrier();
     uint32_t ent = 0;
-    bool keep = false, have_ctx = false;
-    uint32_t ctx[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) ctx[k] = 0;
     const bool have = lane < n;
     if (have) ent = ring[(head + lane) & (QCAP - 1)];
     const uint32_t j = have ? anchor_pos(ent) : 0xFFFFFFFFu;
@@ -419,39 +414,43 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
 #ifdef MXY_ANCHOR_DEBUG
     if (p.debug & 2) { __builtin_amdgcn_s_setprio(PRIO_CHAIN); return; }
 #endif
-    if (have && !later) {
-        keep = true;
-        if (j >= cx.res_lo + 24 && j + 8 <= cx.res_hi) {
-            raw_read<8>(cx.raw32, j - 24, ctx);   // log[j-24, j+8): the last label starts at byte 24
-            have_ctx = true;
-            // the label's 8-byte window as SWAR masks (no per-byte loop, no divergent control flow)
-            constexpr uint64_t H = 0x8080808080808080ull;
-            const uint64_t w64 = (uint64_t)ctx[6] | ((uint64_t)ctx[7] << 32);
-            const ByteMasks mw = domain_masks(w64);
-            const uint64_t ndc = ~mw.dc & H;
-            if (ndc) {   // the label ends inside the window: ll = its length (>= 1: byte j can start a TLD)
-                const uint32_t ll = (uint32_t)(__ffsll((long long)ndc) - 1) >> 3;
-                const uint64_t below = (1ull << (8 * ll)) - 1ull;
-                const uint32_t stop = (uint32_t)(w64 >> (8 * ll)) & 0xFF;
-                const uint32_t h8 = tld_hash8((uint32_t)(w64 & below), (uint32_t)((w64 & below) >> 32));
-                const uint32_t bit = h8 & (TLD_BLOOM_BITS / 2 - 1), bit2 = (h8 >> 14) & (TLD_BLOOM_BITS / 2 - 1);
-                // a '.' inside the label: a later dot owns the run; the run must end at a boundary; the label must be
-                // some public suffix's last label (two bits of the prefilter's Bloom filter)
-                keep = (mw.dot & below) == 0 && d_is_boundary(stop) && ((cx.bloom[bit >> 5] >> (bit & 31)) & (cx.bloom[bit2 >> 5] >> (bit2 & 31)) & 1);
-            } else if (mw.dot) {
-                keep = false;         // 8 domain chars with a dot among them: a later dot owns the run
-            } else if (j + 24 <= cx.res_hi) {
-                // a label of 8+ bytes: usually not the last one ("www.examplesite.com" at 'e'). Look 16 bytes further: a
-                // dot before the first non-domain byte settles it; otherwise it stays undecided (long last label)
-                uint32_t more[4];
-                raw_read<4>(cx.raw32, j + 8, more);
-                const ByteMasks ma = domain_masks((uint64_t)more[0] | ((uint64_t)more[1] << 32));
-                const ByteMasks mb = domain_masks((uint64_t)more[2] | ((uint64_t)more[3] << 32));
-                const uint64_t na = ~ma.dc & H, nb = ~mb.dc & H;
-                const uint64_t below_a = na ? ((1ull << ((uint32_t)(__ffsll((long long)na) - 1) & ~7u)) - 1ull) : ~0ull;
-                const uint64_t below_b = na ? 0ull : (nb ? ((1ull << ((uint32_t)(__ffsll((long long)nb) - 1) & ~7u)) - 1ull) : ~0ull);
-                keep = ((ma.dot & below_a) | (mb.dot & below_b)) == 0;
-            }
+    // Every lane reads its 32 context bytes, wanted or not (a window address is a window address; lanes without an anchor, or with
+    // one whose bytes are not resident, read bytes nobody looks at): ONE definition of ctx[] — as conditional assignments the eight
+    // registers were zeroed and merged on every path, 16 moves per drain.
+    const bool go = have && !later;
+    const bool have_ctx = go && j >= cx.res_lo + 24 && j + 8 <= cx.res_hi;
+    uint32_t ctx[8];
+    raw_read<8>(cx.raw32, j - 24, ctx);   // log[j-24, j+8): the last label starts at byte 24
+    bool keep = go;   // anchors that cannot be decided here (bytes not resident, long last label) are kept
+    {
+        // the label's 8-byte window as SWAR masks (no per-byte loop)
+        constexpr uint64_t H = 0x8080808080808080ull;
+        const uint64_t w64 = (uint64_t)ctx[6] | ((uint64_t)ctx[7] << 32);
+        const ByteMasks mw = domain_masks(w64);
+        const uint64_t ndc = ~mw.dc & H;
+        if (ndc) {   // the label ends inside the window: ll = its length (>= 1: byte j can start a TLD)
+            const uint32_t ll = (uint32_t)(__ffsll((long long)ndc) - 1) >> 3;
+            const uint64_t below = (1ull << (8 * ll)) - 1ull;
+            const uint32_t stop = (uint32_t)(w64 >> (8 * ll)) & 0xFF;
+            const uint32_t h8 = tld_hash8((uint32_t)(w64 & below), (uint32_t)((w64 & below) >> 32));
+            const uint32_t bit = h8 & (TLD_BLOOM_BITS / 2 - 1), bit2 = (h8 >> 14) & (TLD_BLOOM_BITS / 2 - 1);
+            // a '.' inside the label: a later dot owns the run; the run must end at a boundary; the label must be
+            // some public suffix's last label (two bits of the prefilter's Bloom filter)
+            const bool k = (mw.dot & below) == 0 && d_is_boundary(stop) && ((cx.bloom[bit >> 5] >> (bit & 31)) & (cx.bloom[bit2 >> 5] >> (bit2 & 31)) & 1);
+            if (have_ctx) keep = k;
+        } else if (mw.dot) {
+            if (have_ctx) keep = false;         // 8 domain chars with a dot among them: a later dot owns the run
+        } else if (have_ctx && j + 24 <= cx.res_hi) {
+            // a label of 8+ bytes: usually not the last one ("www.examplesite.com" at 'e'). Look 16 bytes further: a
+            // dot before the first non-domain byte settles it; otherwise it stays undecided (long last label)
+            uint32_t more[4];
+            raw_read<4>(cx.raw32, j + 8, more);
+            const ByteMasks ma = domain_masks((uint64_t)more[0] | ((uint64_t)more[1] << 32));
+            const ByteMasks mb = domain_masks((uint64_t)more[2] | ((uint64_t)more[3] << 32));
+            const uint64_t na = ~ma.dc & H, nb = ~mb.dc & H;
+            const uint64_t below_a = na ? ((1ull << ((uint32_t)(__ffsll((long long)na) - 1) & ~7u)) - 1ull) : ~0ull;
+            const uint64_t below_b = na ? 0ull : (nb ? ((1ull << ((uint32_t)(__ffsll((long long)nb) - 1) & ~7u)) - 1ull) : ~0ull);
+            keep = ((ma.dot & below_a) | (mb.dot & below_b)) == 0;
         }
     }
     const uint32_t slot = dw.reserve(keep, p.dom_list, p.dom_cap, [] { return &cold_tok()->counters->n_dom; });
