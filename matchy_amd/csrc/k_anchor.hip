@@ -549,7 +549,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     WaveCtx cx{&p, raw32, ctab, bloom, db.ip_bm24, 0u, 0u};
     PendingV4 pend;
     const uint32_t lane_off = lane << 2;
-    const uint32_t lane0_ones = lane == 0 ? 0xFFFFFFFFu : 0u;
+    const uint32_t lane0_one = lane == 0 ? 1u : 0u;   // shift count: the value that wraps from lane 63 into lane 0 moves one row up (x << 1 there, x elsewhere)
 
     // dword `lane` of the 8 rows of block `b`; positions >= len read as ' ' (a boundary, like the end of the buffer)
     auto load_block = [&](uint32_t b, uint32_t (&w)[8]) {
@@ -772,8 +772,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                 Aprev = a4;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_WAVE_ROR1, 0xF, 0xF, false);
-                    x += x & lane0_ones;
+                    x = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, DPP_WAVE_ROR1, 0xF, 0xF, false) << lane0_one;   // every lane has a source: no `old` value to set up
                     r &= x;
                 }
                 // three all-alphanumeric dwords in a row (12+ such bytes) are rare in logs: the rest only then
@@ -781,8 +780,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                 if (__ballot(r != 0)) {
 #pragma unroll
                     for (int k = 3; k < 5; ++k) {
-                        x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_WAVE_ROR1, 0xF, 0xF, false);
-                        x += x & lane0_ones;
+                        x = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, DPP_WAVE_ROR1, 0xF, 0xF, false) << lane0_one;
                         r &= x;
                     }
                     // only the lowest boundary byte of a dword can close a long token
