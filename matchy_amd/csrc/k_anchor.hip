@@ -787,43 +787,62 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                     cand = (cl.B | (cl.B >> 8) | (cl.B >> 16) | (cl.B >> 24)) & (r >> 1) & 0xFFu;
                 }
                 if (__ballot(cand != 0)) {
-                    // exact length from the boundary-free dwords (G) around the candidate
+                    // Exact length from the boundary-free dwords (G) around the candidate. One candidate per lane and round, whatever row it
+                    // is in (a loop over the eight rows ran its ~60 instructions once per row that holds a candidate: every row of a block
+                    // of an endpoint or JSON log, where each line carries hashes or ids). The rows' free-dword masks — eight ballots and the
+                    // previous block's last row — are parked in the lanes of one register (lane r: low word of row r - 1, lane 16 + r: high
+                    // word; r = 0: the previous block's row 7) and every lane fetches the two rows it needs with ds_bpermute.
                     const uint32_t G = ~(cl.B | (cl.B >> 8) | (cl.B >> 16) | (cl.B >> 24)) & 0xFFu;
                     const uint32_t Gprev = (Bprev & 0x80808080u) ? 0u : 0x80u;   // row 7 of the previous block
-                    const uint64_t Zp = __ballot((Gprev & 0x80u) != 0);   // free dwords of the previous block's last row
-                    uint64_t Zprev_row = Zp;
+                    // (v_writelane through inline assembly: the compiler offers no builtin for it here and does not see the hazard between the
+                    // v_cmp that has just written VCC and a v_writelane that reads it — without the wait states in front of each one the lanes
+                    // received stale masks)
+                    int zt = 0;
+                    {
+                        const uint64_t z = __ballot((Gprev & 0x80u) != 0);
+                        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, 0" : "+v"(zt) : "s"((uint32_t)z));
+                        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, 16" : "+v"(zt) : "s"((uint32_t)(z >> 32)));
+                    }
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const uint64_t Zq = __ballot(((G >> q) & 1u) != 0);
-                        const bool mine = ((cand >> q) & 1u) != 0;
-                        if (__ballot(mine)) {
-                            // free dwords directly below this one: in this row, then at the end of the previous row
-                            const uint64_t below = lane ? (Zq << (64 - lane)) : 0ull;          // bit 63 = dword lane-1
-                            uint32_t run = lane ? (uint32_t)__clzll((long long)~below) : 0u;   // ~below != 0 for lane < 64... see min
-                            run = min(run, lane);
-                            bool too_long = false;
-                            if (run == lane) {
-                                const uint32_t r2 = ~Zprev_row ? (uint32_t)__clzll((long long)~Zprev_row) : 64u;
-                                too_long = r2 == 64u;   // 64 + free dwords = more than 256 bytes: longer than any token
-                                run += r2;
-                            }
-                            // the dword below the run holds the last boundary byte before the token
-                            const int32_t it = (int32_t)(64 * q + lane) - (int32_t)run - 1;    // dword index in the block (negative: previous block)
-                            const uint32_t src_lane = (uint32_t)it & 63u;
-                            const uint32_t wb_cur = (uint32_t)__shfl((int)cl.B, (int)src_lane);
-                            const uint32_t wb_prev = (uint32_t)__shfl((int)Bprev, (int)src_lane);
-                            const uint32_t rowbits = it >= 0 ? ((wb_cur >> (it >> 6)) & 0x01010101u) : ((wb_prev >> 7) & 0x01010101u);
-                            const uint32_t hb = rowbits ? (31u - (uint32_t)__clz((int)rowbits)) >> 3 : 0u;
-                            const int32_t s = (int32_t)blk + 4 * it + (int32_t)hb + 1;         // token start
-                            const uint32_t mybits = (cl.B >> q) & 0x01010101u;
-                            const uint32_t b0 = mybits ? ((uint32_t)__ffs((int)mybits) - 1u) >> 3 : 0u;
-                            const uint32_t e = blk + AB_ROW_BYTES * q + lane_off + b0;          // closing boundary
-                            const uint32_t tl = e - (uint32_t)s;
-                            const bool tok = mine && !too_long && rowbits != 0 &&
-                                             ((tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128);
-                            cw_tok.append(tok, make_uint2((uint32_t)s, (uint32_t)RARE_TOK | (tl << 8)));
+                        const uint64_t z = __ballot(((G >> q) & 1u) != 0);
+                        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(zt) : "s"((uint32_t)z), "n"(q + 1));
+                        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(zt) : "s"((uint32_t)(z >> 32)), "n"(q + 17));
+                    }
+                    uint32_t cleft = cand;
+                    while (__ballot(cleft != 0)) {
+                        const bool mine = cleft != 0;
+                        const uint32_t q = mine ? (uint32_t)__builtin_ctz(cleft) : 0u;   // this lane's row in this round
+                        cleft &= cleft - 1;
+                        const uint64_t Zq = (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * (q + 1)), zt) |
+                                            ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * (q + 17)), zt) << 32);
+                        const uint64_t Zprev_row = (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * q), zt) |
+                                                   ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * (q + 16)), zt) << 32);
+                        // free dwords directly below this one: in this row, then at the end of the previous row
+                        const uint64_t below = lane ? (Zq << (64 - lane)) : 0ull;          // bit 63 = dword lane-1
+                        uint32_t run = lane ? (uint32_t)__clzll((long long)~below) : 0u;   // ~below != 0 for lane < 64... see min
+                        run = min(run, lane);
+                        bool too_long = false;
+                        if (run == lane) {
+                            const uint32_t r2 = ~Zprev_row ? (uint32_t)__clzll((long long)~Zprev_row) : 64u;
+                            too_long = r2 == 64u;   // 64 + free dwords = more than 256 bytes: longer than any token
+                            run += r2;
                         }
-                        Zprev_row = Zq;
+                        // the dword below the run holds the last boundary byte before the token
+                        const int32_t it = (int32_t)(64 * q + lane) - (int32_t)run - 1;    // dword index in the block (negative: previous block)
+                        const uint32_t src_lane = (uint32_t)it & 63u;
+                        const uint32_t wb_cur = (uint32_t)__shfl((int)cl.B, (int)src_lane);
+                        const uint32_t wb_prev = (uint32_t)__shfl((int)Bprev, (int)src_lane);
+                        const uint32_t rowbits = it >= 0 ? ((wb_cur >> (it >> 6)) & 0x01010101u) : ((wb_prev >> 7) & 0x01010101u);
+                        const uint32_t hb = rowbits ? (31u - (uint32_t)__clz((int)rowbits)) >> 3 : 0u;
+                        const int32_t s = (int32_t)blk + 4 * it + (int32_t)hb + 1;         // token start
+                        const uint32_t mybits = (cl.B >> q) & 0x01010101u;
+                        const uint32_t b0 = mybits ? ((uint32_t)__ffs((int)mybits) - 1u) >> 3 : 0u;
+                        const uint32_t e = blk + AB_ROW_BYTES * q + lane_off + b0;          // closing boundary
+                        const uint32_t tl = e - (uint32_t)s;
+                        const bool tok = mine && !too_long && rowbits != 0 &&
+                                         ((tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128);
+                        cw_tok.append(tok, make_uint2((uint32_t)s, (uint32_t)RARE_TOK | (tl << 8)));
                     }
                 }
                 Bprev = cl.B;
