@@ -897,7 +897,22 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         // — k_rare takes what they leave — then get a launch of their own in front of the rare anchors (IPv6 / e-mail: ten times as
         // many, 0.12 ms), so that k_rare runs beside those instead of behind them.
         const bool rare_own = L.split_misc && rare_possible && !L.ip_pass;
-        if (rare_own) {
+        // Both lists long (the previous batch had hundreds of thousands of long tokens AND of IPv6 / e-mail anchors: application logs in
+        // JSON lines): the long tokens do not run in front of the rare anchors on the third stream but beside them on the second, in front
+        // of k_rare (which takes what they leave: stream order instead of an event), and list their hashes in k_rare's candidate list — the
+        // lookup behind k_rare takes both. Two latency-bound passes over millions of entries each then overlap instead of queueing (the
+        // JSON-lines shape: tail 1.18 -> see profiles/r04_log_shapes.txt). With short lists (a web-server log) the two kernels would only
+        // take vector-ALU time from k_validate_dom beside them (+6 us measured): the order stays as it is there.
+        static const int env_tok_aside = getenv("MATCHY_AMD_TOK_ASIDE") ? atoi(getenv("MATCHY_AMD_TOK_ASIDE")) : -1;
+        const bool tok_aside = rare_own && (env_tok_aside >= 0 ? env_tok_aside != 0 : (hint_.n_tok >= 262144u && hint_.n_rare >= 262144u));
+        if (tok_aside) {
+            MXY_HIP(hipStreamWaitEvent(aux_stream_, fork, 0));
+            TokParams tt = t1;
+            tt.vmode = 4u;
+            tt.cands = work_[0].cands_r.p; tt.cand_cap = (uint32_t)work_[0].cands_r.n; tt.n_cand = &counters_.p->n_cand_r;
+            launch_validate_misc(tt, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_tok, 1024, std::max(1, n_cu_ / 2), 8), aux_stream_);
+            t1.vmode = 1u;
+        } else if (rare_own) {
             TokParams tt = t1;
             tt.vmode = 4u;
             launch_validate_misc(tt, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_tok, 1024, std::max(1, n_cu_ / 2), 8), aux2_stream_);   // 6 KB of LDS, workgroups beyond the list leave at once
@@ -922,12 +937,12 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
             tr.vmode = tp.vmode;
             if (L.split_misc) { tr.cands = work_[0].cands_r.p; tr.cand_cap = (uint32_t)work_[0].cands_r.n; tr.n_cand = &counters_.p->n_cand_r; }
             hipStream_t rs = rare_own ? aux_stream_ : aux2_stream_;
-            if (rare_own) MXY_HIP(hipStreamWaitEvent(aux_stream_, ev_v1_, 0));
+            if (rare_own && !tok_aside) MXY_HIP(hipStreamWaitEvent(aux_stream_, ev_v1_, 0));
             launch_rare(tr, view, grid_for(hint_.n_heavy, 128, n_cu_ * 4, 16), rs);
             if (L.split_misc) {
                 LookupParams lr = L.lr;
                 if (arrive) { lr.arrive_chain = rare_own ? 2u : 1u; lr.arrive = counters_.p; ++chains; }
-                launch_lookup(lr, view, grid_for(hint_.n_cand_r, 512, std::max(1, n_cu_ / 8), 4), rs);
+                launch_lookup(lr, view, grid_for(hint_.n_cand_r, 512, std::max(1, n_cu_ / 8), 4), rs);   // (tok_aside: the hint follows the list that now holds the hashes too)
             }
             if (rare_own && !arrive) MXY_HIP(hipEventRecord(ev_join_, aux_stream_));
         }

@@ -455,6 +455,47 @@ print("OK")
     assert "joining the side streams on the host" in p.stderr, p.stderr[-2000:]
 
 
+def test_long_tokens_beside_the_rare_anchors(M, oracle):
+    """When the previous batch listed hundreds of thousands of long tokens AND of IPv6 / e-mail anchors, the engine runs the token
+    pass beside the rare-anchor pass (second stream, in front of k_rare, its hashes in k_rare's candidate list) instead of in front
+    of it. Forced on in a child process (MATCHY_AMD_TOK_ASIDE=1) over a JSON-lines batch, which has both kinds, and — so that the
+    adaptive switch itself runs — left to the engine over the same batch scanned twice (the second scan sees the first one's lists)."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, sys
+sys.path.insert(0, %r)
+import matchy_amd as M
+from tools import synth
+from oracle import oracle as orc
+orc.build()
+cfg = synth.config("c2/10")
+blob = synth.build_db(cfg)
+log = synth.make_log(cfg, 0, int(sys.argv[1]), shape="jsonl-app")
+db = M.Database(blob); sc = M.Scanner(db)
+hip = ctypes.CDLL("libamdhip64.so")
+d = ctypes.c_void_p()
+assert hip.hipMalloc(ctypes.byref(d), ctypes.c_size_t(len(log) + 64)) == 0
+assert hip.hipMemcpy(d, log, ctypes.c_size_t(len(log)), 1) == 0
+want, _, st = orc.Database(blob).scan(log, want_json=False)
+assert len(want) > 100
+for rep in range(3):
+    r = sc.scan_device(d.value, len(log), fetch_mode=3)
+    assert (r.lines, r.candidates) == (st.lines, st.candidates), rep
+    assert r.hits() == want, rep
+    r.close()
+print("OK")
+""" % str(ROOT)
+    # forced: a small batch; adaptive: 800 K lines list 990 K long tokens and 310 K rare anchors, above the switch (262 144 of each)
+    for setting, lines in (("1", 120000), (None, 800000)):
+        env = dict(os.environ)
+        env.pop("MATCHY_AMD_TOK_ASIDE", None)
+        if setting is not None:
+            env["MATCHY_AMD_TOK_ASIDE"] = setting
+        p = subprocess.run([sys.executable, "-c", code, str(lines)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "OK" in p.stdout, (setting, p.stderr[-2000:])
+
+
 def test_multi_device_scanner_matches_the_single_scanner(M, oracle, tmp_path):
     """matchy_multi_scanner_*: the reader -> per-device workers -> ordered gather behind the C ABI (processing/parallel.rs:494-505).
     The same GPU listed three times: a buffer (merged result = the oracle's records with absolute offsets, for several piece sizes),
