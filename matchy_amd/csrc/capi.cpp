@@ -901,68 +901,121 @@ int32_t matchy_scan_result_to_ndjson(matchy_scanner_t* s, const matchy_scan_resu
         sh->json_source.clear();
         json_escape(sh->json_source_of, sh->json_source);
     }
-    auto data_json = [&](uint32_t off) -> const std::string& {
-        auto it = sh->json_of_data.find(off);
-        if (it != sh->json_of_data.end()) return it->second;
-        if (sh->json_of_data.size() > (1u << 20)) sh->json_of_data.clear();   // a database with millions of distinct payloads: bounded
-        std::string js;
-        DataValue dv;
-        if (img.decode_data(off, dv)) to_json(dv, js); else js = "null";
-        return sh->json_of_data.emplace(off, std::move(js)).first->second;
+    // One piece of the result per thread (large results only: a 256 MiB batch of a web-server log carries ~70 K matches, ~15 MB of text; one thread
+    // renders ~9 M lines a second, which is less than two scanners on one GPU deliver). While pieces are rendered side by side the cache of
+    // payload texts is only read: a payload that is not in it yet is decoded into the piece's own list and joins the cache behind the threads.
+    struct Piece {
+        std::string o;
+        std::deque<std::pair<uint32_t, std::string>> fresh;          // payloads decoded by this piece (stable addresses)
+        std::unordered_map<uint32_t, const std::string*> fresh_at;
     };
-    std::string o;
-    o.reserve(n * 192 + 64);
-    char num[16];
-    auto append_uint = [&](unsigned v) { const int k = snprintf(num, sizeof(num), "%u", v); o.append(num, (size_t)k); };
-    // does the text need more than quotes around it? (extracted items are almost always plain ASCII without '"' or a backslash)
-    auto append_quoted = [&](const char* p, size_t len) {
-        bool plain = true;
-        for (size_t k = 0; k < len; ++k) { const unsigned char c = (unsigned char)p[k]; if (c < 0x20 || c == '"' || c == 0x5C || c >= 0x7F) { plain = false; break; } }
-        if (plain) { o.push_back('"'); o.append(p, len); o.push_back('"'); }
-        else json_escape(std::string(p, len), o);
-    };
-    for (size_t i = 0; i < n; ++i) {
-        const bool in_hits = r->hits && i < r->n_hits;
-        const matchy_scan_hit_t h = in_hits ? r->hits[i] : matchy_scan_ip4_hit_expand(r->ip4_hits[i - (r->hits ? r->n_hits : 0)]);
-        const uint32_t hlen = MATCHY_SCAN_HIT_LEN(h);
-        const char* mt = (const char*)text + h.start;
-        if (h.kind == 2) {
-            IpAddr ip;
-            o += "{\"cidr\":";
-            // format_cidr_into parses matched_text again (cli_utils.rs:113); it always parses for extracted IPs
-            if (parse_ip(mt, hlen, ip)) { const std::string c = format_cidr(ip, h.prefix_len); o.push_back('"'); o += c; o.push_back('"'); }
-            else { std::string c(mt, hlen); c += "/"; c += std::to_string((unsigned)h.prefix_len); json_escape(c, o); }
-            o += ",\"data\":";
-            o += data_json(h.value);
-            o += ",\"match_type\":\"ip\",\"matched_text\":";
-            append_quoted(mt, hlen);
-            o += ",\"prefix_len\":";
-            append_uint((unsigned)h.prefix_len);
-        } else {
-            o.push_back('{');
-            bool any = false;
-            for (uint32_t k = 0; k < h.n_ids; ++k) {
-                const int64_t off = r->data_offsets[h.value + k];
-                if (off < 0) continue;
-                o += any ? "," : "\"data\":[";
-                o += data_json((uint32_t)off);
-                any = true;
+    auto render = [&](size_t i0, size_t i1, Piece& pc, bool alone) {
+        std::string& o = pc.o;
+        o.reserve((i1 - i0) * 192 + 64);
+        auto data_json = [&](uint32_t off) -> const std::string& {
+            auto it = sh->json_of_data.find(off);
+            if (it != sh->json_of_data.end()) return it->second;
+            if (alone) {
+                if (sh->json_of_data.size() > (1u << 20)) sh->json_of_data.clear();   // a database with millions of distinct payloads: bounded
+                std::string js;
+                DataValue dv;
+                if (img.decode_data(off, dv)) to_json(dv, js); else js = "null";
+                return sh->json_of_data.emplace(off, std::move(js)).first->second;
             }
-            if (any) o += "],";
-            o += "\"match_type\":\"pattern\",\"matched_text\":";
-            append_quoted(mt, hlen);
-            o += ",\"pattern_count\":";
-            append_uint((unsigned)h.n_ids);
+            auto f = pc.fresh_at.find(off);
+            if (f != pc.fresh_at.end()) return *f->second;
+            std::string js;
+            DataValue dv;
+            if (img.decode_data(off, dv)) to_json(dv, js); else js = "null";
+            pc.fresh.emplace_back(off, std::move(js));
+            pc.fresh_at.emplace(off, &pc.fresh.back().second);
+            return pc.fresh.back().second;
+        };
+        char num[16];
+        auto append_uint = [&](unsigned v) { const int k = snprintf(num, sizeof(num), "%u", v); o.append(num, (size_t)k); };
+        // does the text need more than quotes around it? (extracted items are almost always plain ASCII without '"' or a backslash)
+        auto append_quoted = [&](const char* p, size_t len) {
+            bool plain = true;
+            for (size_t k = 0; k < len; ++k) { const unsigned char c = (unsigned char)p[k]; if (c < 0x20 || c == '"' || c == 0x5C || c >= 0x7F) { plain = false; break; } }
+            if (plain) { o.push_back('"'); o.append(p, len); o.push_back('"'); }
+            else json_escape(std::string(p, len), o);
+        };
+        for (size_t i = i0; i < i1; ++i) {
+            const bool in_hits = r->hits && i < r->n_hits;
+            const matchy_scan_hit_t h = in_hits ? r->hits[i] : matchy_scan_ip4_hit_expand(r->ip4_hits[i - (r->hits ? r->n_hits : 0)]);
+            const uint32_t hlen = MATCHY_SCAN_HIT_LEN(h);
+            const char* mt = (const char*)text + h.start;
+            if (h.kind == 2) {
+                IpAddr ip;
+                o += "{\"cidr\":";
+                // format_cidr_into parses matched_text again (cli_utils.rs:113); it always parses for extracted IPs
+                if (parse_ip(mt, hlen, ip)) { const std::string c = format_cidr(ip, h.prefix_len); o.push_back('"'); o += c; o.push_back('"'); }
+                else { std::string c(mt, hlen); c += "/"; c += std::to_string((unsigned)h.prefix_len); json_escape(c, o); }
+                o += ",\"data\":";
+                o += data_json(h.value);
+                o += ",\"match_type\":\"ip\",\"matched_text\":";
+                append_quoted(mt, hlen);
+                o += ",\"prefix_len\":";
+                append_uint((unsigned)h.prefix_len);
+            } else {
+                o.push_back('{');
+                bool any = false;
+                for (uint32_t k = 0; k < h.n_ids; ++k) {
+                    const int64_t off = r->data_offsets[h.value + k];
+                    if (off < 0) continue;
+                    o += any ? "," : "\"data\":[";
+                    o += data_json((uint32_t)off);
+                    any = true;
+                }
+                if (any) o += "],";
+                o += "\"match_type\":\"pattern\",\"matched_text\":";
+                append_quoted(mt, hlen);
+                o += ",\"pattern_count\":";
+                append_uint((unsigned)h.n_ids);
+            }
+            o += ",\"source\":";
+            o += sh->json_source;
+            o += ",\"timestamp\":\"0.000\"}\n";
         }
-        o += ",\"source\":";
-        o += sh->json_source;
-        o += ",\"timestamp\":\"0.000\"}\n";
-    }
-    char* buf = (char*)malloc(o.size() + 1);
+    };
+    static const unsigned max_threads = [] {
+        if (const char* e = getenv("MATCHY_AMD_JSON_THREADS")) return (unsigned)std::max(1, atoi(e));
+        const unsigned hw = std::thread::hardware_concurrency();
+        return hw >= 8 ? 4u : hw >= 4 ? 2u : 1u;
+    }();
+    const unsigned nt = (unsigned)std::min<size_t>(max_threads, std::max<size_t>(1, n / 16384));
+    std::vector<Piece> pieces(nt);
+    try {
+        if (nt == 1) render(0, n, pieces[0], true);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; ++t) th.emplace_back([&, t] { render(n * t / nt, n * (t + 1) / nt, pieces[t], false); });
+            render(0, n / nt, pieces[0], false);
+            for (auto& x : th) x.join();
+            for (Piece& pc : pieces)
+                for (auto& e : pc.fresh) {
+                    if (sh->json_of_data.size() > (1u << 20)) sh->json_of_data.clear();
+                    sh->json_of_data.emplace(e.first, std::move(e.second));
+                }
+        }
+    } catch (const std::exception& e) { set_error(e.what()); return MATCHY_ERROR_OUT_OF_MEMORY; }
+    size_t total = 0;
+    for (const Piece& pc : pieces) total += pc.o.size();
+    char* buf = (char*)malloc(total + 1);
     if (!buf) { set_error("matchy_scan_result_to_ndjson: out of memory"); return MATCHY_ERROR_OUT_OF_MEMORY; }
-    memcpy(buf, o.data(), o.size());
-    buf[o.size()] = 0;
-    *out = buf; *out_len = o.size();
+    {
+        std::vector<std::thread> th;
+        size_t at = 0;
+        for (unsigned t = 0; t < nt; ++t) {
+            char* dst = buf + at;
+            at += pieces[t].o.size();
+            if (t + 1 < nt) th.emplace_back([dst, &pieces, t] { memcpy(dst, pieces[t].o.data(), pieces[t].o.size()); });
+            else memcpy(dst, pieces[t].o.data(), pieces[t].o.size());
+        }
+        for (auto& x : th) x.join();
+    }
+    buf[total] = 0;
+    *out = buf; *out_len = total;
     return MATCHY_SUCCESS;
 }
 

@@ -1,19 +1,29 @@
-"""NDJSON output rate of `matchy match --format json` on the GPU box: python tools/json_ab.py (after tools/cli_fixed.py has written /tmp/c2.mxy and /tmp/c2.log).
-JSON_AB_FILE=1 writes the output to a file instead of /dev/null; JSON_AB_OLD=<dir with an older matchy + libmatchy_amd.so> adds that build."""
-import os, subprocess, sys, time
+"""`matchy match --format json`: one rendering thread against the default (pieces of a large result rendered side by side) — the two
+outputs must be byte-identical; wall time and scan-phase rate of both, beside --format summary."""
+import hashlib, subprocess, sys, time, os
+sys.path.insert(0, ".")
+from tools import synth
+cfg = synth.config("c2")
+open("/tmp/c2.mxy", "wb").write(synth.build_db(cfg))
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+with open("/tmp/c2.log", "wb") as f:
+    for a in range(0, n, 1_000_000):
+        f.write(synth.make_log(cfg, a, min(1_000_000, n - a)))
 size = os.path.getsize("/tmp/c2.log")
-reps = 10
-to_file = bool(os.environ.get("JSON_AB_FILE"))
-builds = [("this tree", "matchy_amd/bin/matchy", {})]
-old = os.environ.get("JSON_AB_OLD")
-if old:
-    builds.insert(0, ("older build", old + "/matchy", {"LD_LIBRARY_PATH": os.path.abspath(old), "MATCHY_AMD_PSL": os.path.abspath("matchy_amd/data/psl.bin")}))
-for name, cli, env in builds:
-    for fmt, jobs in (("json", "auto"), ("json", "8"), ("summary", "auto")):
-        dest = open("/tmp/out.ndjson", "wb") if to_file else subprocess.DEVNULL
+cli = os.environ.get("MATCHY_CLI", "matchy_amd/bin/matchy")
+sums = {}
+for devs in ("0", "0,0"):
+    for name, fmt, env in (("summary", "summary", {}), ("json 1 thread", "json", {"MATCHY_AMD_JSON_THREADS": "1"}), ("json default", "json", {})):
+        out = "/tmp/out_%s.ndjson" % name.replace(" ", "_")
         t = time.time()
-        r = subprocess.run([cli, "match", "/tmp/c2.mxy"] + ["/tmp/c2.log"] * reps + ["-j", jobs, "--format", fmt, "-s"], stdout=dest, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        r = subprocess.run([cli, "match", "/tmp/c2.mxy"] + ["/tmp/c2.log"] * reps + ["--devices", devs, "--batch-bytes", str(256 << 20), "--format", fmt, "-s"],
+                           stdout=open(out, "wb"), stderr=subprocess.PIPE, env=dict(os.environ, **env))
         dt = time.time() - t
-        thr = [l.split("] ")[1] for l in r.stderr.decode().splitlines() if "Throughput" in l or "Total matches" in l]
-        where = "a file" if to_file else "/dev/null"
-        print(f"{name}: --format {fmt} -j {jobs}, {reps} x {size} B, output to {where}: wall {dt:.2f} s = {size * reps / dt / 1e9:.2f} GB/s; {thr}", flush=True)
+        thr = [l.split("Throughput:")[1].strip() for l in r.stderr.decode().splitlines() if "Throughput" in l]
+        h = hashlib.sha256(open(out, "rb").read()).hexdigest()[:16] if fmt == "json" else "-"
+        sums.setdefault(devs, {})[name] = h
+        print(f"devices={devs:4s} {name:14s}: wall {dt:.2f}s = {size * reps / dt / 1e9:.2f} GB/s; scan phase {thr}; output {os.path.getsize(out)} B sha256 {h}", flush=True)
+for devs, d in sums.items():
+    assert d["json 1 thread"] == d["json default"], (devs, d)
+print("byte-identical: OK")
