@@ -348,6 +348,8 @@ struct MatchPipeline {
     // Mapped inputs: the mapping of a file is released by the printer as soon as the file's last batch has been printed — the
     // page tables of a file of gigabytes take tens of milliseconds to tear down, and that runs beside the scans of the next
     // files instead of behind the last one.
+    // bytes of each input the first pass has read: where --follow starts watching (a size taken AFTER that pass would skip what was appended in between)
+    std::vector<long long> consumed;
     struct Mapping { void* p; size_t len; size_t last_seq; bool released; };
     std::vector<Mapping> mappings;   // guarded by mu
     void add_mapping(void* p, size_t len, size_t last_seq) { std::lock_guard<std::mutex> lk(mu); mappings.push_back({p, len, last_seq, false}); }
@@ -473,6 +475,7 @@ bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t
                 pos = end;
             }
             pl.add_mapping(m, size, last_seq);
+            if (input < pl.consumed.size()) pl.consumed[input] = (long long)size;
             return true;
         }
     }
@@ -483,7 +486,7 @@ bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t
         gzbuffer(zf, 1u << 20);
     }
     RawBuf buf(batch_bytes + 16);
-    size_t have = 0;
+    size_t have = 0, total_read = 0;
     bool ok = true;
     auto send = [&](RawBuf&& data, size_t len) {
         Batch b;
@@ -502,6 +505,7 @@ bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t
             if (n < 0) { fprintf(stderr, "[ERROR] Failed to process %s: %s\n", path.c_str(), strerror(errno)); ok = false; break; }
         }
         have += (size_t)n;
+        total_read += (size_t)n;
         if (n == 0) { send(std::move(buf), have); break; }
         if (have < batch_bytes) continue;
         // newline-aligned cut: scan up to the last '\n', carry the rest into the next batch's buffer
@@ -516,6 +520,7 @@ bool read_input(MatchPipeline& pl, size_t input, const std::string& path, size_t
     }
     if (gz) gzclose(zf);   // closes fd as well
     else if (fd) close(fd);
+    if (ok && !gz && fd != 0 && input < pl.consumed.size()) pl.consumed[input] = (long long)total_read;
     return ok;
 }
 
@@ -531,7 +536,9 @@ void follow_inputs(MatchPipeline& pl, matchy_scanner_t* sc, const std::vector<st
     std::vector<Tail> tails;
     for (size_t i = 0; i < paths.size(); ++i) {
         struct stat sb;
-        tails.push_back({paths[i], i, stat(paths[i].c_str(), &sb) == 0 ? sb.st_size : 0, false});
+        // from where the first pass stopped reading; inputs it could not count (.gz, unreadable): from their size now
+        const bool counted = i < pl.consumed.size() && pl.consumed[i] >= 0;
+        tails.push_back({paths[i], i, counted ? (off_t)pl.consumed[i] : (stat(paths[i].c_str(), &sb) == 0 ? sb.st_size : 0), false});
     }
     struct sigaction sa;
     memset(&sa, 0, sizeof(sa));
@@ -725,6 +732,7 @@ int cmd_match(int argc, char** argv) {
     std::vector<char> input_failed(paths.size(), 0);
     std::vector<char> read_failed(paths.size(), 0);   // written by this thread only (input_failed belongs to the printer until it is joined)
     std::thread printer([&] { pl.printer(t, input_failed); });
+    pl.consumed.assign(paths.size(), -1);
     for (size_t i = 0; i < paths.size(); ++i)
         if (!read_input(pl, i, paths[i], batch_bytes)) read_failed[i] = 1;
     pl.reader_done = true;
