@@ -502,3 +502,26 @@ def test_lowercase_table_covers_case_pairs_added_after_unicode_13(oracle):
     b.add_entry(pairs[4][0], {"k": 1})
     assert oracle.Database(b.build()).lookup(pairs[4][1])["data"] == [{"k": 1}]
     b.close()
+
+
+def _tree_kat():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_tree_kat", Path(__file__).parent / "golden" / "make_tree_kat.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.files()
+
+
+def test_tree_record_vectors_of_the_reference_pin_the_oracle_reader(oracle):
+    """mmdb/tree.rs:322-398 (test_read_24bit_record, test_read_28bit_record, test_calculate_data_offset) as whole files
+    (tests/golden/make_tree_kat.py, assembled here: the 28- and 32-bit files are ~32 MiB because records 0x1000001 / 0x2000002
+    are data pointers that far into the data section). The 28-bit node carries NON-ZERO high nibbles in its middle byte."""
+    for name, (blob, node0, queries) in _tree_kat().items():
+        odb = oracle.Database(blob)
+        for q, want in queries:
+            got = odb.lookup(q)
+            if want is None:
+                assert got == {"kind": "notfound"}, (name, q, got)
+            else:
+                assert got == {"kind": "ip", "prefix_len": want[0], "data": want[1]}, (name, q, got)
+        odb.close()

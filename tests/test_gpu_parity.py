@@ -1364,3 +1364,121 @@ def test_suffix_globs_take_the_suffix_filter(M, oracle, ci, first):
     b.close()
     assert M.lib().matchy_amd_suffix_filter(db.handle) == 0
     db.close()
+
+
+def _xmr_kat():
+    return json.loads((GOLD / "xmr_kat.json").read_text())
+
+
+def test_monero_accept_branch_against_constructed_vectors(M, gpu_extractor, oracle):
+    """E9 (lib.rs:1367-1409, 1895-1920): checksum-valid Monero tokens — constructed by tests/golden/make_xmr_kat.py from the rule,
+    not taken from the oracle — through matchy_extractor_extract_chunk: GPU == oracle == the construction; every accept with one
+    flipped character and with its last character flipped is a reject; accepts straddling the row (64 B), block (2 KiB) and
+    segment edges of the streaming pass, at the very end of the buffer, and two in a row."""
+    k = _xmr_kat()
+    for a in k["accept"]:
+        ab = a.encode()
+        for pre, post in ((b"pay ", b" now"), (b"", b""), (b"addr=", b"\n"), (b"[", b"]"), (b"\n", b"\n")):
+            buf = pre + ab + post
+            got = norm(gpu_extractor.extract_from_chunk(buf))
+            assert got == norm(oracle.extract(buf)), buf
+            assert [m for m in got if m[0] == "Monero"] == [("Monero", len(pre), len(pre) + len(a), a)], buf
+        buf = b"x" + ab
+        got = norm(gpu_extractor.extract_from_chunk(buf))
+        assert got == norm(oracle.extract(buf)) and not [m for m in got if m[0] == "Monero"]
+    for r in k["reject"]:
+        buf = b"pay " + r["text"].encode() + b" now\n"
+        got = norm(gpu_extractor.extract_from_chunk(buf))
+        assert got == norm(oracle.extract(buf)), r
+        assert not [m for m in got if m[0] == "Monero"], r
+    picks = [a for a in k["accept"] if len(a) in (95, 106)][:4] + [k["accept"][-1]]
+    for edge in (64, 256, 2048, 4096, 8192, 16384, 32768, 65536):
+        for a in picks:
+            ab = a.encode()
+            for shift in (0, 1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, len(ab) - 5, len(ab) - 4, len(ab) - 1, len(ab), len(ab) + 1):
+                pre = edge - shift
+                if pre < 1:
+                    continue
+                buf = b"a" * (pre - 1) + b" " + ab + b" tail\n"
+                got = norm(gpu_extractor.extract_from_chunk(buf))
+                assert got == norm(oracle.extract(buf)), (edge, a, shift)
+                assert ("Monero", pre, pre + len(ab), a) in got, (edge, a, shift)
+    for a in picks:
+        for pad in (0, 1, 15, 63, 64, 2047, 2048 - len(a)):
+            buf = b"x" * pad + b" " + a.encode()
+            got = norm(gpu_extractor.extract_from_chunk(buf))
+            assert got == norm(oracle.extract(buf)) and ("Monero", pad + 1, pad + 1 + len(a), a) in got, (a, pad)
+    buf = " ".join(k["accept"]).encode() + b"\n" + ",".join(r["text"] for r in k["reject"]).encode() + b"\n"
+    got = norm(gpu_extractor.extract_from_chunk(buf))
+    assert got == norm(oracle.extract(buf))
+    assert [m[3] for m in got if m[0] == "Monero"] == k["accept"]
+
+
+def test_monero_hits_through_scans_and_a_hash_dense_batch(M, oracle):
+    """The same vectors as DATABASE KEYS and log tokens: a small log through every scan entry (host buffer, device-resident
+    forked / sliced / submitted / compact), then spliced into a HASH-DENSE batch (k_validate<4> beside k_rare, > 256 K long-token
+    anchors) of the c2/10 database extended by the addresses. Every accept that is a key must be a hit, no reject may be."""
+    from tools import synth
+    k = _xmr_kat()
+    keys = k["accept"][::2]
+    b = M.DatabaseBuilder(build_epoch=1)
+    for i, a in enumerate(keys):
+        b.add_entry(a, {"coin": "xmr", "n": i})
+    b.add_entry("evil.com", {"why": "bad"})
+    b.add_entry("8.8.8.8", {"who": "dns"})
+    blob = b.build()
+    rows = [f"203.0.113.{i} paid {a} via evil.com" for i, a in enumerate(k["accept"])]
+    rows += [f"8.8.8.8 refused {r['text']}" for r in k["reject"]]
+    text = ("\n".join(rows) + "\n").encode()
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, text)
+    assert gs == ws and gh == wh and gl == wl
+    got_xmr = [text[h["start"]:h["end"]].decode() for h in gh if h["type"] == "Monero"]
+    assert got_xmr == keys
+
+    cfg = synth.config("c2/10")
+    b = M.DatabaseBuilder(build_epoch=1)
+    for key, data in synth.ioc_entries(cfg):
+        b.add_entry(key.decode(), json.loads(data))
+    for i, a in enumerate(keys):
+        b.add_entry(a, {"coin": "xmr", "n": i})
+    blob = b.build()
+    dense = synth.make_log(cfg, 3_000_000, 300000, shape="hash-dense")
+    lines = dense.split(b"\n")
+    everything = k["accept"] + [r["text"] for r in k["reject"]]
+    rng = random.Random(9)
+    for j, tok in enumerate(everything * 40):
+        at = rng.randrange(len(lines) - 1)
+        lines[at] = lines[at] + (b" xmr=" if j & 1 else b" ") + tok.encode()
+    dense = b"\n".join(lines)
+    db = M.Database(blob); sc = M.Scanner(db)
+    odb = oracle.Database(blob)
+    want, _, st = odb.scan(dense, threads=min(len(os.sched_getaffinity(0)), 16), cache=0, want_json=False)
+    n_xmr = sum(1 for h in want if h["type"] == "Monero")
+    assert n_xmr == 40 * len(keys) and st.candidates > 600000
+    res = sc.scan(dense)
+    assert (res.lines, res.candidates) == (st.lines, st.candidates)
+    assert res.hits() == want
+    res.close()
+    _device_entries(sc, dense, want, None, (st.lines, st.candidates), slices=(3,))
+    sc.close(); db.close()
+
+
+def test_tree_record_vectors_of_the_reference(M, oracle):
+    """mmdb/tree.rs:322-398 as whole files (tests/golden/make_tree_kat.py): node 0 holds exactly the bytes the reference's tests
+    write — 24-bit `000001 000002`, 28-bit `000001 12 000002` (records 0x1000001 / 0x2000002: non-zero high nibbles, data
+    pointers 16 and 32 MiB into the data section), the same two as 32-bit words, and test_calculate_data_offset's node_count 100 /
+    records 116 and 200. Single queries give the answers that follow from the construction; a scan equals the oracle's."""
+    from tests.test_builder_oracle import _tree_kat
+    for name, (blob, node0, queries) in _tree_kat().items():
+        db = M.Database(blob)
+        for q, want in queries:
+            got = db.lookup(q)
+            if want is None:
+                assert got is None, (name, q, got)
+            else:
+                assert got == {"found": True, "prefix_len": want[0], "data": want[1]}, (name, q, got)
+        db.close()
+        log = b"".join(b"%s - - [x] \"GET /a?from=%s HTTP/1.1\"\n" % (q.encode(), q.encode()) for q, _ in queries)
+        gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, log)
+        assert gs == ws and gh == wh and gl == wl
+        assert len(gh) == 2 * sum(1 for _, w in queries if w is not None)

@@ -475,3 +475,31 @@ def test_ipv4_lookup_table_variants(M, oracle, monkeypatch, env):
                 seen += 1
         assert seen > 20
         sc.close(); db.close()
+
+
+@pytest.mark.parametrize("shape", ["ip-dense", "url-heavy", "skewed-halves", "jsonl-app"])
+def test_log_shapes_through_every_device_entry(M, oracle, shape):
+    """The log shapes of `bench.py --log-shape` that are NOT nginx against the oracle at 300 K lines of the C2
+    database (100 K indicators), TWO consecutive batches through one scanner (the second batch runs with the grids and the
+    chunk sizes the first one's list lengths chose: `SparseWriter` chunks of 64 -> 512 slots, sentinel padding), then the
+    second batch through every device-resident entry — forked, sliced, submitted, compact records."""
+    from tools import synth
+    from tests.test_gpu_parity import _device_entries
+    cfg = synth.config("c2")
+    blob = synth.build_db(cfg)
+    db = M.Database(blob)
+    sc = M.Scanner(db)
+    odb = oracle.Database(blob)
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    last = None
+    for bi in range(2):
+        log = synth.make_log(cfg, 5_000_000 + bi * 300000, 300000, shape=shape)
+        want, _, st = odb.scan(log, threads=threads, cache=0, want_json=False)
+        res = sc.scan(log)
+        assert (res.lines, res.candidates) == (st.lines, st.candidates), (shape, bi)
+        assert res.hits() == want, (shape, bi)
+        res.close()
+        last = (log, want, (st.lines, st.candidates))
+    assert len(last[1]) > 1000
+    _device_entries(sc, last[0], last[1], None, last[2], slices=(3,))
+    sc.close(); db.close()

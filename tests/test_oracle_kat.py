@@ -96,3 +96,20 @@ def test_oracle_reproduces_config_golden(oracle, cfgname, lines):
     hits, ndjson, st = oracle.Database(synth.build_db(cfg)).scan(synth.make_log(cfg, 0, lines), source="access.log")
     assert (st.lines, st.candidates, len(ndjson)) == (head["lines"], head["candidates"], head["matches"])
     assert ndjson == want
+
+
+def test_monero_constructed_accepts_and_rejects(oracle):
+    """E9: checksum-VALID Monero tokens constructed from the rule itself (tests/golden/make_xmr_kat.py: whole-string Base58 +
+    Keccak-256, crates/matchy-extractor/src/lib.rs:1367-1409, 1895-1920; the reference's own test asserts nothing on accept)."""
+    k = json.loads((GOLD / "xmr_kat.json").read_text())
+    assert len(k["accept"]) >= 8 and {len(a) for a in k["accept"]} >= {95, 106} and {a[0] for a in k["accept"]} == {"4", "8"}
+    for a in k["accept"]:
+        for pre, post in ((b"pay ", b" now"), (b"", b""), (b"addr=", b"\n"), (b"[", b"]")):
+            buf = pre + a.encode() + post
+            got = [m for m in oracle.extract(buf) if m[0] == "Monero"]
+            assert got == [("Monero", len(pre), len(pre) + len(a), a)], buf
+        # glued to another token character the token is longer than the address: not a candidate, or a failing checksum
+        assert not [m for m in oracle.extract(b"x" + a.encode()) if m[0] == "Monero"]
+    for r in k["reject"]:
+        buf = b"pay " + r["text"].encode() + b" now"
+        assert not [m for m in oracle.extract(buf) if m[0] == "Monero"], r
