@@ -504,8 +504,7 @@ def main():
         barrier()
         if rank == 0:
             import numpy as np
-            pinned = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-            pinned.copy_(host[:nbytes])
+            import threading
             hv = host[:nbytes].numpy()
             cuts = [0]
             step_b = 256 << 20
@@ -515,33 +514,70 @@ def main():
                 cuts.append(want - (1 << 16) + int(back[-1]) + 1 if len(back) else want)
             cuts.append(nbytes)
             pieces = [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
-            devs = ([0] * world if rehearse else list(range(world))) * 2   # two scanners per GPU: one copies while the other post-processes
+            gpus = [0] * world if rehearse else list(range(world))
+            devs = gpus * 2   # two scanners per GPU: one copies while the other post-processes
+            # ONE pinned copy of the block PER NUMA NODE that has GPUs of this job, allocated and filled (first touch) by a thread
+            # bound to that node's CPUs: a GPU then pulls its batches from the memory of its own socket. (Round 4 fed every GPU from
+            # one buffer on rank 0's node: on a two-socket node half the copies crossed the socket link.) The main thread, which only
+            # submits and gathers, goes back to the process's whole affinity for this leg.
+            ML = M.lib()
+            node_of_gpu = [int(ML.matchy_amd_device_numa_node(g)) for g in gpus]
+            buffers = {}   # node -> pinned tensor
+
+            def alloc_on(node, gpu):
+                bound = int(ML.matchy_amd_bind_thread_to_device(gpu)) if not rehearse else 0
+                t = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+                t.copy_(host[:nbytes])
+                buffers[node] = (t, bound)
+
+            for node in sorted(set(node_of_gpu)):
+                th = threading.Thread(target=alloc_on, args=(node, gpus[node_of_gpu.index(node)]))
+                th.start(); th.join()
+            if not rehearse:
+                ML.matchy_amd_unbind_thread()
             ms = M.MultiScanner(db, devices=devs, extract_flags=args.extract_flags)
+            limit = ms.max_pending()
             times, sg_counts = [], None
             for rep in range(4):
                 tsg = time.perf_counter()
-                tl = tc = th = 0
-                n_sub = 0
-                for blk in range(world):
-                    for off, n in pieces:
-                        ms.submit_ptr(pinned.data_ptr() + off, n, tag=blk)
-                        n_sub += 1
-                for _ in range(n_sub):
+                tl = tc = th_ = 0
+
+                def take():
+                    nonlocal tl, tc, th_
                     b = ms.next()
-                    tl += b["lines"]; tc += b["candidates"]; th += b["n_hits"]
+                    tl += b["lines"]; tc += b["candidates"]; th_ += b["n_hits"]
+
+                for blk in range(world):
+                    node = node_of_gpu[blk]          # block `blk` is GPU blk's share of the job: it lives on that GPU's node
+                    base = buffers[node][0].data_ptr()
+                    for off, n in pieces:
+                        # one thread submits and gathers: take a batch back whenever the in-flight bound is reached (back-pressure:
+                        # at most 2 x workers + 2 batches exist between submit and next)
+                        while ms.pending() >= limit:
+                            take()
+                        ms.submit_ptr(base + off, n, tag=blk, numa_node=node)
+                while ms.pending():
+                    take()
                 times.append(time.perf_counter() - tsg)
-                sg_counts = (tl, tc, th)
+                sg_counts = (tl, tc, th_)
+            worker_numa = ms.worker_numa()
             ms.close()
             best = min(times[1:])
             scatter_gather = {"value": round(world * nbytes / best / 1e9, 2), "unit": "GB/s", "ms": round(best * 1e3, 2), "job_bytes": world * nbytes,
-                              "devices": devs, "batches": len(pieces) * world,
-                              "entry": "matchy_multi_scanner_submit / _next: one process, pinned host memory -> per-device H2D -> scan -> records gathered in submission order",
+                              "devices": devs, "batches": len(pieces) * world, "max_pending": limit,
+                              "numa": {"buffers": [{"node": n_, "bytes": nbytes, "allocating_thread_cpus": b_[1]} for n_, b_ in sorted(buffers.items())],
+                                       "gpu_nodes": node_of_gpu,
+                                       "workers": [{"device": devs[w], "node": wn[0], "cpus_bound": wn[1]} for w, wn in enumerate(worker_numa)]},
+                              "entry": "matchy_multi_scanner_submit_near / _next: one process, one pinned copy of the block per NUMA node -> per-device H2D from the local node -> scan -> records gathered in submission order",
                               "same_counts": bool(sg_counts == (world * counts[0], world * counts[1], world * counts[2]))}
-            del pinned
+            buffers.clear()
+            if not rehearse:
+                ML.matchy_amd_bind_thread_to_device(local_rank)
         barrier()
 
     cpu = None
     cpu_t1 = None
+    cpu_all = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu:
         # ---- CPU baseline: the oracle ("port" of the reference CPU path) on a bounded sample of the SAME log,
@@ -561,6 +597,18 @@ def main():
                "affinity_cpus": len(os.sched_getaffinity(0)),
                "sample": f"first {n_cpu_lines} lines ({len(sample)} B) of the same log, {cores} threads, 256 KiB newline-aligned chunks, LRU 10000",
                "lines_per_s": round(st.lines / st.seconds, 1)}
+        # ... and at T = every CPU this process may run on (SURVEY §8d "T = all host cores"; reference: available_parallelism workers,
+        # crates/matchy/src/bin/match_processor/parallel.rs:134-138 and the chunk sizes of processing/parallel.rs:107-123). On the GPU
+        # boxes the affinity mask is the whole machine while the pod's CPU share is smaller: the figure is what the box gives THIS
+        # process with that many threads, `cores` says how many were started.
+        all_cores = len(os.sched_getaffinity(0))
+        if all_cores != cores:
+            _, _, sta = odb.scan(sample, threads=all_cores, cache=10000, want_json=False)
+            cpu_all = {"value": round(len(sample) / sta.seconds / 1e9, 4), "unit": "GB/s", "cores": all_cores, "kind": "port",
+                       "sample": f"the same {n_cpu_lines} lines, {all_cores} threads (= affinity_cpus), 256 KiB newline-aligned chunks, LRU 10000",
+                       "lines_per_s": round(sta.lines / sta.seconds, 1)}
+        else:
+            cpu_all = dict(cpu, sample=cpu["sample"] + " (= affinity_cpus: the same run)")
         # the same path on ONE core (T = all cores and T = 1), on a tenth of the sample
         n1 = max(1, n_cpu_lines // 10)
         s1_end = int(nl[n1 - 1]) + 1 if len(nl) >= n1 else sample_end
@@ -615,6 +663,12 @@ def main():
                                   "frac": round(pipe_achieved / HBM_PEAK_GBS, 4), "kernels_ms": round(pipe_ms, 4)},
             "cpu_baseline": cpu,
             "cpu_baseline_t1": cpu_t1,
+            "cpu_baseline_all": cpu_all,
+            # what the reference documents for itself (unstated hardware) — the oracle port above is a restatement, not the
+            # Rust binary, and its single-thread rate is below these ranges: read the GPU/CPU ratio against BOTH
+            "reference_documented": {"extractor_single_thread_MBps": "~450 (DEVELOPMENT.md:266)", "match_sequential_MBps": "200-500 (book/src/commands/matchy-match.md:343)",
+                                     "match_parallel_MBps": "400-2000 depending on core count (matchy-match.md:344)",
+                                     "extract_plus_lookup_MBps": "100-300 (book/src/guide/querying.md:187)"} if cpu else None,
             "end_to_end": end_to_end,
             "scatter_gather": scatter_gather,
             "numa": numa,

@@ -351,10 +351,12 @@ int32_t matchy_amd_device_count(void);
 /* Host topology for multi-GPU scatter / gather (every GPU is fed from host memory over its own PCIe link, and on a
  * two-socket node the H2D rate depends on which socket the feeding thread runs on). NUMA node of a device's PCI function
  * (hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<id>/numa_node; -1 = the platform does not say), and binding of the CALLING thread to
- * the CPUs of that node (sched_setaffinity within the thread's current mask; returns the CPUs it may run on afterwards, 0 = unchanged).
+ * the CPUs of that node (sched_setaffinity within the PROCESS's affinity as it was when the library was loaded — not the thread's current
+ * mask, which a creating thread may already have narrowed to another node; returns the CPUs it may run on afterwards, 0 = unchanged).
  * matchy_amd_numa_cpus is the mapping itself over any sysfs root (tests): CPUs near `pci_bus_id`, count returned, first `cap` stored. */
 int32_t matchy_amd_device_numa_node(int32_t device);
 int32_t matchy_amd_bind_thread_to_device(int32_t device);
+int32_t matchy_amd_unbind_thread(void); /* back to the process's affinity at load time; CPUs afterwards, 0 = unchanged */
 int32_t matchy_amd_numa_cpus(const char *sysfs_root, const char *pci_bus_id, int32_t *out_cpus, size_t cap);
 
 /* ---- Multi-device scanner (additive). The reader -> workers -> ordered gather of the reference's process_files_parallel
@@ -389,9 +391,22 @@ size_t matchy_multi_scanner_workers(const matchy_multi_scanner_t *ms);
 matchy_scanner_t *matchy_multi_scanner_worker_scanner(const matchy_multi_scanner_t *ms, size_t worker);
 void matchy_multi_scanner_set_batch_hook(matchy_multi_scanner_t *ms, matchy_multi_batch_fn fn, void *user);
 /* Queue one batch (it should end at a line end; len < 4 GiB). The bytes stay the caller's and must remain valid until the batch has
- * been taken with _next. Blocks while one batch per worker is already waiting. pinned_range: NULL, or the page range the caller
- * registered for this batch with matchy_amd_host_register — the worker unregisters it after the scan. */
+ * been taken with _next. BACK-PRESSURE (the reference's bounded channels, processing/parallel.rs:563-577): blocks while one batch
+ * per worker is already waiting, and while matchy_multi_scanner_max_pending() batches (2 x workers + 2) are out — submitted and not
+ * yet taken with _next, finished or not. Submit from one thread and gather from another, or interleave on one thread: call _next
+ * whenever matchy_multi_scanner_pending() has reached the maximum (a lone thread that only submits would block for good).
+ * pinned_range: NULL, or the page range the caller registered for this batch with matchy_amd_host_register — the worker unregisters it
+ * after the scan (if submit FAILS the range is still the caller's to unregister). */
 int32_t matchy_multi_scanner_submit(matchy_multi_scanner_t *ms, const uint8_t *data, size_t len, void *tag, const void *pinned_range);
+/* The same with the NUMA node the batch's bytes live on (-1 = anywhere = matchy_multi_scanner_submit): a worker whose GPU hangs off
+ * that node takes it first, a worker of another node only when it has nothing of its own. */
+int32_t matchy_multi_scanner_submit_near(matchy_multi_scanner_t *ms, const uint8_t *data, size_t len, void *tag, const void *pinned_range,
+                                         int32_t numa_node);
+/* NUMA node of a worker's GPU (-1 = unknown) and the number of CPUs its thread bound itself to (0 = not bound); valid once the
+ * worker thread has started (after the first _next at the latest). */
+int32_t matchy_multi_scanner_worker_numa(const matchy_multi_scanner_t *ms, size_t worker, int32_t *node, int32_t *cpus_bound);
+size_t matchy_multi_scanner_pending(const matchy_multi_scanner_t *ms);     /* submitted and not yet taken */
+size_t matchy_multi_scanner_max_pending(const matchy_multi_scanner_t *ms); /* the bound submit blocks on */
 /* The next batch in submission order (blocks until it is done): 1 = *out filled, 0 = nothing pending, < 0 = error. */
 int32_t matchy_multi_scanner_next(matchy_multi_scanner_t *ms, matchy_multi_batch_t *out);
 /* One buffer through all workers, cut at newlines into pieces of batch_bytes (0 = chosen from len and the worker count), merged into

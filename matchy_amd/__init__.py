@@ -46,6 +46,8 @@ EXPORTED_SYMBOLS = [
     "matchy_amd_device_numa_node", "matchy_amd_bind_thread_to_device", "matchy_amd_numa_cpus",
     "matchy_multi_scanner_create", "matchy_multi_scanner_free", "matchy_multi_scanner_workers", "matchy_multi_scanner_worker_scanner",
     "matchy_multi_scanner_set_batch_hook", "matchy_multi_scanner_submit", "matchy_multi_scanner_next", "matchy_multi_scanner_scan",
+    "matchy_multi_scanner_pending", "matchy_multi_scanner_max_pending", "matchy_multi_scanner_submit_near", "matchy_multi_scanner_worker_numa",
+    "matchy_amd_unbind_thread",
     "matchy_multi_scanner_scan_file", "matchy_scan_result_to_ndjson",
 ]
 
@@ -200,6 +202,11 @@ def lib():
         "matchy_multi_scanner_worker_scanner": (vp, [vp, C.c_size_t]),
         "matchy_multi_scanner_submit": (C.c_int32, [vp, vp, C.c_size_t, vp, vp]),
         "matchy_multi_scanner_next": (C.c_int32, [vp, C.POINTER(_MultiBatch)]),
+        "matchy_multi_scanner_submit_near": (C.c_int32, [vp, vp, C.c_size_t, vp, vp, C.c_int32]),
+        "matchy_multi_scanner_worker_numa": (C.c_int32, [vp, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+        "matchy_multi_scanner_pending": (C.c_size_t, [vp]),
+        "matchy_multi_scanner_max_pending": (C.c_size_t, [vp]),
+        "matchy_amd_unbind_thread": (C.c_int32, []),
         "matchy_multi_scanner_scan": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(_ScanResult)]),
         "matchy_multi_scanner_scan_file": (C.c_int32, [vp, cp, C.c_size_t, _MULTI_ORDERED_FN, vp, C.POINTER(_MultiTotals)]),
     }
@@ -595,11 +602,28 @@ class MultiScanner:
             raise RuntimeError(f"matchy_multi_scanner_scan failed ({rc}): " + last_error())
         return ScanResult(_WorkerScanner(lib().matchy_multi_scanner_worker_scanner(self._h, 0)), raw)
 
-    def submit_ptr(self, host_ptr: int, nbytes: int, tag: int = 0):
-        """queue one newline-aligned batch that lives at a host address (e.g. a pinned torch tensor); take it back with next()"""
-        rc = lib().matchy_multi_scanner_submit(self._h, host_ptr, nbytes, tag, None)
+    def submit_ptr(self, host_ptr: int, nbytes: int, tag: int = 0, numa_node: int = -1):
+        """queue one newline-aligned batch that lives at a host address (e.g. a pinned torch tensor); take it back with next().
+        Blocks while max_pending() batches are out: a caller that submits and gathers on one thread calls next() when
+        pending() has reached max_pending(). numa_node: the node the bytes live on (-1 = anywhere)."""
+        rc = lib().matchy_multi_scanner_submit_near(self._h, host_ptr, nbytes, tag, None, numa_node)
         if rc != 0:
             raise RuntimeError(f"matchy_multi_scanner_submit failed ({rc}): " + last_error())
+
+    def pending(self) -> int:
+        return lib().matchy_multi_scanner_pending(self._h)
+
+    def max_pending(self) -> int:
+        return lib().matchy_multi_scanner_max_pending(self._h)
+
+    def worker_numa(self):
+        """[(NUMA node of the worker's GPU, CPUs its thread is bound to)] per worker"""
+        out = []
+        for w in range(self.workers):
+            node, cpus = C.c_int32(-1), C.c_int32(0)
+            lib().matchy_multi_scanner_worker_numa(self._h, w, C.byref(node), C.byref(cpus))
+            out.append((node.value, cpus.value))
+        return out
 
     def next(self, want_hits=False):
         """the next batch in submission order: dict(seq, tag, worker, lines, candidates, n_hits[, hits]) or None when nothing is pending"""

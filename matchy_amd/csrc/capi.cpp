@@ -988,10 +988,19 @@ int32_t matchy_scan_result_to_ndjson(matchy_scanner_t* s, const matchy_scan_resu
     try {
         if (nt == 1) render(0, n, pieces[0], true);
         else {
+            // An exception must not leave a render thread (std::terminate), and none may leave this scope while a thread is still
+            // joinable: every piece catches its own, the joiner runs on every way out, the first failure is rethrown afterwards.
+            std::atomic<bool> failed{false};
             std::vector<std::thread> th;
-            for (unsigned t = 1; t < nt; ++t) th.emplace_back([&, t] { render(n * t / nt, n * (t + 1) / nt, pieces[t], false); });
-            render(0, n / nt, pieces[0], false);
+            struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{th};
+            auto guarded = [&](size_t i0, size_t i1, Piece& pc) {
+                try { render(i0, i1, pc, false); } catch (...) { failed.store(true); }
+            };
+            th.reserve(nt);
+            for (unsigned t = 1; t < nt; ++t) th.emplace_back([&, t] { guarded(n * t / nt, n * (t + 1) / nt, pieces[t]); });
+            guarded(0, n / nt, pieces[0]);
             for (auto& x : th) x.join();
+            if (failed.load()) throw std::bad_alloc();
             for (Piece& pc : pieces)
                 for (auto& e : pc.fresh) {
                     if (sh->json_of_data.size() > (1u << 20)) sh->json_of_data.clear();
@@ -1005,14 +1014,18 @@ int32_t matchy_scan_result_to_ndjson(matchy_scanner_t* s, const matchy_scan_resu
     if (!buf) { set_error("matchy_scan_result_to_ndjson: out of memory"); return MATCHY_ERROR_OUT_OF_MEMORY; }
     {
         std::vector<std::thread> th;
+        struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{th};
         size_t at = 0;
         for (unsigned t = 0; t < nt; ++t) {
             char* dst = buf + at;
             at += pieces[t].o.size();
-            if (t + 1 < nt) th.emplace_back([dst, &pieces, t] { memcpy(dst, pieces[t].o.data(), pieces[t].o.size()); });
-            else memcpy(dst, pieces[t].o.data(), pieces[t].o.size());
+            bool spawned = false;
+            if (t + 1 < nt) {
+                try { th.emplace_back([dst, &pieces, t] { memcpy(dst, pieces[t].o.data(), pieces[t].o.size()); }); spawned = true; }
+                catch (...) {}   // no thread to be had: copy here
+            }
+            if (!spawned) memcpy(dst, pieces[t].o.data(), pieces[t].o.size());
         }
-        for (auto& x : th) x.join();
     }
     buf[total] = 0;
     *out = buf; *out_len = total;
@@ -1028,7 +1041,7 @@ int32_t matchy_scan_result_to_ndjson(matchy_scanner_t* s, const matchy_scan_resu
 }  // extern "C"
 
 namespace {
-struct MultiJob { size_t seq; const uint8_t* data; size_t len; void* tag; const void* pinned; };
+struct MultiJob { size_t seq; const uint8_t* data; size_t len; void* tag; const void* pinned; int32_t node; };   // node: NUMA node the bytes live on, -1 = anywhere
 struct MultiDone { int32_t status = MATCHY_SUCCESS; matchy_scan_result_t res{}; const uint8_t* data = nullptr; size_t len = 0; void* tag = nullptr; void* payload = nullptr; size_t worker = 0; };
 struct MultiScanner {
     const matchy_t* db = nullptr;
@@ -1041,23 +1054,39 @@ struct MultiScanner {
     std::deque<MultiJob> q;
     std::map<size_t, MultiDone> done;
     size_t submitted = 0, taken = 0, max_q = 2;
+    // END-TO-END back-pressure (the reference bounds its channels for the same reason, processing/parallel.rs:563-577 "prevent memory
+    // explosion"): at most max_inflight batches exist between submit() and next() — queued, being scanned, or finished and not yet
+    // taken. Without it a slow consumer of next() (a blocked stdout) lets the reader buffer the whole input and every result.
+    size_t max_inflight = 4;
     bool closing = false;
     matchy_multi_batch_fn hook = nullptr;
     void* hook_user = nullptr;
     std::string first_error;   // of a worker (scanner creation, scan): reported through matchy_amd_last_error by next()
 
+    std::vector<int32_t> worker_node, worker_cpus;   // NUMA node of each worker's GPU (-1 unknown), CPUs its thread was bound to (0 = unbound)
+
     void worker(size_t w) {
-        // this thread faults its batches' pages in, pins them and queues their copies: on the NUMA node of its GPU
+        // this thread faults its batches' pages in, pins them and queues their copies: on the NUMA node of its GPU (the binding is
+        // taken against the process's affinity at load time, host_topology.cpp: whoever created this thread may have bound itself)
         static const bool no_bind = getenv("MATCHY_AMD_NO_NUMA_BIND") != nullptr;
-        if (!no_bind) (void)matchy_amd_bind_thread_to_device(devices[w]);
+        {
+            const int32_t node = matchy_amd_device_numa_node(devices[w]);
+            const int32_t cpus = no_bind ? 0 : matchy_amd_bind_thread_to_device(devices[w]);
+            std::lock_guard<std::mutex> lk(mu);
+            worker_node[w] = node; worker_cpus[w] = cpus;
+        }
         for (;;) {
             MultiJob j;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_work.wait(lk, [&] { return closing || !q.empty(); });
                 if (q.empty()) return;
-                j = q.front();
-                q.pop_front();
+                // a batch whose bytes live on this worker's node (or anywhere) first — the copy then stays off the socket link; a worker
+                // with nothing of its own takes the oldest batch of another node rather than idling
+                auto it = q.begin();
+                for (auto k = q.begin(); k != q.end(); ++k) if (k->node < 0 || k->node == worker_node[w]) { it = k; break; }
+                j = *it;
+                q.erase(it);
                 cv_space.notify_one();
             }
             MultiDone d;
@@ -1092,10 +1121,11 @@ int32_t matchy_amd_bind_thread_to_device(int32_t device) {
     if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return mxy::bind_calling_thread(mxy::cpus_near_pci("/sys", bus));
 }
+int32_t matchy_amd_unbind_thread(void) { return mxy::unbind_calling_thread(); }
 int32_t matchy_amd_numa_cpus(const char* sysfs_root, const char* pci_bus_id, int32_t* out, size_t cap) {
     if (!sysfs_root || !pci_bus_id) return -1;
     const std::vector<int> cpus = mxy::cpus_near_pci(sysfs_root, pci_bus_id);
-    for (size_t i = 0; i < cpus.size() && i < cap; ++i) out[i] = cpus[i];
+    if (out) for (size_t i = 0; i < cpus.size() && i < cap; ++i) out[i] = cpus[i];
     return (int32_t)cpus.size();
 }
 
@@ -1106,7 +1136,10 @@ matchy_multi_scanner_t* matchy_multi_scanner_create(const matchy_t* db, uint32_t
     if (!devices || !n_devices) ms->devices.push_back(reinterpret_cast<const Db*>(db)->default_device);
     else for (size_t i = 0; i < n_devices; ++i) { if (devices[i] < 0) { set_error("matchy_multi_scanner_create: negative device"); return nullptr; } ms->devices.push_back(devices[i]); }
     ms->scanners.assign(ms->devices.size(), nullptr);
+    ms->worker_node.assign(ms->devices.size(), -1);
+    ms->worker_cpus.assign(ms->devices.size(), 0);
     ms->max_q = ms->devices.size() + 1;
+    ms->max_inflight = 2 * ms->devices.size() + 2;
     // the first scanner now, so that a database or device that cannot be used fails here; the others are created by their workers
     // when the first batch reaches them (a small input never pays for scanners it does not use)
     ms->scanners[0] = matchy_scanner_create(db, extract_flags, ms->devices[0]);
@@ -1136,14 +1169,34 @@ void matchy_multi_scanner_set_batch_hook(matchy_multi_scanner_t* h, matchy_multi
     ms->hook = fn; ms->hook_user = user;
 }
 int32_t matchy_multi_scanner_submit(matchy_multi_scanner_t* h, const uint8_t* data, size_t len, void* tag, const void* pinned_range) {
+    return matchy_multi_scanner_submit_near(h, data, len, tag, pinned_range, -1);
+}
+int32_t matchy_multi_scanner_worker_numa(const matchy_multi_scanner_t* h, size_t worker, int32_t* node, int32_t* cpus_bound) {
+    MultiScanner* ms = const_cast<MultiScanner*>(reinterpret_cast<const MultiScanner*>(h));
+    if (!ms || worker >= ms->devices.size()) return MATCHY_ERROR_INVALID_PARAM;
+    std::lock_guard<std::mutex> lk(ms->mu);
+    if (node) *node = ms->worker_node[worker];
+    if (cpus_bound) *cpus_bound = ms->worker_cpus[worker];
+    return MATCHY_SUCCESS;
+}
+int32_t matchy_multi_scanner_submit_near(matchy_multi_scanner_t* h, const uint8_t* data, size_t len, void* tag, const void* pinned_range, int32_t numa_node) {
     if (!h || (!data && len) || len > 0xFFFFFFFFull) return MATCHY_ERROR_INVALID_PARAM;
     MultiScanner* ms = reinterpret_cast<MultiScanner*>(h);
     std::unique_lock<std::mutex> lk(ms->mu);
-    ms->cv_space.wait(lk, [&] { return ms->q.size() < ms->max_q; });
-    ms->q.push_back(MultiJob{ms->submitted++, data, len, tag, pinned_range});
+    // blocks while the job queue is full OR max_inflight batches are out (someone has to call matchy_multi_scanner_next: a caller that
+    // submits and gathers on ONE thread interleaves the two — matchy_multi_scanner_pending() tells it when a next() is due)
+    ms->cv_space.wait(lk, [&] { return ms->q.size() < ms->max_q && ms->submitted - ms->taken < ms->max_inflight; });
+    ms->q.push_back(MultiJob{ms->submitted++, data, len, tag, pinned_range, numa_node});
     ms->cv_work.notify_one();
     return MATCHY_SUCCESS;
 }
+size_t matchy_multi_scanner_pending(const matchy_multi_scanner_t* h) {
+    if (!h) return 0;
+    MultiScanner* ms = const_cast<MultiScanner*>(reinterpret_cast<const MultiScanner*>(h));
+    std::lock_guard<std::mutex> lk(ms->mu);
+    return ms->submitted - ms->taken;
+}
+size_t matchy_multi_scanner_max_pending(const matchy_multi_scanner_t* h) { return h ? reinterpret_cast<const MultiScanner*>(h)->max_inflight : 0; }
 int32_t matchy_multi_scanner_next(matchy_multi_scanner_t* h, matchy_multi_batch_t* out) {
     if (!h || !out) return MATCHY_ERROR_INVALID_PARAM;
     MultiScanner* ms = reinterpret_cast<MultiScanner*>(h);
@@ -1153,6 +1206,7 @@ int32_t matchy_multi_scanner_next(matchy_multi_scanner_t* h, matchy_multi_batch_
     const MultiDone d = ms->done[ms->taken];
     ms->done.erase(ms->taken);
     out->seq = ms->taken++;
+    ms->cv_space.notify_all();
     out->status = d.status; out->result = d.res; out->data = d.data; out->len = d.len; out->tag = d.tag; out->payload = d.payload; out->worker = d.worker;
     if (d.status != MATCHY_SUCCESS) set_error(ms->first_error.empty() ? "multi scanner: a batch failed" : ms->first_error);
     return 1;
@@ -1173,9 +1227,10 @@ int32_t matchy_multi_scanner_scan(matchy_multi_scanner_t* h, const uint8_t* data
     uint64_t lines = 0, cands = 0;
     int32_t status = MATCHY_SUCCESS;
     std::string err;
-    auto take = [&](bool all) {
+    enum { READY = 0, ALL = 1, ONE = 2 };   // the finished ones / everything pending / exactly the next one (blocking)
+    auto take_mode = [&](int mode) {
         for (;;) {
-            { std::lock_guard<std::mutex> lk(ms->mu); if (ms->taken == ms->submitted) return; if (!all && !ms->done.count(ms->taken)) return; }
+            { std::lock_guard<std::mutex> lk(ms->mu); if (ms->taken == ms->submitted) return; if (mode == READY && !ms->done.count(ms->taken)) return; }
             matchy_multi_batch_t b;
             if (matchy_multi_scanner_next(h, &b) != 1) return;
             if (b.status != MATCHY_SUCCESS) { if (status == MATCHY_SUCCESS) { status = b.status; err = matchy_amd_last_error(); } }
@@ -1192,8 +1247,11 @@ int32_t matchy_multi_scanner_scan(matchy_multi_scanner_t* h, const uint8_t* data
                 lines += b.result.lines; cands += b.result.candidates;
             }
             matchy_scan_result_free(&b.result);
+            if (mode == ONE) return;
         }
     };
+    auto take = [&](bool all) { take_mode(all ? ALL : READY); };
+    auto take_one = [&] { take_mode(ONE); };
     for (size_t pos = 0; pos < len;) {
         size_t end = std::min(len, pos + batch_bytes);
         if (end < len) {   // newline-aligned cut; a line longer than the piece extends it to that line's end
@@ -1201,7 +1259,10 @@ int32_t matchy_multi_scanner_scan(matchy_multi_scanner_t* h, const uint8_t* data
             if (nl) end = (size_t)((const uint8_t*)nl - data) + 1;
             else { const void* fw = memchr(data + end, '\n', len - end); end = fw ? (size_t)((const uint8_t*)fw - data) + 1 : len; }
         }
-        matchy_multi_scanner_submit(h, data + pos, end - pos, nullptr, nullptr);
+        // this thread submits AND gathers: make room before a submit that would block on the in-flight bound
+        while (matchy_multi_scanner_pending(h) >= ms->max_inflight) take_one();
+        const int32_t src = matchy_multi_scanner_submit(h, data + pos, end - pos, nullptr, nullptr);
+        if (src != MATCHY_SUCCESS) { if (status == MATCHY_SUCCESS) { status = src; err = "matchy_multi_scanner_scan: a line of 4 GiB or more cannot be submitted"; } break; }
         pos = end;
         take(false);
     }
@@ -1257,7 +1318,11 @@ int32_t matchy_multi_scanner_scan_file(matchy_multi_scanner_t* h, const char* pa
 #endif
                     if (z > a && matchy_amd_host_register((const void*)a, z - a) == MATCHY_SUCCESS) pinned = (const void*)a;
                 }
-                matchy_multi_scanner_submit(h, p, n, (void*)(uintptr_t)pos, pinned);
+                if (matchy_multi_scanner_submit(h, p, n, (void*)(uintptr_t)pos, pinned) != MATCHY_SUCCESS) {   // a line of 4 GiB or more
+                    if (pinned) matchy_amd_host_unregister(pinned);
+                    reader_ok = false;
+                    return;
+                }
                 pos = end;
             }
             return;
@@ -1280,8 +1345,9 @@ int32_t matchy_multi_scanner_scan_file(matchy_multi_scanner_t* h, const char* pa
             uint8_t* nxt = nullptr;
             const size_t rest = have - cut;
             if (!eof) { nxt = (uint8_t*)malloc(std::max(batch_bytes, rest) + 16); if (!nxt) { reader_ok = false; break; } memcpy(nxt, buf + cut, rest); }
-            if (cut) matchy_multi_scanner_submit(h, buf, cut, (void*)(uintptr_t)off, nullptr);
-            else free(buf);
+            if (cut) {
+                if (matchy_multi_scanner_submit(h, buf, cut, (void*)(uintptr_t)off, nullptr) != MATCHY_SUCCESS) { free(buf); free(nxt); buf = nullptr; reader_ok = false; break; }
+            } else free(buf);
             off += cut;
             buf = nxt; cap = std::max(batch_bytes, rest) + 16; have = rest;
             if (eof || stop) break;

@@ -340,6 +340,7 @@ struct MatchPipeline {
         if (matchy_multi_scanner_submit(ms, hb->ptr, hb->len, hb, hb->reg) != MATCHY_SUCCESS) {
             // not queued (cannot happen for batches below 4 GiB): the printer never sees it
             fprintf(stderr, "[ERROR] batch of %zu bytes rejected: %s\n", hb->len, matchy_amd_last_error());
+            { std::lock_guard<std::mutex> lk(mu); rejected_inputs.push_back(hb->input); }   // its matches are missing: the input counts as failed
             if (hb->reg) matchy_amd_host_unregister(hb->reg);
             delete hb;
         }
@@ -350,6 +351,7 @@ struct MatchPipeline {
     // files instead of behind the last one.
     // bytes of each input the first pass has read: where --follow starts watching (a size taken AFTER that pass would skip what was appended in between)
     std::vector<long long> consumed;
+    std::vector<size_t> rejected_inputs;   // guarded by mu: inputs with a batch the library did not take
     struct Mapping { void* p; size_t len; size_t last_seq; bool released; };
     std::vector<Mapping> mappings;   // guarded by mu
     void add_mapping(void* p, size_t len, size_t last_seq) { std::lock_guard<std::mutex> lk(mu); mappings.push_back({p, len, last_seq, false}); }
@@ -418,6 +420,7 @@ struct MatchPipeline {
                 fprintf(stderr, "[ERROR] scan failed: %s\n", matchy_amd_last_error());
                 input_failed[hb->input] = 1;
             } else if (d) {
+                if (!d->ok) input_failed[hb->input] = 1;   // rendering failed in the batch hook: the batch's matches are missing, exit status says so
                 if (d->text_len) write_all_stdout(d->text, d->text_len);
                 total.lines += d->t.lines; total.lines_with_matches += d->t.lines_with_matches; total.matches += d->t.matches;
                 total.candidates += d->t.candidates; total.bytes += d->t.bytes;
@@ -738,6 +741,7 @@ int cmd_match(int argc, char** argv) {
     pl.reader_done = true;
     printer.join();
     for (size_t i = 0; i < paths.size(); ++i) if (read_failed[i]) input_failed[i] = 1;
+    for (size_t i : pl.rejected_inputs) if (i < input_failed.size()) input_failed[i] = 1;
     fflush(stdout);
     if (trace) fprintf(stderr, "[matchy] all batches done after %.1f ms\n", since0());
     pl.release_mappings((size_t)-1);

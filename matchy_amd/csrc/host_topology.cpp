@@ -72,19 +72,36 @@ std::vector<int> cpus_near_pci(const std::string& sysfs_root, const std::string&
     return cpus_of_node(sysfs_root, numa_node_of_pci(sysfs_root, pci_bus_id));
 }
 
-// Restrict the calling thread to `cpus` ∩ its current affinity (a container's cpuset stays in force); returns the number of CPUs
-// the thread may run on afterwards, 0 when nothing was changed (empty list, empty intersection, or the call failed).
+// The affinity of the PROCESS as it was when this library was loaded (a container's cpuset, a launcher's taskset). Bindings are taken
+// relative to it, not to the calling thread's current mask: a thread created by one that had already bound itself to GPU 0's node
+// inherits that node's CPUs, and an intersection with them is empty for every GPU of the other socket (round-4 advisor finding:
+// half the scatter/gather workers of a two-socket node stayed on the wrong socket).
+static cpu_set_t initial_affinity() {
+    cpu_set_t s;
+    CPU_ZERO(&s);
+    if (sched_getaffinity(0, sizeof(s), &s) != 0) CPU_ZERO(&s);
+    return s;
+}
+static const cpu_set_t g_initial = initial_affinity();   // runs at load time (dlopen / program start), before any binding of ours
+
+// Restrict the calling thread to `cpus` ∩ the process's initial affinity (a container's cpuset stays in force); returns the number of
+// CPUs the thread may run on afterwards, 0 when nothing was changed (empty list, empty intersection, or the call failed).
 int bind_calling_thread(const std::vector<int>& cpus) {
     if (cpus.empty()) return 0;
-    cpu_set_t cur, want;
-    CPU_ZERO(&cur);
-    if (sched_getaffinity(0, sizeof(cur), &cur) != 0) return 0;
+    cpu_set_t want;
     CPU_ZERO(&want);
     int n = 0;
-    for (int c : cpus) if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &cur)) { CPU_SET(c, &want); ++n; }
+    for (int c : cpus) if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &g_initial)) { CPU_SET(c, &want); ++n; }
     if (n == 0) return 0;
     if (sched_setaffinity(0, sizeof(want), &want) != 0) return 0;
     return n;
+}
+
+// Back to the process's initial affinity (a thread that bound itself for one allocation and goes on to other work)
+int unbind_calling_thread() {
+    if (CPU_COUNT(&g_initial) == 0) return 0;
+    if (sched_setaffinity(0, sizeof(g_initial), &g_initial) != 0) return 0;
+    return CPU_COUNT(&g_initial);
 }
 
 }  // namespace mxy
