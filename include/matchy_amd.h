@@ -110,7 +110,9 @@ matchy_t *matchy_open(const char *filename);                                    
 matchy_t *matchy_open_buffer(const uint8_t *buffer, uintptr_t size);                             /* matchy.h:863 (copies the buffer) */
 void matchy_close(matchy_t *db);                                                                 /* matchy.h:938 (NULL-safe) */
 
-/* ---- query (c_api/matchy.rs:1100-1239; matchy.h:980-1034). One query = one device lookup. */
+/* ---- query (c_api/matchy.rs:1100-1239; matchy.h:980-1034). A single query is answered on the HOST (csrc/host_lookup.cpp: trie walk,
+ * literal probe, Paraglob::find_all over the mapped sections; SURVEY §8b "single queries stay on the CPU path"): a kernel launch would cost
+ * tens of microseconds where the reference answers in 0.2. Bulk work — matchy_scanner_*, matchy_extractor_extract_chunk — runs the HIP kernels. */
 matchy_result_t matchy_query(const matchy_t *db, const char *query);                    /* matchy.h:980 */
 void matchy_query_into(const matchy_t *db, const char *query, matchy_result_t *result); /* matchy.h:1008 */
 void matchy_free_result(matchy_result_t *result);                                       /* matchy.h:1022 */

@@ -316,6 +316,18 @@ class Database:
         finally:
             L.matchy_free_result(C.byref(r))
 
+    def query_json(self, query: str):
+        """what `matchy query DB QUERY` prints (matchy_amd_query_json): (found, list) — one object per pattern that carries data
+        (literal first, then globs by id), or one object for an IP hit with "cidr" and "prefix_len" added; [] when nothing matches"""
+        L = lib()
+        found = C.c_int32(0)
+        L.matchy_amd_query_json.restype = C.c_void_p
+        L.matchy_amd_query_json.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]
+        p = L.matchy_amd_query_json(self._h, query.encode("utf-8") if isinstance(query, str) else bytes(query), C.byref(found))
+        if not p:
+            raise RuntimeError("matchy_amd_query_json failed: " + last_error())
+        return bool(found.value), json.loads(_take_string(p))
+
     @staticmethod
     def _entry_value(ed):
         """matchy_entry_data_t -> (type, python value); maps / arrays yield their element count."""

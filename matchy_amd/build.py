@@ -10,7 +10,7 @@ LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libmatchy_amd.so"
 BINDIR = PKG / "bin"
 CLI = BINDIR / "matchy"
-SOURCES = ["k_anchor.hip", "validate_kernels.hip", "lookup_kernels.hip", "sort_hits.hip", "ip_tables.hip", "engine.cpp", "db_image.cpp", "db_builder.cpp", "data_codec.cpp", "unicode_lower.cpp", "host_topology.cpp", "capi.cpp"]
+SOURCES = ["k_anchor.hip", "validate_kernels.hip", "lookup_kernels.hip", "sort_hits.hip", "ip_tables.hip", "engine.cpp", "db_image.cpp", "db_builder.cpp", "data_codec.cpp", "unicode_lower.cpp", "host_topology.cpp", "host_lookup.cpp", "capi.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # lookup_kernels.hip: keep the dynamically indexed private arrays of the glob matcher (result list, star stack: 80 dwords,
 # touched a few times per text) in scratch instead of in vector registers — 96 VGPRs instead of 512 for k_lookup<true>.

@@ -16,6 +16,7 @@
 #include "db_builder.h"
 #include "db_image.h"
 #include "engine.h"
+#include "host_lookup.h"
 #include "host_topology.h"
 
 #include <fcntl.h>
@@ -33,6 +34,7 @@
 
 #include <list>
 #include <unordered_map>
+#include <unordered_set>
 
 using namespace mxy;
 
@@ -49,34 +51,56 @@ struct Db {
     std::shared_ptr<DbImage> img;
     std::mutex mu;                                   // guards dev + query scanner (single queries are serialised)
     std::vector<std::shared_ptr<DeviceDb>> dev;      // per device ordinal, uploaded on first use
-    std::unique_ptr<Scanner> query_scanner;
+    std::unique_ptr<Scanner> query_scanner;        // single queries through the lookup kernels (MATCHY_AMD_QUERY_ON_GPU=1: tests)
+    std::unique_ptr<HostTables> host_tables;       // single queries on the host (host_lookup.h): built by the first query
     DevBuf<uint8_t> qbuf;
     DevBuf<Candidate> qcand;
     std::string format;
     int default_device = 0;
     // DatabaseStats (database.rs:728-795)
     mutable std::atomic<uint64_t> st_total{0}, st_match{0}, st_nomatch{0}, st_ip{0}, st_str{0}, st_chit{0}, st_cmiss{0};
-    // Query cache of Database::lookup (database.rs:32-40, 384-407, 725-804): LRU keyed by the query string, holds "not found"
-    // too. The reference keeps one cache per thread; here one per handle (guarded by `mu`, like the single-query path), so
-    // a query repeated by another thread hits as well. 0 entries = disabled (matchy_open_options_t.cache_capacity).
+    // Query cache of Database::lookup (database.rs:32-40, 384-407, 725-804): LRU keyed by the query string, holds "not found" too.
+    // ONE PER THREAD AND HANDLE, like the reference's thread-local caches (round 5; until then one per handle behind `mu`, which made
+    // eight querying threads slower than one): a query takes no lock. 0 entries = disabled (matchy_open_options_t.cache_capacity).
     struct Cached { int kind; uint8_t prefix_len; bool has_data; DataValue data; };   // kind: 0 not found, 2 IP, 3 pattern
+    struct Lru {
+        std::list<std::pair<std::string, Cached>> lru;
+        std::unordered_map<std::string, std::list<std::pair<std::string, Cached>>::iterator> index;
+        const Cached* get(const std::string& q) {
+            auto it = index.find(q);
+            if (it == index.end()) return nullptr;
+            lru.splice(lru.begin(), lru, it->second);
+            return &it->second->second;
+        }
+        void put(const std::string& q, Cached&& c, size_t cap) {
+            if (!cap) return;
+            auto it = index.find(q);
+            if (it != index.end()) { it->second->second = std::move(c); lru.splice(lru.begin(), lru, it->second); return; }
+            lru.emplace_front(q, std::move(c));
+            index[q] = lru.begin();
+            if (lru.size() > cap) { index.erase(lru.back().first); lru.pop_back(); }
+        }
+        void clear() { lru.clear(); index.clear(); }
+    };
     size_t cache_cap = 10000;
-    std::list<std::pair<std::string, Cached>> lru;
-    std::unordered_map<std::string, std::list<std::pair<std::string, Cached>>::iterator> lru_index;
-    const Cached* cache_get(const std::string& q) {
-        auto it = lru_index.find(q);
-        if (it == lru_index.end()) return nullptr;
-        lru.splice(lru.begin(), lru, it->second);
-        return &it->second->second;
+    const uint64_t uid = next_uid();   // names this handle in the threads' cache maps (a pointer could be reused by a later handle)
+    static uint64_t next_uid() { static std::atomic<uint64_t> n{1}; return n.fetch_add(1); }
+    static std::mutex& live_mu() { static std::mutex m; return m; }
+    static std::unordered_set<uint64_t>& live() { static std::unordered_set<uint64_t> s; return s; }
+    Db() { std::lock_guard<std::mutex> lk(live_mu()); live().insert(uid); }
+    ~Db() { std::lock_guard<std::mutex> lk(live_mu()); live().erase(uid); }
+    // the calling thread's cache of this handle; caches of closed handles are dropped when a thread meets a new handle
+    Lru& cache() {
+        thread_local std::unordered_map<uint64_t, Lru> mine;
+        auto it = mine.find(uid);
+        if (it != mine.end()) return it->second;
+        if (mine.size() >= 4) {
+            std::lock_guard<std::mutex> lk(live_mu());
+            for (auto k = mine.begin(); k != mine.end();) k = live().count(k->first) ? std::next(k) : mine.erase(k);
+        }
+        return mine[uid];
     }
-    void cache_put(const std::string& q, Cached&& c) {
-        if (!cache_cap) return;
-        auto it = lru_index.find(q);
-        if (it != lru_index.end()) { it->second->second = std::move(c); lru.splice(lru.begin(), lru, it->second); return; }
-        lru.emplace_front(q, std::move(c));
-        lru_index[q] = lru.begin();
-        if (lru.size() > cache_cap) { lru_index.erase(lru.back().first); lru.pop_back(); }
-    }
+    std::once_flag host_tables_once;
 
     std::shared_ptr<DeviceDb> device_db(int device) {
         if ((int)dev.size() <= device) dev.resize(device + 1);
@@ -374,8 +398,7 @@ void matchy_get_stats(const matchy_t* dbc, matchy_stats_t* st) {
 void matchy_clear_cache(const matchy_t* dbc) {
     if (!dbc) return;
     Db* db = const_cast<Db*>(reinterpret_cast<const Db*>(dbc));
-    std::lock_guard<std::mutex> lk(db->mu);
-    db->lru.clear(); db->lru_index.clear();
+    db->cache().clear();   // the calling thread's cache, like Database::clear_cache (thread-local caches)
 }
 uintptr_t matchy_pattern_count(const matchy_t* db) { return db ? reinterpret_cast<const Db*>(db)->img->pattern_count : 0; }
 char* matchy_metadata(const matchy_t* db) {
@@ -417,6 +440,32 @@ static bool query_candidate(const char* query, size_t qn, IpAddr& ip, bool& is_i
     return true;
 }
 
+// One uncached query. SURVEY §8b: single queries stay on the CPU (latency) — host_lookup.cpp walks the same sections the kernels get
+// uploaded; MATCHY_AMD_QUERY_ON_GPU=1 sends the query through the lookup kernels instead (the GPU tests hold the two against each other
+// and against the oracle). Fills `so` like Scanner::lookup_one: no hit, or hits[0] (+ its glob ids in so.ids).
+// Takes no lock on the host path (the sections are read-only: queries of several threads proceed side by side, like the reference's
+// per-thread lookups); the kernel path serialises on Db::mu.
+static void single_lookup(Db* db, const std::string& text, const Candidate& c, const IpAddr& ip, bool is_ip, ScanOutput& so) {
+    static const bool on_gpu = [] { const char* e = getenv("MATCHY_AMD_QUERY_ON_GPU"); return e && atoi(e) != 0; }();
+    if (on_gpu) {
+        std::lock_guard<std::mutex> lk(db->mu);
+        if (!db->query_scanner) db->query_scanner = std::make_unique<Scanner>(db->img, db->device_db(db->default_device), EX_ALL, 2);
+        db->query_scanner->lookup_one(text, c, so);
+        return;
+    }
+    std::call_once(db->host_tables_once, [db] { db->host_tables = std::make_unique<HostTables>(*db->img); });
+    HostHit hh;
+    host_lookup(*db->img, *db->host_tables, text, is_ip ? &ip : nullptr, hh);
+    so.hits.clear(); so.ids.clear();
+    if (!hh.kind) return;
+    if (hh.globs.size() > 0xFFFFu) throw std::runtime_error("query matches more than 65535 glob patterns");   // the limit of the scan records (engine.cpp)
+    Hit h{};
+    h.kind = hh.kind; h.prefix_len = hh.prefix_len; h.a = hh.a; h.ids_off = 0; h.n_globs = (uint16_t)hh.globs.size();
+    h.start = 0; h.len_type = c.len_type;
+    so.hits.push_back(h);
+    so.ids = std::move(hh.globs);
+}
+
 void matchy_query_into(const matchy_t* dbc, const char* query, matchy_result_t* result) {
     if (!result) return;
     *result = matchy_result_t{false, 0, nullptr, nullptr};
@@ -425,13 +474,13 @@ void matchy_query_into(const matchy_t* dbc, const char* query, matchy_result_t* 
     size_t qn = strlen(query);
     if (!valid_utf8_host((const uint8_t*)query, qn)) return;  // CStr::to_str failure -> found=false
     try {
-        std::lock_guard<std::mutex> lk(db->mu);
         const std::string key(query, qn);
+        Db::Lru& cache = db->cache();
         IpAddr ip;
         bool is_ip;
         std::string text;
         Candidate c;
-        if (const Db::Cached* hit = db->cache_get(key)) {
+        if (const Db::Cached* hit = db->cache_cap ? cache.get(key) : nullptr) {
             // cache hit (database.rs:727-757): same accounting as a lookup, except that a cached miss is typed by parsing the query
             db->st_total++; db->st_chit++;
             if (hit->kind == 0) { if (parse_ip(query, qn, ip)) db->st_ip++; else db->st_str++; db->st_nomatch++; return; }
@@ -443,15 +492,14 @@ void matchy_query_into(const matchy_t* dbc, const char* query, matchy_result_t* 
             result->_db_ref = dbc;
             return;
         }
-        if (!db->query_scanner) db->query_scanner = std::make_unique<Scanner>(db->img, db->device_db(db->default_device), EX_ALL, 2);
         if (!query_candidate(query, qn, ip, is_ip, text, c)) return;
         ScanOutput so;
-        db->query_scanner->lookup_one(text, c, so);
+        single_lookup(db, text, c, ip, is_ip, so);
         db->st_total++;
         if (db->cache_cap) db->st_cmiss++;
         if (so.hits.empty()) {   // a miss counts as a string query (database.rs:786-790)
             db->st_str++; db->st_nomatch++;
-            db->cache_put(key, Db::Cached{0, 0, false, DataValue()});
+            cache.put(key, Db::Cached{0, 0, false, DataValue()}, db->cache_cap);
             return;
         }
         const Hit& h = so.hits[0];
@@ -468,11 +516,11 @@ void matchy_query_into(const matchy_t* dbc, const char* query, matchy_result_t* 
             else if ((h.a == 0xFFFFFFFFu || !db->img->lit_data_offset(h.a, off)) && h.n_globs > 0) have = db->img->glob_data_offset(so.ids[h.ids_off], off);
             ok = have && db->img->decode_data(off, *dv);
         }
-        if (!ok) { delete dv; result->prefix_len = 0; db->cache_put(key, Db::Cached{h.kind, 0, false, DataValue()}); return; }
+        if (!ok) { delete dv; result->prefix_len = 0; cache.put(key, Db::Cached{h.kind, 0, false, DataValue()}, db->cache_cap); return; }
         result->found = true;
         result->_data_cache = dv;
         result->_db_ref = dbc;
-        db->cache_put(key, Db::Cached{h.kind, result->prefix_len, true, *dv});
+        cache.put(key, Db::Cached{h.kind, result->prefix_len, true, *dv}, db->cache_cap);
     } catch (const HipError& e) { set_error(e.what); }
     catch (const std::exception& e) { set_error(e.what()); }
 }
@@ -486,15 +534,13 @@ char* matchy_amd_query_json(const matchy_t* dbc, const char* query, int32_t* fou
     const size_t qn = strlen(query);
     if (!valid_utf8_host((const uint8_t*)query, qn)) return strdup("[]");
     try {
-        std::lock_guard<std::mutex> lk(db->mu);
-        if (!db->query_scanner) db->query_scanner = std::make_unique<Scanner>(db->img, db->device_db(db->default_device), EX_ALL, 2);
         IpAddr ip;
         bool is_ip;
         std::string text;
         Candidate c;
         if (!query_candidate(query, qn, ip, is_ip, text, c)) return strdup("[]");
         ScanOutput so;
-        db->query_scanner->lookup_one(text, c, so);
+        single_lookup(db, text, c, ip, is_ip, so);
         if (so.hits.empty()) return strdup("[]");
         const Hit& h = so.hits[0];
         if (found) *found = 1;

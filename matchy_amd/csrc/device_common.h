@@ -319,13 +319,6 @@ __device__ inline bool d_valid_utf8(const uint8_t* s, uint32_t n) {
 
 // Byte-class masks of 8 log bytes at once (SWAR; bit 7 of each byte of the result is the class bit, all other bits 0).
 // Every addend keeps each byte below 0x100, so no carry crosses a byte.
-// all four bytes of x are ASCII hex digits (SWAR; no carries cross bytes because every addend keeps bytes below 0x100)
-__device__ __forceinline__ bool hex4(uint32_t x) {
-    const uint32_t t = x & 0x7F7F7F7Fu, l = t | 0x20202020u;
-    const uint32_t dig = (t + 0x50505050u) & ~(t + 0x46464646u);   // >= '0' and not >= ':'
-    const uint32_t alp = (l + 0x1F1F1F1Fu) & ~(l + 0x19191919u);   // >= 'a' and not >= 'g' (case folded)
-    return (((dig | alp) & ~x) & 0x80808080u) == 0x80808080u;
-}
 struct ByteMasks { uint64_t dc, dot, dash, high; };
 // The class arithmetic keeps every byte lane below 0x100, so no carry ever crosses a byte — nor the middle of a 64-bit word: the two
 // halves are computed on their own with 32-bit adds. (Written on uint64_t the compiler emits v_add_co / v_addc_co pairs, a carry chain

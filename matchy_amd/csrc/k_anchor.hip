@@ -507,60 +507,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
 template <int K> __device__ __forceinline__ uint32_t back(uint32_t P, uint32_t PV) { return K == 4 ? PV : __builtin_amdgcn_alignbyte(P, PV, 4 - K); }
 template <int K> __device__ __forceinline__ uint32_t ahead(uint32_t P, uint32_t NV) { return K == 4 ? NV : __builtin_amdgcn_alignbyte(NV, P, K); }
 
-// A long token decided where its bytes are (round 5): the candidate lane reads the token from the wave's LDS window — 32 bytes per step —
-// and settles what k_validate used to gather from HBM per token: is it a hex hash of a listed length (ext:1212-1250), can the literal
-// table hold it (DevDb::lit_bm over its first 32 bytes and its length), and which checksum validator do its first bytes name
-// (ext:1289-1307, 1331-1350, 1388-1397). Returns the TOKF_* bits of the list entry; `list` = the entry is needed at all; `unlisted`
-// counts valid hashes that cannot hit (they are candidates of the extractor all the same). All lanes of the converged wave call this.
-__device__ __forceinline__ uint32_t tok_decide(const uint32_t* raw32, uint32_t s, uint32_t tl, bool tok, uint32_t ex_flags, bool& list, uint32_t& unlisted) {
-    uint32_t w[8];
-    raw_read<8>(raw32, s, w);
-    const int ht = tl == 32 ? IT_MD5 : tl == 40 ? IT_SHA1 : tl == 64 ? IT_SHA256 : tl == 96 ? IT_SHA384 : tl == 128 ? IT_SHA512 : -1;
-    bool hex = tok && ht >= 0 && (ex_flags & EX_HASHES);
-    if (__ballot(hex)) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) hex = hex && hex4(w[k]);
-        // bytes 32 .. tl of the longer hashes (lengths are multiples of 8: whole dwords)
-        for (uint32_t off = 32; __ballot(hex && tl > off); off += 32) {
-            uint32_t x[8];
-            raw_read<8>(raw32, s + off, x);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) hex = hex && (off + 4 * k >= tl || hex4(x[k]));
-        }
-    }
-    uint32_t fl = TOKF_DECIDED;
-    if (__ballot(hex)) {
-        const ColdTok kp = cold_tok();
-        const ColdDb kd = cold_db();
-        // a hash can only hit through the literal table when the database has no glob section (see k_validate)
-        const uint32_t* bm = kd->lit_bm;
-        const bool tok_filter = kp->filter_lit && !kd->has_glob && bm != nullptr;
-        bool pass = hex;
-        if (tok_filter) {
-            uint64_t l0 = (uint64_t)w[0] | ((uint64_t)w[1] << 32), l1 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-            uint64_t l2 = (uint64_t)w[4] | ((uint64_t)w[5] << 32), l3 = (uint64_t)w[6] | ((uint64_t)w[7] << 32);
-            if (kd->ci) { l0 = ascii_lower8(l0); l1 = ascii_lower8(l1); l2 = ascii_lower8(l2); l3 = ascii_lower8(l3); }
-            const uint32_t b = name_hash31(l0, l1, l2, l3, tl) & kd->lit_bm_mask;
-            uint32_t word = 0;
-            if (hex) word = bm[b >> 5];
-            pass = hex && ((word >> (b & 31)) & 1u);
-            if (hex && !pass) ++unlisted;
-        }
-        if (pass) fl |= TOKF_HASH;
-    }
-    const uint32_t c0 = w[0] & 0xFFu, c1 = (w[0] >> 8) & 0xFFu, c2 = (w[0] >> 16) & 0xFFu;
-    uint32_t hk = 0;
-    if ((ex_flags & EX_BITCOIN) && tl >= 26 && tl <= 62) {
-        if (c0 == 'b' && c1 == 'c' && c2 == '1') hk = HEAVY_BECH32;
-        else if (c0 == '1' || c0 == '3') hk = HEAVY_B58;
-    }
-    if ((ex_flags & EX_ETHEREUM) && tl == 42 && c0 == '0' && c1 == 'x') hk = HEAVY_ETH;
-    if ((ex_flags & EX_MONERO) && tl >= 90 && tl <= 110 && (c0 == '4' || c0 == '8')) hk = HEAVY_XMR;
-    fl |= hk << TOKF_HEAVY_SHIFT;
-    list = tok && ((fl & TOKF_HASH) || hk);
-    return fl;
-}
-
 // ALL: every extractor is enabled and the public-suffix first-byte class is the narrow one (the command line's and the
 // bulk scan's configuration): no run-time flag tests in the block loop.
 // INL: TokParams::inline_v4 (the wave looks its IPv4 candidates up itself)
@@ -593,7 +539,6 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     const bool tl_wide = !ALL && anchor_tl_wide(db);
 
     uint32_t nl_count = 0;                       // per-lane '\n' count, reduced once at the end
-    uint32_t tok_unlisted = 0;                   // per-lane count of valid hashes the literal bitmap ruled out (candidates all the same)
     uint32_t v4h = 0, v4t = 0, dh = 0, dt = 0;   // ring heads / tails (wave-uniform)
     uint32_t v4_old = 0, dom_old = 0;            // block start of the oldest ring entry (valid while the ring is non-empty)
     CandWriter cw_cand(wb_cand[wave], p.cand_chunk);   // IPv4 candidates: sparse when the /24 bitmap filters, else one per line
@@ -897,17 +842,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
                         const uint32_t tl = e - (uint32_t)s;
                         const bool tok = mine && !too_long && rowbits != 0 &&
                                          ((tl >= 26 && tl <= 62) || tl == 64 || (tl >= 90 && tl <= 110) || tl == 128);
-                        // decided here when the token's bytes are in the window (its end is in this block; its start lies in front of the
-                        // window only at a segment's first bytes), else left to k_validate
-                        uint32_t fl = 0;
-                        bool list = tok;
-                        const bool resident = tok && (uint32_t)s >= cx.res_lo;
-                        if (__ballot(resident)) {
-                            bool l2 = false;
-                            const uint32_t f2 = tok_decide(raw32, (uint32_t)s, tl, resident, ALL ? (uint32_t)EX_ALL : p.flags, l2, tok_unlisted);
-                            if (resident) { fl = f2; list = l2; }
-                        }
-                        cw_tok.append(list, make_uint2((uint32_t)s, (uint32_t)RARE_TOK | (tl << 8) | fl));
+                        cw_tok.append(tok, make_uint2((uint32_t)s, (uint32_t)RARE_TOK | (tl << 8)));
                     }
                 }
                 Bprev = cl.B;
@@ -925,7 +860,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     cw_dom.pad_rest(p.dom_list, p.dom_cap);
     cw_cand.finish(p.cands_a, p.cand_a_cap, &p.counters->n_cand_a, Candidate{0u, 0xFFFFFFFFu, 0u, 0u});
     {
-        uint32_t nv = pend.n_valid + tok_unlisted;  // validated IPv4 candidates, listed or not, and the hashes that cannot hit
+        uint32_t nv = pend.n_valid;  // validated IPv4 candidates, listed or not
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nv += __shfl_down(nv, off);
         if (lane == 0 && nv) atomicAdd(&cold_tok()->counters->cand_true, nv);

@@ -31,15 +31,8 @@ constexpr uint32_t CAND_NO_GLOB = 1, CAND_GLOB = 2;
 enum RareKind : uint32_t { RARE_V6 = 0, RARE_AT = 1, RARE_TOK = 2, HEAVY_B58 = 3, HEAVY_BECH32 = 4, HEAVY_ETH = 5, HEAVY_XMR = 6, RARE_DOM = 7 };
 struct RareAnchor {
     uint32_t pos;       // RARE_V6: index of the 2nd ':' of a "::"; RARE_AT: index of '@'; RARE_TOK: token start
-    uint32_t len_kind;  // RareKind in bits 0..7, token length in bits 8..31 (RARE_TOK: length <= 128 in bits 8..15, TOKF_* above)
+    uint32_t len_kind;  // RareKind in bits 0..7, token length in bits 8..31
 };
-// RARE_TOK entries of k_anchor (round 5): what the streaming pass already decided from the token's bytes while they were in its LDS window,
-// so that k_validate need not gather them from HBM again (a hash-dense log re-read 2.6 GB that way: 0.97 ms).
-//   TOKF_DECIDED  the hash question is settled: TOKF_HASH set = a hex hash of a listed length that the literal bitmap lets through (list it),
-//                 clear = no hash, or one that cannot hit (k_anchor counted it); TOKF_HEAVY = the checksum validator the prefix tests name
-//                 (0 none; HEAVY_B58 still needs the alphabet test of k_validate, which reads the bytes for those tokens only)
-//   without it    the token started in front of the window (segment edge): k_validate decides from the log as before
-constexpr uint32_t TOKF_DECIDED = 1u << 16, TOKF_HASH = 1u << 17, TOKF_HEAVY_SHIFT = 18, TOKF_HEAVY_MASK = 7u << 18;
 
 // One database hit, 24 bytes. For IP hits `a` is the data-section offset; for pattern hits `a` is the literal
 // pattern id (or 0xFFFFFFFF) and [ids_off, ids_off + n_globs) indexes the glob-id side buffer.

@@ -362,6 +362,13 @@ __device__ bool all_hex(const LogView& lg, uint32_t s, uint32_t n) {
     for (uint32_t k = 0; k < n; ++k) if (!d_is_hex(lg.at(s + k))) return false;
     return true;
 }
+// all four bytes of x are ASCII hex digits (SWAR; no carries cross bytes because every addend keeps bytes below 0x100)
+__device__ __forceinline__ bool hex4(uint32_t x) {
+    const uint32_t t = x & 0x7F7F7F7Fu, l = t | 0x20202020u;
+    const uint32_t dig = (t + 0x50505050u) & ~(t + 0x46464646u);   // >= '0' and not >= ':'
+    const uint32_t alp = (l + 0x1F1F1F1Fu) & ~(l + 0x19191919u);   // >= 'a' and not >= 'g' (case folded)
+    return (((dig | alp) & ~x) & 0x80808080u) == 0x80808080u;
+}
 // all_hex for the hash lengths (multiples of 8): independent 8-byte loads instead of a dependent byte-load chain
 __device__ __forceinline__ bool all_hex_wide(const uint8_t* p, uint32_t n) {
     bool ok = true;
@@ -1021,18 +1028,14 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         RareAnchor ra{0, 0xFF};
         if (i < nt) ra = p.tok[i];
         const bool live = (ra.len_kind & 0xFF) == RARE_TOK;
-        const uint32_t tl = (ra.len_kind >> 8) & 0xFFu;
-        // decided by k_anchor from its LDS window (TOKF_*): the bytes are only needed for the Base58 alphabet test
-        const bool decided = live && (ra.len_kind & TOKF_DECIDED);
-        const uint32_t pre_heavy = (ra.len_kind & TOKF_HEAVY_MASK) >> TOKF_HEAVY_SHIFT;
-        const bool need_bytes = live && (!decided || pre_heavy == HEAVY_B58);
+        const uint32_t tl = ra.len_kind >> 8;
         const uint8_t* s = lg.p + (live ? ra.pos : 0);
         // The token's first 32 bytes (every token is at least 26 long; the bytes behind a short one belong to the log or to the 64
         // bytes of padding behind it... a token that ends within 32 bytes of the buffer's end is read byte-wise) in ONE round trip:
         // the prefix tests, the hex test of an MD5 and the bitmap hash all come out of these registers. One lane per token and a
         // dependent 8-byte load per step made this loop a chain of round trips to HBM per token (18 M tokens of a hash-dense log: 3.6 ms).
         uint64_t w[4] = {0, 0, 0, 0};
-        if (need_bytes) {
+        if (live) {
             if (ra.pos + 32 <= lg.len) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) __builtin_memcpy(&w[k], s + 8 * k, 8);
@@ -1045,10 +1048,8 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         {
             Candidate c{0, 0, 0, 0};
             bool emit = false;
-            const int ht = tl == 32 ? IT_MD5 : tl == 40 ? IT_SHA1 : tl == 64 ? IT_SHA256 : tl == 96 ? IT_SHA384 : tl == 128 ? IT_SHA512 : -1;
-            if (decided) {
-                if (ra.len_kind & TOKF_HASH) { c.start = ra.pos; c.len_type = tl | ((uint32_t)ht << 24); emit = true; }
-            } else if (live && (p.flags & EX_HASHES)) {
+            if (live && (p.flags & EX_HASHES)) {
+                const int ht = tl == 32 ? IT_MD5 : tl == 40 ? IT_SHA1 : tl == 64 ? IT_SHA256 : tl == 96 ? IT_SHA384 : tl == 128 ? IT_SHA512 : -1;
                 if (ht >= 0) {
                     bool hex = true;
 #pragma unroll
@@ -1070,11 +1071,9 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         // a token can yield several items: hash, Bitcoin, Ethereum and Monero are independent extractors
         {
             uint32_t hk = 0;
-            // (decided tokens: the prefix tests ran in k_anchor; HEAVY_B58 = first byte '1' / '3', length 26..62, alphabet test still to do)
-            if (decided && pre_heavy == HEAVY_BECH32) hk = HEAVY_BECH32;
-            if ((decided ? pre_heavy == HEAVY_B58 : live) && (p.flags & EX_BITCOIN) && tl >= 26 && tl <= 62) {
-                if (!decided && c0 == 'b' && c1 == 'c' && c2 == '1') hk = HEAVY_BECH32;
-                else if (decided || c0 == '1' || c0 == '3') {
+            if (live && (p.flags & EX_BITCOIN) && tl >= 26 && tl <= 62) {
+                if (c0 == 'b' && c1 == 'c' && c2 == '1') hk = HEAVY_BECH32;
+                else if (c0 == '1' || c0 == '3') {
                     // Base58Check starts with decoding, and decoding fails on a symbol outside the Bitcoin alphabet (bs58: lib.rs:1799-1822):
                     // a token with '0', 'O', 'I' or 'l' in it — every second lower-case hex hash that starts with 1 or 3 — need not go to the
                     // checksum kernel, whose waves would run the whole decode + double SHA-256 for the one lane in 64 that can pass.
@@ -1109,12 +1108,8 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
             }
             hw.append(hk != 0, RareAnchor{ra.pos, (tl << 8) | hk}, p.heavy, p.heavy_cap, &p.counters->n_heavy);
             hk = 0;
-            if (decided) {
-                if (pre_heavy == HEAVY_ETH || pre_heavy == HEAVY_XMR) hk = pre_heavy;
-            } else {
-                if (live && (p.flags & EX_ETHEREUM) && tl == 42 && c0 == '0' && c1 == 'x') hk = HEAVY_ETH;
-                if (live && (p.flags & EX_MONERO) && tl >= 90 && tl <= 110 && (c0 == '4' || c0 == '8')) hk = HEAVY_XMR;
-            }
+            if (live && (p.flags & EX_ETHEREUM) && tl == 42 && c0 == '0' && c1 == 'x') hk = HEAVY_ETH;
+            if (live && (p.flags & EX_MONERO) && tl >= 90 && tl <= 110 && (c0 == '4' || c0 == '8')) hk = HEAVY_XMR;
             hw.append(hk != 0, RareAnchor{ra.pos, (tl << 8) | hk}, p.heavy, p.heavy_cap, &p.counters->n_heavy);
         }
     }

@@ -1526,3 +1526,87 @@ def test_multi_scanner_back_pressure(M, oracle):
     assert done_submitting.is_set() and ms.pending() == 0 and ms.next() is None
     assert all(n >= -1 for n, _ in ms.worker_numa())
     sc.close(); ms.close(); db.close()
+
+
+def _query_probe_set(seed, cfgname):
+    """(database blob, queries): keys of the configuration, names / addresses cut from its log, near misses"""
+    from tools import synth
+    cfg = synth.config(cfgname)
+    blob = synth.build_db(cfg)
+    rng = random.Random(seed)
+    keys = [k.decode() for k, _ in synth.ioc_entries(cfg)]
+    qs = rng.sample(keys, min(len(keys), 400))
+    for k in list(qs):
+        if "/" in k and ":" not in k:
+            qs.append(k.split("/")[0])                      # an address inside a CIDR key
+        if k.startswith("*."):
+            qs += ["www" + k[1:], "a.b" + k[1:], k[2:]]     # names under a suffix glob, and the bare suffix
+        if k.startswith("glob:"):
+            qs += [k[5:], "x" + k[5:] + "y"]                # substring semantics of literal patterns (Q9)
+    log = synth.make_log(cfg, 0, 3000)
+    import re
+    toks = re.findall(rb"[0-9A-Za-z][0-9A-Za-z.:\-]{3,80}", log)
+    qs += [t.decode() for t in rng.sample(toks, 600)]
+    qs += ["", ".", "1.2.3.4", "255.255.255.255", "0.0.0.0", "::", "::1", "2001:db8::1", "::ffff:1.2.3.4", "1.2.3", "münchen.de", "x" * 300,
+           "EXAMPLE.COM", "a" * 70000]
+    return blob, qs
+
+
+@pytest.mark.parametrize("cfgname", ["c1", "c2/20", "c3b/50", "c4/20", "c5/100"])
+def test_host_query_path_against_oracle_and_kernels(M, oracle, cfgname):
+    """matchy_query / matchy_amd_query_json answer on the HOST since round 5 (csrc/host_lookup.cpp: SURVEY §8b "single queries stay
+    on the CPU path"; trie walk, literal probe, Paraglob::find_all written against the on-disk sections — not the oracle). Every
+    probe against the oracle's Database::lookup: same verdict, same prefix length, same data values in the same order; and the same
+    probes through the lookup KERNELS (MATCHY_AMD_QUERY_ON_GPU=1 in a child process) give byte-identical JSON."""
+    import subprocess
+    import sys
+    import tempfile
+    blob, qs = _query_probe_set(5, cfgname)
+    db = M.Database(blob)
+    odb = oracle.Database(blob)
+    host_answers = []
+    n_found = 0
+    for q in qs:
+        want = odb.lookup(q)
+        found, arr = db.query_json(q)
+        host_answers.append(json.loads(json.dumps([found, arr])))   # (a copy: the checks below take the IP answer apart)
+        got1 = db.lookup(q)
+        if want["kind"] == "ip":
+            n_found += 1
+            assert found and len(arr) == 1 and arr[0].pop("prefix_len") == want["prefix_len"] and arr[0].pop("cidr"), (q, arr)
+            assert arr[0] == want["data"], (q, arr, want)
+            assert got1 == {"found": True, "prefix_len": want["prefix_len"], "data": want["data"]}, q
+        elif want["kind"] == "pattern":
+            n_found += 1
+            assert found and arr == [d for d in want["data"] if d is not None], (q, arr, want)
+            first = next((d for d in want["data"] if d is not None), None)
+            # matchy_query: the FIRST pattern's data only (c_api/matchy.rs:1143-1154)
+            if want["data"] and want["data"][0] is not None:
+                assert got1 == {"found": True, "prefix_len": 0, "data": want["data"][0]}, q
+            elif first is None:
+                assert got1 is None, q
+        else:
+            assert not found and arr == [] and got1 is None, (q, arr)
+    assert n_found > 100
+    db.close()
+    with tempfile.TemporaryDirectory() as td:
+        (Path(td) / "db.mxy").write_bytes(blob)
+        (Path(td) / "q.json").write_text(json.dumps(qs))
+        code = r"""
+import json, sys
+sys.path.insert(0, %r)
+import matchy_amd as M
+db = M.Database(open(sys.argv[1], "rb").read())
+out = []
+for q in json.load(open(sys.argv[2])):
+    f, a = db.query_json(q)
+    out.append([f, a])
+json.dump(out, open(sys.argv[3], "w"))
+""" % str(ROOT)
+        env = dict(os.environ, MATCHY_AMD_QUERY_ON_GPU="1")
+        p = subprocess.run([sys.executable, "-c", code, str(Path(td) / "db.mxy"), str(Path(td) / "q.json"), str(Path(td) / "out.json")],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        gpu_answers = json.loads((Path(td) / "out.json").read_text())
+    for q, h, g in zip(qs, host_answers, gpu_answers):
+        assert h == g, q
