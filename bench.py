@@ -128,12 +128,24 @@ def run_strong(args, rank, local_rank, world, rehearse, torch, dist, dev, coll_d
                "entry": "matchy_scanner_scan from pinned host memory, two scanners per GPU on their own streams, H2D included"}
         for sc in scs:
             sc.close()
+    # same-run parity on the head of the job: the first lines of rank 0's first batch (the generator is a pure function of the line
+    # index, so the sample is generated again on the host) through the same scanner and through the oracle
+    parity = None
+    if rank == 0 and not args.no_cpu:
+        from oracle import oracle
+        n_par = min(args.cpu_lines, batches[0][1], 1_000_000)
+        sample = synth.make_log(cfg, batches[0][0], n_par)
+        ohits, _, ost = oracle.Database(blob).scan(sample, threads=min(len(os.sched_getaffinity(0)), 16), cache=0, want_json=False)
+        r = scanner.scan(sample)
+        parity = "ok" if (r.hits() == ohits and (r.lines, r.candidates) == (ost.lines, ost.candidates)) else f"MISMATCH gpu={r.n_hits} cpu={len(ohits)}"
+        r.close()
     if rank == 0:
         step_s = agg["elapsed_s"] / args.steps
         print(json.dumps({
             "metric": "log GB/s scanned (matchy match hot path, 100K IoCs)", "value": round(agg["bytes"] / step_s / 1e9, 3), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic", "parity_vs_oracle": parity,
+            "batches": len(batches), "per_batch_ms": round(step_s * 1e3 / max(1, len(batches)), 4),
             "config": {"workload": f"BASELINE configs[3]-style strong scaling: ONE job of {args.lines} nginx-style lines ({agg['bytes']} B), config {args.config}, "
                                    f"cut into {world} contiguous newline-aligned ranges, batches of <= {per} lines, DB replicated, no collective",
                        "total_lines": args.lines, "total_bytes": agg["bytes"]},
