@@ -65,7 +65,8 @@ constexpr int WALK_NO = 0, WALK_YES = 1, WALK_LONG = 2;
 constexpr uint32_t WALK_BUDGET_WORDS = 128;   // 8-byte words one lane walks alone before it asks the wave for help
 template <bool HASH>
 __device__ __forceinline__ int domain_walk_back(const LogView& lg, const DevDb& db, uint32_t min_labels, uint32_t e, BackReader& br,
-                                                 const WalkInit& wi, uint32_t& start, WalkState* long_out, bool* defer_utf8 = nullptr) {
+                                                 const WalkInit& wi, uint32_t& start, WalkState* long_out, bool* defer_utf8 = nullptr,
+                                                 bool* hit_start = nullptr) {
     uint64_t rh = wi.rh;
     bool found = wi.found, bad = wi.bad, high = wi.high;
     uint32_t labels = wi.labels, cur = wi.cur, last_c = wi.last_c;
@@ -123,6 +124,8 @@ __device__ __forceinline__ int domain_walk_back(const LogView& lg, const DevDb& 
         last_c = c;
     }
     const uint32_t s = br.pos;
+    // the walk ran into the start of what `lg` shows: for a window view of the log (k_validate) the verdict below is not to be trusted
+    if (hit_start && first_c == 0x100) *hit_start = true;
     if (cur == 0 || last_c == '-') bad = true;  // leftmost label empty / starts with '-'
     if (bad || !found || labels < min_labels) return WALK_NO;
     if (first_c != 0x100 && !d_is_boundary(first_c)) return WALK_NO;
@@ -207,8 +210,9 @@ __device__ __forceinline__ void coop_domain_skip(const LogView& lg, WalkState& s
 // of a maximal domain-char run owns the run; it validates the run as a whole. `tldtab` is the LDS copy of
 // DevDb::tld_tab (exact table of the last labels of <= 7 bytes), `bloom` covers the longer ones.
 struct DomLong { WalkState st; uint32_t e; bool alone; };
+// `edge` (optional) is set when the scan touched either end of what `lg` shows (the verdict then depends on bytes outside a window view).
 __device__ int val_domain(const LogView& lg, const DevDb& db, const uint32_t* bloom, const uint2* tldtab, uint32_t min_labels,
-                          uint32_t j, uint32_t& start, uint32_t& end, DomLong* long_out) {
+                          uint32_t j, uint32_t& start, uint32_t& end, DomLong* long_out, bool* edge = nullptr) {
     uint32_t p = j, th = 2166136261u;
     bool open = true;  // last label not yet terminated
     uint32_t stop_c = 0x100;  // byte that ended the run on the right (0x100 = buffer end)
@@ -239,6 +243,7 @@ __device__ int val_domain(const LogView& lg, const DevDb& db, const uint32_t* bl
         ++p;
     }
     const uint32_t e = p, ll = e - j;
+    if (edge && stop_c == 0x100) *edge = true;
     if (ll > db.max_tld_len) return false;
     if (stop_c != 0x100 && !d_is_boundary(stop_c)) return false;  // boundary (or buffer end) after the run (ext:600-606)
     bool alone = false;  // the last label by itself is a public suffix: the first dot of the walk decides
@@ -263,8 +268,8 @@ __device__ int val_domain(const LogView& lg, const DevDb& db, const uint32_t* bl
     WalkInit wi;
     wi.rh = psl_hash_init();
     WalkState ws{};
-    const int r = alone ? domain_walk_back<false>(lg, db, min_labels, e, br, wi, s, long_out ? &ws : nullptr)
-                        : domain_walk_back<true>(lg, db, min_labels, e, br, wi, s, long_out ? &ws : nullptr);
+    const int r = alone ? domain_walk_back<false>(lg, db, min_labels, e, br, wi, s, long_out ? &ws : nullptr, nullptr, edge)
+                        : domain_walk_back<true>(lg, db, min_labels, e, br, wi, s, long_out ? &ws : nullptr, nullptr, edge);
     if (r == WALK_LONG) { long_out->st = ws; long_out->e = e; long_out->alone = alone; return WALK_LONG; }
     if (r != WALK_YES) return WALK_NO;
     start = s; end = e;
@@ -511,7 +516,8 @@ __device__ __forceinline__ void coop_email_skip(const LogView& lg, EmailState& e
     }
 }
 // everything after the local part: boundary in front of it, the domain part, the public-suffix test
-__device__ bool val_email_finish(const LogView& lg, const DevDb& db, uint32_t at, const EmailState& es, uint32_t& start, uint32_t& end) {
+__device__ bool val_email_finish(const LogView& lg, const DevDb& db, uint32_t at, const EmailState& es, uint32_t& start, uint32_t& end,
+                                 bool* edge = nullptr) {
     constexpr uint64_t H = 0x8080808080808080ull;
     const uint32_t s = es.s;
     if (s == at) return false;
@@ -536,6 +542,7 @@ __device__ bool val_email_finish(const LogView& lg, const DevDb& db, uint32_t at
         has_dot |= c == '.';
         ++e;
     }
+    if (edge && (e >= lg.len || s == 0)) *edge = true;   // the scans touched an end of what `lg` shows
     if (e == at + 1) return false;
     if (e < lg.len && !d_is_boundary(lg.at(e))) return false;
     if (es.dotdot || !es.has_letter || !has_dot) return false;
@@ -993,8 +1000,21 @@ template <uint32_t VM>
 __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     constexpr bool MISC = (VM & 1u) != 0, DOM = (VM & 2u) != 0, TOK = (VM & 4u) != 0;
     __shared__ uint32_t bloom[DOM ? TLD_BLOOM_WORDS : 1];
-    __shared__ uint2 tldtab[DOM ? (1u << TLD_TAB_BITS) : 1];
-    __shared__ __attribute__((aligned(16))) uint8_t winbuf[MISC ? 256 * 80 : 16];   // one 80-byte IPv6 window per lane
+    constexpr bool TLD_LDS = DOM && (MISC || TOK);   // the launch that only walks domains probes the table in global memory (LDS budget: below)
+    __shared__ uint2 tldtab[TLD_LDS ? (1u << TLD_TAB_BITS) : 1];
+    const uint2* const tldtab_p = TLD_LDS ? tldtab : db.tld_tab;
+    // One 128-byte window of the log per lane (round 5; until then 80 bytes, IPv6 only). The e-mail and domain walks read the log a byte or
+    // a word at a time at per-lane addresses — every such load is 64 scattered requests to the memory pipeline, 2.5 M of them per batch of an
+    // application log (k_validate<1>: 0.85 ms for 2.9 M anchors). A lane now copies log[anchor - 64, anchor + 64) (domains: [j - 104, j + 24))
+    // into its window with eight 16-byte loads and runs the SAME walk on a view of the window; when the walk touches an end of the window its
+    // verdict would depend on bytes outside, and the lane walks the log itself as before.
+    // LDS is what limits the resident waves of these latency-bound passes (they share the CUs with k_validate_dom and each other): the window
+    // is 80 bytes with the IPv6 / e-mail list (what the IPv6 windows took before: e-mail [at - 48, at + 32)) and 64 bytes in the launch that only
+    // walks domains ([j - 48, j + 16)), which in turn reads the suffix table from global memory (one probe per walk) instead of staging 16 KB
+    // of it. With 128-byte windows the walks were twice as fast and the kernels no faster: two workgroups per CU instead of six.
+    constexpr uint32_t WIN = MISC ? 80 : 64;
+    constexpr uint32_t WIN_BACK = WIN - (MISC ? 32 : 16);   // bytes in front of the anchor
+    __shared__ __attribute__((aligned(16))) uint8_t winbuf[(MISC || DOM) ? 256 * WIN : 16];
     if constexpr (DOM && !MISC && !TOK) {
         // the undecided domains are a few thousand per batch: workgroups beyond the list leave before they stage 20 KB of tables
         if (blockIdx.x * blockDim.x >= min(p.counters->n_rare_dom, p.rare_dom_cap)) return;
@@ -1004,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     }
     if constexpr (DOM) {
         for (uint32_t i = threadIdx.x; i < TLD_BLOOM_WORDS; i += blockDim.x) bloom[i] = db.tld_bloom[i];
-        for (uint32_t i = threadIdx.x; i < (1u << TLD_TAB_BITS); i += blockDim.x) tldtab[i] = db.tld_tab[i];
+        if constexpr (TLD_LDS) for (uint32_t i = threadIdx.x; i < (1u << TLD_TAB_BITS); i += blockDim.x) tldtab[i] = db.tld_tab[i];
         __syncthreads();
     }
     LogView lg{p.log, p.len};
@@ -1116,7 +1136,15 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     hw.flush(p.heavy, p.heavy_cap, &p.counters->n_heavy);
     // IPv6 ("::") and e-mail ('@') anchors from the rare list. The IPv6 parser reads its bytes many times: each lane
     // copies log[p2-40, p2+40) into its LDS window with five wide loads first.
-    uint8_t* win = winbuf + (MISC ? threadIdx.x * 80 : 0);
+    uint8_t* win = winbuf + ((MISC || DOM) ? threadIdx.x * WIN : 0);
+    // copies log[from, from + 128) into the lane's window (callers make sure the range lies inside the buffer)
+    auto fill_window = [&](uint32_t from) {
+        uint4 v[WIN / 16];
+#pragma unroll
+        for (uint32_t k = 0; k < WIN / 16; ++k) __builtin_memcpy(&v[k], lg.p + from + 16 * k, 16);
+#pragma unroll
+        for (uint32_t k = 0; k < WIN / 16; ++k) *reinterpret_cast<uint4*>(win + 16 * k) = v[k];
+    };
     // two lists through the same code: k_anchor's rare anchors (vmode bit 0) and the domain anchors k_validate_dom left (bit 1);
     // the engine runs the first beside k_validate_dom on a stream of its own and the second behind it
     uint32_t unlisted = unlisted_tok;   // valid candidates this lane did not list (they cannot hit)
@@ -1159,8 +1187,27 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         }
         // e-mail anchors: the local part leftwards (a lane that meets a long run gets the wave's help), then the rest
         {
+            bool is_at = MISC && kind == RARE_AT;
+            if constexpr (MISC) {
+                // the window first: most addresses are short and stand in the middle of a line
+                const bool inner = is_at && ra.pos >= WIN_BACK && ra.pos + (WIN - WIN_BACK) <= lg.len;
+                if (__ballot(inner)) {
+                    if (inner) fill_window(ra.pos - WIN_BACK);
+                    __builtin_amdgcn_wave_barrier();
+                    if (inner) {
+                        const LogView wv{win, WIN};
+                        EmailState ws{WIN_BACK, (uint32_t)'@', false, false};
+                        bool edge = email_local_scan(wv, ws, false);   // (no budget: a window is ten words)
+                        uint32_t s2 = 0, e2 = 0;
+                        const bool okw = val_email_finish(wv, db, WIN_BACK, ws, s2, e2, &edge);
+                        if (!edge) {
+                            is_at = false;   // decided
+                            if (okw) { c.start = s2 + (ra.pos - WIN_BACK); c.len_type = (e2 - s2) | ((uint32_t)IT_EMAIL << 24); emit = true; }
+                        }
+                    }
+                }
+            }
             EmailState es{ra.pos, (uint32_t)'@', false, false};
-            const bool is_at = MISC && kind == RARE_AT;
             bool el = is_at && email_local_scan(lg, es, true);
             for (uint64_t lm = __ballot(el); lm; lm &= lm - 1) {
                 const int src = __ffsll((long long)lm) - 1;
@@ -1182,14 +1229,29 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         DomLong dl{};
         int dr = WALK_NO;
         uint32_t ds = 0, de = 0;
-        if (DOM && kind == RARE_DOM) {
-            // The walk is a chain of dependent 8-byte loads going left from the anchor, and the lanes of a wave take them one
-            // after the other (different lengths, different branches): ~100 load round trips per wave. Touch the two 128-byte
-            // lines in front of the anchor first — one round trip to HBM for both — and the chain runs out of the cache.
-            const uint32_t a0 = ra.pos & ~127u;
-            uint32_t t0 = lg.p[a0], t1 = a0 >= 128 ? lg.p[a0 - 128] : 0u;
-            asm volatile("" ::"v"(t0), "v"(t1));
-            dr = val_domain(lg, db, bloom, tldtab, p.min_labels, ra.pos, ds, de, &dl);
+        if constexpr (DOM) {
+            bool todo = kind == RARE_DOM;
+            const bool inner = todo && ra.pos >= WIN_BACK && ra.pos + (WIN - WIN_BACK) <= lg.len;
+            if (__ballot(inner)) {
+                if (inner) fill_window(ra.pos - WIN_BACK);
+                __builtin_amdgcn_wave_barrier();
+                if (inner) {
+                    const LogView wv{win, WIN};
+                    bool edge = false;
+                    uint32_t s2 = 0, e2 = 0;
+                    const int rw = val_domain(wv, db, bloom, tldtab_p, p.min_labels, WIN_BACK, s2, e2, nullptr, &edge);
+                    if (!edge) { todo = false; dr = rw; ds = s2 + (ra.pos - WIN_BACK); de = e2 + (ra.pos - WIN_BACK); }
+                }
+            }
+            if (todo) {
+                // The walk over the log itself is a chain of dependent 8-byte loads going left from the anchor, and the lanes of a wave take them
+                // one after the other (different lengths, different branches). Touch the two 128-byte lines in front of the anchor first — one
+                // round trip to HBM for both — and the chain runs out of the cache.
+                const uint32_t a0 = ra.pos & ~127u;
+                uint32_t t0 = lg.p[a0], t1 = a0 >= 128 ? lg.p[a0 - 128] : 0u;
+                asm volatile("" ::"v"(t0), "v"(t1));
+                dr = val_domain(lg, db, bloom, tldtab_p, p.min_labels, ra.pos, ds, de, &dl);
+            }
         }
         for (uint64_t lm = __ballot(dr == WALK_LONG); lm; lm &= lm - 1) {
             const int src = __ffsll((long long)lm) - 1;
