@@ -203,7 +203,7 @@ matchy_t* open_bytes(std::vector<uint8_t>&& bytes) {
         if (trace) fprintf(stderr, "[matchy_amd] open: parsed and checked after %.1f ms\n", ms());
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
-            set_error("matchy_amd: no HIP device available (this build has no CPU lookup path)");
+            set_error("matchy_amd: no HIP device available (scans and extraction run on the GPU only; a handle is not opened without one)");
             return nullptr;
         }
         // "uploaded once to device memory" at open. One process per GPU selects its device with MATCHY_AMD_DEVICE.

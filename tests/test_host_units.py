@@ -79,3 +79,95 @@ def test_numa_mapping_of_a_gpu_to_its_cpus(tmp_path):
     assert M.numa_cpus(str(root), "0000:05:00.0") == []
     (root / "devices" / "system" / "node" / "node0" / "cpulist").write_text("1,3-4,x\n")
     assert M.numa_cpus(str(root), "0000:05:00.0") == [1, 3, 4]
+
+
+def _host_lookup_exe(tmp_path_factory_dir):
+    import os
+    csrc = ROOT / "matchy_amd" / "csrc"
+    exe = tmp_path_factory_dir / "host_lookup_cli"
+    if not exe.exists():
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", str(csrc), str(ROOT / "tests/cpp/host_lookup_cli.cpp"),
+                        *(str(csrc / f) for f in ("host_lookup.cpp", "db_image.cpp", "data_codec.cpp", "unicode_lower.cpp")), "-o", str(exe)], check=True)
+    return exe
+
+
+def _host_answers(exe, blob, queries, tmp_path):
+    import json
+    import os
+    (tmp_path / "db.mxy").write_bytes(blob)
+    (tmp_path / "q.txt").write_bytes(b"".join(q.encode("utf-8") + b"\n" for q in queries))
+    env = dict(os.environ, MATCHY_AMD_LOWERCASE=str(ROOT / "matchy_amd" / "data" / "lowercase.bin"))
+    r = subprocess.run([str(exe), str(tmp_path / "db.mxy"), str(tmp_path / "q.txt")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [json.loads(l) for l in r.stdout.splitlines()]
+    assert len(out) == len(queries)
+    return out
+
+
+def test_host_query_path_against_the_oracle(tmp_path):
+    """csrc/host_lookup.cpp — what answers matchy_query since round 5 — compiled on its own with g++ under AddressSanitizer + UBSan (no GPU, no
+    library) against the oracle's Database::lookup: the handmade files (24 / 28 / 32-bit trees, IPv4 in an IPv6 tree, EMPTY / ONE / SPARSE / DENSE
+    automaton nodes, a full ACLH table, a pure wildcard), the tree.rs record vectors, builder-made databases of the synthetic configurations,
+    a glob fuzz case (stars, question marks, classes, multi-byte characters, near misses) and a case-insensitive database."""
+    import json
+    import random
+    import sys
+    sys.path.insert(0, str(ROOT))
+    import matchy_amd as M
+    from oracle import oracle
+    from tools import synth
+    from tests.test_builder_oracle import _tree_kat
+    oracle.build()
+    exe = _host_lookup_exe(tmp_path)
+    gold = ROOT / "tests" / "golden"
+    cases = []
+    exp = json.loads((gold / "handmade_expect.json").read_text())
+    for name in ("24", "28", "32", "v6"):
+        cases.append((f"handmade_{name}", (gold / f"handmade_{name}.mxy").read_bytes(), [q["query"] for q in exp[name]["queries"]]))
+    for name, (blob, _, queries) in _tree_kat().items():
+        if len(blob) < (1 << 22):
+            cases.append((name, blob, [q for q, _ in queries]))
+    rng = random.Random(3)
+    for cfgname in ("c1", "c4/50", "c3b/200"):
+        cfg = synth.config(cfgname)
+        keys = [k.decode() for k, _ in synth.ioc_entries(cfg)]
+        qs = rng.sample(keys, min(len(keys), 300))
+        for k in list(qs):
+            if "/" in k and ":" not in k:
+                qs.append(k.split("/")[0])
+            if k.startswith("*."):
+                qs += ["www" + k[1:], "a.b" + k[1:], k[2:]]
+            if k.startswith("glob:"):
+                qs += [k[5:], "x" + k[5:] + "y"]
+        import re
+        toks = re.findall(rb"[0-9A-Za-z][0-9A-Za-z.:\-]{3,80}", synth.make_log(cfg, 0, 1500))
+        qs += [t.decode() for t in rng.sample(toks, 400)]
+        qs += ["", ".", "1.2.3.4", "::", "::1", "2001:db8::1", "::ffff:1.2.3.4", "münchen.de", "x" * 300, "EXAMPLE.COM"]
+        cases.append((cfgname, synth.build_db(cfg), qs))
+    # glob fuzz (the generator of the GPU glob test) and a case-insensitive twin of it
+    sys.path.insert(0, str(ROOT / "tests"))
+    from tests.test_gpu_parity import _glob_fuzz_case
+    pats, log = _glob_fuzz_case(11)
+    names = [t.decode("utf-8") for t in re.split(rb"[ \n/\"]+", log) if t]
+    for ci in (False, True):
+        b = M.DatabaseBuilder(build_epoch=6, case_insensitive=ci)
+        for pt, i in pats.items():
+            b.add_entry(pt, {"g": i})
+        b.add_entry("literal:" + names[0], {"lit": True})
+        b.add_entry("Straße.Example", {"s": 1})
+        qs = names[:500] + ([n.upper() for n in names[:200]] if ci else []) + ["STRASSE.EXAMPLE", "straße.example", "Straße.Example"]
+        cases.append((f"globfuzz ci={ci}", b.build(), qs))
+    for name, blob, qs in cases:
+        qs = [q for q in qs if "\n" not in q]
+        got = _host_answers(exe, blob, qs, tmp_path)
+        odb = oracle.Database(blob)
+        n_found = 0
+        for q, g in zip(qs, got):
+            want = odb.lookup(q)
+            if want["kind"] in ("notfound", "none"):
+                assert g == {"kind": "notfound"}, (name, q, g)
+            else:
+                n_found += 1
+                assert g == want, (name, q, g, want)
+        assert n_found >= 3, name
