@@ -503,3 +503,22 @@ def test_log_shapes_through_every_device_entry(M, oracle, shape):
     assert len(last[1]) > 1000
     _device_entries(sc, last[0], last[1], None, last[2], slices=(3,))
     sc.close(); db.close()
+
+
+def test_recorded_limits_of_the_hit_record_fail_cleanly(M, oracle):
+    """DESIGN §7 deviation (2): the 16-byte hit record holds a candidate's length in 24 bits and its pattern count in 16. A candidate of 16 MiB
+    or more (the reference extracts it: nothing bounds an e-mail's local part) makes the call FAIL with a message — never a truncated record —
+    and the handle keeps working; just below the limit the item is extracted like the oracle's. (The other limit — a candidate that matches
+    more than 65 535 patterns at once — has NO test on purpose: 66 000 backtracking globs against one 500-byte name are 66 000 x up to 100 000
+    matcher steps in ONE lane of the spill pass; the round-5 attempt to run exactly that took a GPU box down. DESIGN §7.)"""
+    ex = M.Extractor()
+    small = b"ab@c.io 1.2.3.4 "
+    big = b"x" * ((16 << 20) + 5) + b"@a.com "
+    with pytest.raises(RuntimeError) as e:
+        ex.extract_from_chunk(small + big)
+    assert "16 MiB" in str(e.value), str(e.value)
+    assert [(t, v) for t, _, _, v in ex.extract_from_chunk(small)] == [(t, v) for t, _, _, v in oracle.extract(small)]
+    under = b"x" * ((16 << 20) - 64) + b"@a.com "
+    got, want = ex.extract_from_chunk(under), oracle.extract(under)
+    assert [(t, s, e2) for t, s, e2, _ in got] == [(t, s, e2) for t, s, e2, _ in want] and got
+    ex.close()
