@@ -1610,3 +1610,42 @@ json.dump(out, open(sys.argv[3], "w"))
         gpu_answers = json.loads((Path(td) / "out.json").read_text())
     for q, h, g in zip(qs, host_answers, gpu_answers):
         assert h == g, q
+
+
+def test_glob_vectors_of_the_reference_through_matchy_query(M):
+    """glob.rs:464-705 through `matchy_query`: on the host path (the default) and, in a child process with MATCHY_AMD_QUERY_ON_GPU=1, through the
+    lookup kernels (DFA walk, glob matcher with its 100 000-step budget, UTF-8 stepping, case folding)."""
+    import subprocess
+    import sys
+    import tempfile
+    from tests.test_builder_oracle import _glob_kat_dbs
+    dbs = _glob_kat_dbs()
+    for c, blob in dbs:
+        db = M.Database(blob)
+        for t in c["match"]:
+            assert db.lookup(t) == {"found": True, "prefix_len": 0, "data": {"p": 1}}, (c["ref"], c["pattern"], t)
+        for t in c["nomatch"]:
+            assert db.lookup(t) is None, (c["ref"], c["pattern"], t)
+        db.close()
+    with tempfile.TemporaryDirectory() as td:
+        spec = []
+        for i, (c, blob) in enumerate(dbs):
+            (Path(td) / f"{i}.mxy").write_bytes(blob)
+            spec.append({"db": str(Path(td) / f"{i}.mxy"), "match": c["match"], "nomatch": c["nomatch"], "ref": c["ref"]})
+        (Path(td) / "spec.json").write_text(json.dumps(spec))
+        code = r"""
+import json, sys
+sys.path.insert(0, %r)
+import matchy_amd as M
+for s in json.load(open(sys.argv[1])):
+    db = M.Database(open(s["db"], "rb").read())
+    for t in s["match"]:
+        assert db.lookup(t) is not None, (s["ref"], t)
+    for t in s["nomatch"]:
+        assert db.lookup(t) is None, (s["ref"], t)
+    db.close()
+print("OK")
+""" % str(ROOT)
+        p = subprocess.run([sys.executable, "-c", code, str(Path(td) / "spec.json")], env=dict(os.environ, MATCHY_AMD_QUERY_ON_GPU="1"),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-2000:]

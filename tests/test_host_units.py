@@ -171,3 +171,16 @@ def test_host_query_path_against_the_oracle(tmp_path):
                 n_found += 1
                 assert g == want, (name, q, g, want)
         assert n_found >= 3, name
+
+
+def test_host_query_path_on_the_glob_vectors_of_the_reference(tmp_path):
+    """the same vectors (glob.rs:464-705, tests/golden/glob_kat.json) through csrc/host_lookup.cpp under ASan / UBSan"""
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from tests.test_builder_oracle import _glob_kat_dbs
+    exe = _host_lookup_exe(tmp_path)
+    for c, blob in _glob_kat_dbs():
+        qs = [t for t in c["match"] + c["nomatch"] if "\n" not in t]
+        got = _host_answers(exe, blob, qs, tmp_path)
+        for t, g in zip(qs, got):
+            assert (g["kind"] == "pattern") == (t in c["match"]), (c["ref"], c["pattern"], t, g)
