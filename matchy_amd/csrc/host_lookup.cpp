@@ -154,11 +154,14 @@ void ac_literals(const Pg& g, const std::string& text, std::vector<uint32_t>& li
     for (const char tc : text) {
         uint8_t ch = (uint8_t)tc;
         if (g.ci && ch - 'A' < 26u) ch += 32;   // ASCII lower-casing of the text bytes
-        for (;;) {
+        // (a well-formed automaton's failure chain gets one level shallower per step; the bound keeps a file whose links form a cycle from
+        // hanging the query — the reference would spin on it)
+        for (size_t hops = 0, max_hops = g.ac_n / 20 + 1;; ++hops) {
             size_t nx;
             if (ac_transition(g, cur, ch, nx)) { cur = nx; break; }
             if (cur == 0) break;
             if (cur + 20 > g.ac_n) break;
+            if (hops > max_hops) { cur = 0; break; }
             cur = le32(g.ac + cur + 8);   // failure link, then try again
         }
         if (cur + 20 > g.ac_n) continue;
@@ -174,79 +177,87 @@ void ac_literals(const Pg& g, const std::string& text, std::vector<uint32_t>& li
     lits.erase(std::unique(lits.begin(), lits.end()), lits.end());
 }
 
-// match_segments_impl (:1402-1639). 1 = match, 0 = no match, -1 = error (aborts the whole match: the caller's `if let Ok(true)`)
+// match_segments_impl (:1402-1639). 1 = match, 0 = no match, -1 = error (aborts the whole match: the caller's `if let Ok(true)`).
+// The reference recurses once per segment; here only a star recurses (once per position it tries) and the segments between stars are a loop —
+// the same steps in the same order, one budget step per segment visited, but a stack as deep as the pattern has stars, not as long as it is.
 int match_segments(const Pg& g, const std::string& text, size_t first_seg, size_t seg_count, size_t pos, size_t seg, size_t& steps) {
-    if (steps == 0) return 0;
-    --steps;
-    if (seg >= seg_count) return pos >= text.size() ? 1 : 0;
-    const size_t so = first_seg + seg * 12;
-    if (so + 12 > g.n) return 0;
-    const uint8_t* sh = g.b + so;
-    const uint32_t data_len = le32(sh + 4), data_off = le32(sh + 8);
     const uint8_t* t = (const uint8_t*)text.data();
     const size_t tn = text.size();
-    switch (sh[0]) {
-        case 0: {   // literal
-            if ((size_t)data_off + data_len > g.n) return 0;
-            const uint8_t* lit = g.b + data_off;
-            if (!valid_utf8(lit, data_len)) return -1;
-            size_t adv;
-            if (!g.ci) {
-                if (tn - pos < data_len || memcmp(t + pos, lit, data_len) != 0) return 0;
-                adv = data_len;
-            } else {
-                // character by character, ASCII case folded; a text that ends early does not match
-                size_t tp = pos, lp = 0;
-                while (tp < tn && lp < data_len) {
-                    const size_t tl = utf8_len(t[tp]), ll = utf8_len(lit[lp]);
-                    const uint32_t tc = utf8_cp(t + tp, tl), lc = utf8_cp(lit + lp, ll);
-                    if (lower_ascii(tc) != lower_ascii(lc)) return 0;
-                    tp += tl; lp += ll;
+    for (;;) {
+        if (steps == 0) return 0;
+        --steps;
+        if (seg >= seg_count) return pos >= tn ? 1 : 0;
+        const size_t so = first_seg + seg * 12;
+        if (so + 12 > g.n) return 0;
+        const uint8_t* sh = g.b + so;
+        const uint32_t data_len = le32(sh + 4), data_off = le32(sh + 8);
+        switch (sh[0]) {
+            case 0: {   // literal
+                if ((size_t)data_off + data_len > g.n) return 0;
+                const uint8_t* lit = g.b + data_off;
+                if (!valid_utf8(lit, data_len)) return -1;
+                if (!g.ci) {
+                    if (tn - pos < data_len || memcmp(t + pos, lit, data_len) != 0) return 0;
+                    pos += data_len;
+                } else {
+                    // character by character, ASCII case folded; a text that ends early does not match
+                    size_t tp = pos, lp = 0;
+                    while (tp < tn && lp < data_len) {
+                        const size_t tl = utf8_len(t[tp]), ll = utf8_len(lit[lp]);
+                        const uint32_t tc = utf8_cp(t + tp, tl), lc = utf8_cp(lit + lp, ll);
+                        if (lower_ascii(tc) != lower_ascii(lc)) return 0;
+                        tp += tl; lp += ll;
+                    }
+                    if (lp < data_len) return 0;
+                    pos = tp;
                 }
-                if (lp < data_len) return 0;
-                adv = tp - pos;
+                ++seg;
+                continue;
             }
-            return match_segments(g, text, first_seg, seg_count, pos + adv, seg + 1, steps);
-        }
-        case 1: {   // star
-            if (seg + 1 >= seg_count) return 1;
-            size_t p = pos;
-            for (;;) {
-                const int r = match_segments(g, text, first_seg, seg_count, p, seg + 1, steps);
-                if (r != 0) return r;
-                if (p >= tn) break;
-                p += utf8_len(t[p]);
-            }
-            return 0;
-        }
-        case 2:     // question mark: one character
-            if (pos >= tn) return 0;
-            return match_segments(g, text, first_seg, seg_count, pos + utf8_len(t[pos]), seg + 1, steps);
-        case 3: {   // character class
-            if (pos >= tn) return 0;
-            const size_t cl = utf8_len(t[pos]);
-            uint32_t ch = utf8_cp(t + pos, cl);
-            if (g.ci) ch = lower_ascii(ch);
-            if ((size_t)data_off + data_len > g.n) return 0;
-            const size_t items = data_len / 12;
-            bool in_class = false;
-            for (size_t i = 0; i < items && !in_class; ++i) {
-                const uint8_t* it = g.b + data_off + i * 12;
-                uint32_t c1 = le32(it + 4), c2 = le32(it + 8);
-                if (it[0] == 0) {
-                    if (!is_scalar(c1)) continue;
-                    if (g.ci) c1 = lower_ascii(c1);
-                    in_class = ch == c1;
-                } else if (it[0] == 1) {
-                    if (!is_scalar(c1) || !is_scalar(c2)) continue;
-                    if (g.ci) { c1 = lower_ascii(c1); c2 = lower_ascii(c2); }
-                    in_class = ch >= c1 && ch <= c2;
+            case 1: {   // star
+                if (seg + 1 >= seg_count) return 1;
+                size_t p = pos;
+                for (;;) {
+                    const int r = match_segments(g, text, first_seg, seg_count, p, seg + 1, steps);
+                    if (r != 0) return r;
+                    if (p >= tn) break;
+                    p += utf8_len(t[p]);
                 }
+                return 0;
             }
-            if (((sh[1] & 1) != 0) == in_class) return 0;
-            return match_segments(g, text, first_seg, seg_count, pos + cl, seg + 1, steps);
+            case 2:     // question mark: one character
+                if (pos >= tn) return 0;
+                pos += utf8_len(t[pos]);
+                ++seg;
+                continue;
+            case 3: {   // character class
+                if (pos >= tn) return 0;
+                const size_t cl = utf8_len(t[pos]);
+                uint32_t ch = utf8_cp(t + pos, cl);
+                if (g.ci) ch = lower_ascii(ch);
+                if ((size_t)data_off + data_len > g.n) return 0;
+                const size_t items = data_len / 12;
+                bool in_class = false;
+                for (size_t i = 0; i < items && !in_class; ++i) {
+                    const uint8_t* it = g.b + data_off + i * 12;
+                    uint32_t c1 = le32(it + 4), c2 = le32(it + 8);
+                    if (it[0] == 0) {
+                        if (!is_scalar(c1)) continue;
+                        if (g.ci) c1 = lower_ascii(c1);
+                        in_class = ch == c1;
+                    } else if (it[0] == 1) {
+                        if (!is_scalar(c1) || !is_scalar(c2)) continue;
+                        if (g.ci) { c1 = lower_ascii(c1); c2 = lower_ascii(c2); }
+                        in_class = ch >= c1 && ch <= c2;
+                    }
+                }
+                if (((sh[1] & 1) != 0) == in_class) return 0;
+                pos += cl;
+                ++seg;
+                continue;
+            }
+            default: return 0;
         }
-        default: return 0;
     }
 }
 
