@@ -1649,3 +1649,18 @@ print("OK")
         p = subprocess.run([sys.executable, "-c", code, str(Path(td) / "spec.json")], env=dict(os.environ, MATCHY_AMD_QUERY_ON_GPU="1"),
                            capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-2000:]
+
+
+def test_query_tests_again_through_the_lookup_kernels():
+    """Since round 5 `matchy_query` answers on the host; the tests that pin the LOOKUP KERNELS through single queries (handmade files,
+    the reference's behaviour vectors, tree record vectors, Unicode special casing, the structured-data walkers) run a second time in a
+    child process with MATCHY_AMD_QUERY_ON_GPU=1, so that both paths stay pinned by the same vectors."""
+    import subprocess
+    import sys
+    sel = ("handmade_database_files or reference_behaviour_vectors or single_query_api or tree_record_vectors or special_casing "
+           "or structured_data_walkers or case_insensitive_long_non_ascii_key")
+    env = dict(os.environ, MATCHY_AMD_QUERY_ON_GPU="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", str(Path(__file__)), "-q", "-x", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-1000:]
