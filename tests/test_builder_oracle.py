@@ -555,3 +555,28 @@ def test_glob_vectors_of_the_reference_pin_the_oracle(oracle):
         n += len(c["match"]) + len(c["nomatch"])
         odb.close()
     assert n >= 60
+
+
+# crates/matchy/tests/test_ip_exact_match.rs, transcribed as data: (reference lines, keys, addresses that must be found, addresses that must not)
+IP_EXACT_MATCH_KAT = [
+    ("test_ip_exact_match.rs:13-86", [("0.0.0.1", {}), ("0.0.0.3", {}), ("0.0.0.5", {})],
+     ["0.0.0.1", "0.0.0.3", "0.0.0.5"], ["0.0.0.0", "0.0.0.2", "0.0.0.4", "0.0.0.6"]),
+    ("test_ip_exact_match.rs:89-138", [(f"10.0.0.{i}", {}) for i in range(10)],
+     [f"10.0.0.{i}" for i in range(10)], [f"10.0.0.{i}" for i in range(10, 20)] + ["10.0.1.0"]),
+    ("test_ip_exact_match.rs:141-196", [("192.168.1.1", {}), ("192.168.1.100", {}), ("192.168.1.200", {})],
+     ["192.168.1.1", "192.168.1.100", "192.168.1.200"], ["192.168.1.2", "192.168.1.50", "192.168.1.150", "192.168.1.250"]),
+    ("test_ip_exact_match.rs:199-270", [("10.0.0.0/30", {"type": "cidr"}), ("10.0.0.5", {"type": "individual"}), ("10.0.0.10", {"type": "individual"})],
+     ["10.0.0.0", "10.0.0.1", "10.0.0.2", "10.0.0.3", "10.0.0.5", "10.0.0.10"], ["10.0.0.4", "10.0.0.7"]),
+]
+
+
+def test_exact_ip_matching_vectors_of_the_reference(oracle):
+    """test_ip_exact_match.rs: individually inserted addresses match exactly — no neighbour, no implied range — and a /30 beside them covers
+    its four addresses only. Oracle over builder-made databases."""
+    for ref, entries, found, missing in IP_EXACT_MATCH_KAT:
+        db = oracle.Database(build(entries))
+        for q in found:
+            assert db.lookup(q)["kind"] == "ip", (ref, q)
+        for q in missing:
+            assert db.lookup(q)["kind"] == "notfound", (ref, q)
+        db.close()

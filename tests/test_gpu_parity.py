@@ -866,7 +866,19 @@ REFERENCE_BEHAVIOUR = [
 
 
 def test_reference_behaviour_vectors_through_matchy_query(M, oracle):
-    for entries, queries in REFERENCE_BEHAVIOUR:
+    from tests.test_builder_oracle import IP_EXACT_MATCH_KAT
+    # test_ip_exact_match.rs: found / not found as the reference asserts it (the loop below also compares with the oracle)
+    for ref, entries, found, missing in IP_EXACT_MATCH_KAT:
+        b = M.DatabaseBuilder(build_epoch=5)
+        for k, v in entries:
+            b.add_entry(k, v)
+        db = M.Database(b.build())
+        for q in found:
+            assert db.lookup(q) is not None and db.lookup(q)["found"], (ref, q)
+        for q in missing:
+            assert db.lookup(q) is None, (ref, q)
+        db.close()
+    for entries, queries in REFERENCE_BEHAVIOUR + [(e, f + m) for _, e, f, m in IP_EXACT_MATCH_KAT]:
         b = M.DatabaseBuilder(build_epoch=5)
         for k, v in entries:
             b.add_entry(k, v)
@@ -1664,3 +1676,65 @@ def test_query_tests_again_through_the_lookup_kernels():
                        env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-1000:]
+
+
+def test_query_cache_is_per_handle_and_handles_are_isolated(M, tmp_path):
+    """crates/matchy/tests/cache_stale_notfound_test.rs (a cached NotFound — or a cached match — of one database must not answer for the
+    next one opened, same path rewritten included) and sequential_builder_test.rs (databases built one after the other, queried
+    interleaved, each answer only its own keys), through matchy_open / matchy_query with the query cache on. The cache here is per thread
+    AND handle (capi.cpp Db::cache): a new handle starts empty whatever address or path it has."""
+    import threading
+
+    def build(entries):
+        b = M.DatabaseBuilder(build_epoch=7)
+        for k, v in entries:
+            b.add_entry(k, v)
+        blob = b.build()
+        b.close()
+        return blob
+    ip = "80.239.174.89"
+    a, bb = build([("1.1.1.0/24", {"name": "other"})]), build([("80.239.0.0/16", {"name": "matched"})])
+    # cache_stale_notfound_test.rs:37-135 — NotFound cached by A must not persist into B ...
+    for first, second, want in ((a, bb, {"found": True, "prefix_len": 16, "data": {"name": "matched"}}), (bb, a, None)):   # ... nor a match (:138-222)
+        d1 = M.Database(first)
+        for _ in range(3):
+            d1.lookup(ip)
+        d1.close()
+        d2 = M.Database(second)
+        assert d2.lookup(ip) == want and d2.lookup(ip) == want
+        d2.close()
+    # :389-460 — the same PATH rewritten and reopened
+    path = tmp_path / "db.mxy"
+    path.write_bytes(a)
+    d = M.Database(str(path))
+    assert d.lookup(ip) is None
+    d.close()
+    os.chmod(path, 0o644)
+    path.write_bytes(bb)
+    d = M.Database(str(path))
+    assert d.lookup(ip) == {"found": True, "prefix_len": 16, "data": {"name": "matched"}}
+    d.close()
+    # sequential_builder_test.rs:23-100, 210-285 — three databases open at once, interleaved queries, also from other threads
+    dbs = [M.Database(build([(f"{i}.{i}.{i}.{i}", {"db": i}), (f"host{i}.example.com", {"db": i}), (f"*.zone{i}.test", {"db": i})])) for i in (1, 2, 3)]
+
+    def rounds(n, errs):
+        try:
+            for r in range(n):
+                for i, d in zip((1, 2, 3), dbs):
+                    for j in (1, 2, 3):
+                        for q, hit in ((f"{j}.{j}.{j}.{j}", {"found": True, "prefix_len": 32, "data": {"db": j}}),
+                                       (f"host{j}.example.com", {"found": True, "prefix_len": 0, "data": {"db": j}}),
+                                       (f"a.zone{j}.test", {"found": True, "prefix_len": 0, "data": {"db": j}})):
+                            got = d.lookup(q)
+                            assert got == (hit if i == j else None), (r, i, j, q, got)
+        except AssertionError as e:
+            errs.append(e)
+    errs = []
+    rounds(10, errs)
+    ths = [threading.Thread(target=rounds, args=(5, errs)) for _ in range(4)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert not errs, errs[:1]
+    st = dbs[0].stats()
+    assert st["cache_hits"] > 0 and st["total_queries"] == st["cache_hits"] + st["cache_misses"]
+    for d in dbs:
+        d.close()

@@ -184,3 +184,15 @@ def test_host_query_path_on_the_glob_vectors_of_the_reference(tmp_path):
         got = _host_answers(exe, blob, qs, tmp_path)
         for t, g in zip(qs, got):
             assert (g["kind"] == "pattern") == (t in c["match"]), (c["ref"], c["pattern"], t, g)
+
+
+def test_host_query_path_on_the_exact_ip_vectors_of_the_reference(tmp_path):
+    """test_ip_exact_match.rs through csrc/host_lookup.cpp (ASan / UBSan)"""
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from tests.test_builder_oracle import IP_EXACT_MATCH_KAT, build
+    exe = _host_lookup_exe(tmp_path)
+    for ref, entries, found, missing in IP_EXACT_MATCH_KAT:
+        got = _host_answers(exe, build(entries), found + missing, tmp_path)
+        for q, g in zip(found + missing, got):
+            assert (g["kind"] == "ip") == (q in found), (ref, q, g)
