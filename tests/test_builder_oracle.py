@@ -580,3 +580,61 @@ def test_exact_ip_matching_vectors_of_the_reference(oracle):
         for q in missing:
             assert db.lookup(q)["kind"] == "notfound", (ref, q)
         db.close()
+
+
+# crates/matchy-paraglob/tests/integration_tests.rs:11-260 (Paraglob::find_all on patterns given directly to the paraglob builder), as data.
+# Through a database the same patterns are written with the `glob:` prefix where they carry no wildcard — that is what routes a key into the
+# paraglob section as a LITERAL pattern with its substring semantics (mmdb_builder.rs:399-406, Q9); pattern ids are positional (all keys are
+# glob entries). Expectation per text: ("n", k) exactly k ids, ("ge", k) at least k, ("has", [ids]) those ids among them, ("none",) nothing.
+# Not transcribed: test_duplicate_pattern_deduplication (:43-62: duplicate strings inside ONE paraglob builder — the database builder keys its
+# entries by string) and the `v2` tests (:263-700: the paraglob's own data section, unused in combined databases).
+PARAGLOB_KAT = [
+    ("integration_tests.rs:11", False, ["*.txt", "test*", "*file*"],
+     [("document.txt", ("ge", 1)), ("test_case", ("ge", 1)), ("myfile.dat", ("ge", 1)), ("nomatch", ("none",))]),
+    ("integration_tests.rs:27", False, ["hello", "world", "test"],
+     [("hello", ("n", 1)), ("world", ("n", 1)), ("hello world", ("n", 2)), ("nomatch", ("none",))]),
+    ("integration_tests.rs:64", False, ["*.txt", "*file*", "test*"], [("testfile.txt", ("has", [0, 1, 2])), ("testfile.txt", ("n", 3))]),
+    ("integration_tests.rs:78", False, ["Test*", "HELLO"], [("Test123", ("ge", 1)), ("test123", ("none",)), ("HELLO", ("ge", 1)), ("hello", ("none",))]),
+    ("integration_tests.rs:100", True, ["Test*", "HELLO"], [("Test123", ("ge", 1)), ("test123", ("ge", 1)), ("HELLO", ("ge", 1)), ("hello", ("ge", 1))]),
+    ("integration_tests.rs:122", False, ["test"], [("", ("none",)), ("test", ("n", 1))]),
+    ("integration_tests.rs:134", False, ["exact_match", "another_literal", "third"],
+     [("exact_match", ("n", 1)), ("prefix_exact_match_suffix", ("n", 1)), ("nomatch", ("none",))]),
+    ("integration_tests.rs:152", False, ["*test*", "test*", "*test"], [("test", ("n", 3)), ("testing", ("n", 2)), ("mytest", ("n", 2)), ("mytesting", ("n", 1))]),
+    ("integration_tests.rs:169", False, ["*.rs", "*.toml", "Cargo.*", "src/*", "*.md"],
+     [("main.rs", ("ge", 1)), ("Cargo.toml", ("ge", 2)), ("src/lib.rs", ("ge", 2)), ("README.md", ("ge", 1)), ("test.py", ("none",))]),
+    ("integration_tests.rs:190", False, [f"pattern_{i}_*" for i in range(1000)],
+     [("pattern_500_test", ("has", [500])), ("pattern_999_data", ("has", [999])), ("nomatch", ("none",))]),
+    ("integration_tests.rs:222", False, ["hello", "*.txt", "test_*"],
+     [("hello.txt", ("n", 2)), ("hello.txt", ("has", [0, 1])), ("test_file.txt", ("n", 2)), ("test_file.txt", ("has", [1, 2]))]),
+    ("integration_tests.rs:242", False, ["*", "?", "**"], [("test", ("ge", 2)), ("a", ("ge", 3)), ("", ("ge", 2))]),
+]
+
+
+def paraglob_kat_db(patterns, ci):
+    b = M.DatabaseBuilder(build_epoch=9, case_insensitive=ci)
+    for i, p in enumerate(patterns):
+        wild = any(ch in p for ch in "*?[")
+        b.add_entry(p if wild else "glob:" + p, {"i": i})
+    blob = b.build()
+    b.close()
+    return blob
+
+
+def paraglob_kat_check(ids, expect):
+    if expect[0] == "n":
+        return len(ids) == expect[1]
+    if expect[0] == "ge":
+        return len(ids) >= expect[1]
+    if expect[0] == "has":
+        return all(i in ids for i in expect[1])
+    return not ids
+
+
+def test_paraglob_integration_vectors_of_the_reference(oracle):
+    for ref, ci, patterns, checks in PARAGLOB_KAT:
+        db = oracle.Database(paraglob_kat_db(patterns, ci))
+        for text, expect in checks:
+            r = db.lookup(text)
+            ids = r.get("pattern_ids", []) if r["kind"] == "pattern" else []
+            assert paraglob_kat_check(ids, expect), (ref, text, expect, ids)
+        db.close()

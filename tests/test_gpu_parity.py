@@ -1670,7 +1670,7 @@ def test_query_tests_again_through_the_lookup_kernels():
     import subprocess
     import sys
     sel = ("handmade_database_files or reference_behaviour_vectors or single_query_api or tree_record_vectors or special_casing "
-           "or structured_data_walkers or case_insensitive_long_non_ascii_key")
+           "or structured_data_walkers or case_insensitive_long_non_ascii_key or paraglob_integration_vectors or per_handle")
     env = dict(os.environ, MATCHY_AMD_QUERY_ON_GPU="1")
     p = subprocess.run([sys.executable, "-m", "pytest", str(Path(__file__)), "-q", "-x", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
@@ -1738,3 +1738,17 @@ def test_query_cache_is_per_handle_and_handles_are_isolated(M, tmp_path):
     assert st["cache_hits"] > 0 and st["total_queries"] == st["cache_hits"] + st["cache_misses"]
     for d in dbs:
         d.close()
+
+
+def test_paraglob_integration_vectors_through_matchy_query(M):
+    """matchy-paraglob/tests/integration_tests.rs:11-260 (tests/test_builder_oracle.py PARAGLOB_KAT) through matchy_amd_query_json: the ids of the
+    patterns that matched come back as their data values. Runs on the host path here and through the lookup kernels in the child process of
+    test_query_tests_again_through_the_lookup_kernels."""
+    from tests.test_builder_oracle import PARAGLOB_KAT, paraglob_kat_check, paraglob_kat_db
+    for ref, ci, patterns, checks in PARAGLOB_KAT:
+        db = M.Database(paraglob_kat_db(patterns, ci))
+        for text, expect in checks:
+            found, arr = db.query_json(text)
+            ids = [d["i"] for d in arr]
+            assert paraglob_kat_check(ids, expect) and found == bool(ids), (ref, text, expect, ids)
+        db.close()

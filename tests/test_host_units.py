@@ -196,3 +196,16 @@ def test_host_query_path_on_the_exact_ip_vectors_of_the_reference(tmp_path):
         got = _host_answers(exe, build(entries), found + missing, tmp_path)
         for q, g in zip(found + missing, got):
             assert (g["kind"] == "ip") == (q in found), (ref, q, g)
+
+
+def test_host_query_path_on_the_paraglob_vectors_of_the_reference(tmp_path):
+    """matchy-paraglob/tests/integration_tests.rs:11-260 through csrc/host_lookup.cpp (ASan / UBSan)"""
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from tests.test_builder_oracle import PARAGLOB_KAT, paraglob_kat_check, paraglob_kat_db
+    exe = _host_lookup_exe(tmp_path)
+    for ref, ci, patterns, checks in PARAGLOB_KAT:
+        got = _host_answers(exe, paraglob_kat_db(patterns, ci), [t for t, _ in checks], tmp_path)
+        for (text, expect), g in zip(checks, got):
+            ids = g.get("pattern_ids", []) if g["kind"] == "pattern" else []
+            assert paraglob_kat_check(ids, expect), (ref, text, expect, g)
