@@ -582,6 +582,38 @@ def test_exact_ip_matching_vectors_of_the_reference(oracle):
         db.close()
 
 
+# crates/matchy/tests/test_literal_hash.rs:52-300 as data: (reference lines, keys, [(query, kind the reference asserts, number of pattern ids)]).
+# add_literal / add_glob of the reference are the `literal:` / `glob:` prefixes of add_entry (mmdb_builder.rs:399-406); a literal holding glob
+# characters stays a literal (:220-265). The last row is test_builder_stats (:267-300) read back from the metadata the builder writes.
+LITERAL_HASH_KAT = [
+    ("test_literal_hash.rs:53", [("literal:evil.com", {"source": "literal"}), ("glob:*.com", {"source": "glob"})],
+     [("evil.com", "pattern", 2), ("other.com", "pattern", 1), ("evil.org", "notfound", 0)]),
+    ("test_literal_hash.rs:118", [("glob:*.phishing.com", {"type": "glob"}), ("glob:bad-*", {"type": "glob"})],
+     [("test.phishing.com", "pattern", 1), ("bad-actor", "pattern", 1), ("good-actor", "notfound", 0)]),
+    ("test_literal_hash.rs:161", [("1.2.3.4", {"type": "ip"}), ("literal:evil.com", {"type": "literal"}), ("glob:*.bad.com", {"type": "glob"})],
+     [("1.2.3.4", "ip", 0), ("evil.com", "pattern", 1), ("test.bad.com", "pattern", 1), ("1.2.3.5", "notfound", 0)]),
+    ("test_literal_hash.rs:221", [("literal:file[1].txt", {"note": "has brackets"}), ("literal:what?.com", {"note": "has brackets"}),
+                                  ("literal:price*list", {"note": "has brackets"})],
+     [("file[1].txt", "pattern", 1), ("what?.com", "pattern", 1), ("price*list", "pattern", 1), ("file2.txt", "notfound", 0),
+      ("file1.txt", "notfound", 0), ("whatX.com", "notfound", 0), ("priceXXlist", "notfound", 0)]),
+    ("test_literal_hash.rs:268", [("1.2.3.4", {}), ("literal:evil.com", {}), ("literal:bad.org", {}), ("glob:*.phishing.com", {})], []),
+]
+
+
+def test_literal_hash_vectors_of_the_reference(oracle):
+    for ref, entries, checks in LITERAL_HASH_KAT:
+        db = oracle.Database(build(entries))
+        for q, kind, n in checks:
+            r = db.lookup(q)
+            assert r["kind"] == kind and len(r.get("pattern_ids", [])) == n, (ref, q, r)
+        if ref.endswith(":53"):
+            assert sorted(d["source"] for d in db.lookup("evil.com")["data"]) == ["glob", "literal"]
+        if ref.endswith(":268"):
+            md = db.metadata()
+            assert (md["ip_entry_count"], md["literal_entry_count"], md["glob_entry_count"]) == (1, 2, 1)
+        db.close()
+
+
 # crates/matchy-paraglob/tests/integration_tests.rs:11-260 (Paraglob::find_all on patterns given directly to the paraglob builder), as data.
 # Through a database the same patterns are written with the `glob:` prefix where they carry no wildcard — that is what routes a key into the
 # paraglob section as a LITERAL pattern with its substring semantics (mmdb_builder.rs:399-406, Q9); pattern ids are positional (all keys are

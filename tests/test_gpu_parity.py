@@ -1670,7 +1670,7 @@ def test_query_tests_again_through_the_lookup_kernels():
     import subprocess
     import sys
     sel = ("handmade_database_files or reference_behaviour_vectors or single_query_api or tree_record_vectors or special_casing "
-           "or structured_data_walkers or case_insensitive_long_non_ascii_key or paraglob_integration_vectors or per_handle")
+           "or structured_data_walkers or case_insensitive_long_non_ascii_key or paraglob_integration_vectors or literal_hash_vectors or per_handle")
     env = dict(os.environ, MATCHY_AMD_QUERY_ON_GPU="1")
     p = subprocess.run([sys.executable, "-m", "pytest", str(Path(__file__)), "-q", "-x", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
@@ -1751,4 +1751,25 @@ def test_paraglob_integration_vectors_through_matchy_query(M):
             found, arr = db.query_json(text)
             ids = [d["i"] for d in arr]
             assert paraglob_kat_check(ids, expect) and found == bool(ids), (ref, text, expect, ids)
+        db.close()
+
+
+def test_literal_hash_vectors_through_matchy_query(M):
+    """crates/matchy/tests/test_literal_hash.rs:52-265 (tests/test_builder_oracle.py LITERAL_HASH_KAT) through matchy_amd_query_json and
+    matchy_query: literal and glob on one text give two data objects, the literal's first; literals holding glob characters match exactly and
+    nothing else. Host path here, lookup kernels in the child process of test_query_tests_again_through_the_lookup_kernels."""
+    from tests.test_builder_oracle import LITERAL_HASH_KAT, build
+    for ref, entries, checks in LITERAL_HASH_KAT:
+        db = M.Database(build(entries))
+        for q, kind, n in checks:
+            found, arr = db.query_json(q)
+            r = db.lookup(q)
+            if kind == "notfound":
+                assert not found and arr == [] and r is None, (ref, q, arr)
+            elif kind == "ip":
+                assert found and len(arr) == 1 and arr[0]["prefix_len"] == 32 and r["found"] and r["prefix_len"] == 32, (ref, q, arr)
+            else:
+                assert found and len(arr) == n and r["found"] and r["prefix_len"] == 0 and r["data"] == arr[0], (ref, q, arr, r)
+        if ref.endswith(":53"):
+            assert [d["source"] for d in db.query_json("evil.com")[1]] == ["literal", "glob"]
         db.close()

@@ -209,3 +209,17 @@ def test_host_query_path_on_the_paraglob_vectors_of_the_reference(tmp_path):
         for (text, expect), g in zip(checks, got):
             ids = g.get("pattern_ids", []) if g["kind"] == "pattern" else []
             assert paraglob_kat_check(ids, expect), (ref, text, expect, g)
+
+
+def test_host_query_path_on_the_literal_hash_vectors_of_the_reference(tmp_path):
+    """crates/matchy/tests/test_literal_hash.rs:52-265 through csrc/host_lookup.cpp (ASan / UBSan)"""
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from tests.test_builder_oracle import LITERAL_HASH_KAT, build
+    exe = _host_lookup_exe(tmp_path)
+    for ref, entries, checks in LITERAL_HASH_KAT:
+        if not checks:
+            continue
+        got = _host_answers(exe, build(entries), [q for q, _, _ in checks], tmp_path)
+        for (q, kind, n), g in zip(checks, got):
+            assert g["kind"] == kind and len(g.get("pattern_ids", [])) == n, (ref, q, g)
