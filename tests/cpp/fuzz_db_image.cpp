@@ -12,6 +12,8 @@
 
 #include "db_builder.h"
 #include "db_image.h"
+#include "host_lookup.h"
+#include "netaddr.h"
 
 using namespace mxy;
 
@@ -98,6 +100,30 @@ static size_t exercise(const DbImage& img) {
         }
     }
     sink += walk_value(img.metadata, 0) + img.format_name().size();
+    // ... and the single-query path of matchy_query (csrc/host_lookup.cpp) walks the same tables on the host: addresses, keys the seeds
+    // hold, names their globs match, long and non-ASCII texts. Whatever it answers on a mutated image, it answers within the image.
+    {
+        static const char* const Q[] = {
+            "10.0.0.0", "10.7.49.91", "10.249.243.237", "255.255.255.255", "0.0.0.0", "2001:db8:3::9", "2001:db8:18::48", "::1", "::ffff:10.1.2.3",
+            "host0.example0.com", "host24.example3.com", "HOST3.EXAMPLE3.COM", "www.bad7.example.org", "a.b.c.bad39.example.org", "evil3-x-a1.net",
+            "evil10-some-thing-cz.net", "evil.example.com", "x.evil.example.com", "", "a", "caf\xc3\xa9.fr", "\xc4\xb0stanbul.example.org",
+            "aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa.bad1.example.org",
+        };
+        const HostTables tables(img);
+        sink += tables.v4_start_node + tables.lit2pat.size();
+        for (const char* q : Q) {
+            const std::string query(q);
+            IpAddr ip;
+            const bool is_ip = parse_ip(query.data(), query.size(), ip);
+            HostHit h;
+            host_lookup(img, tables, query, is_ip ? &ip : nullptr, h);
+            sink += h.kind + h.prefix_len + h.globs.size();
+            uint32_t off = 0;
+            if (h.kind == 2) { DataValue v; if (img.decode_data(h.a, v)) sink += walk_value(v, 0); }
+            if (h.kind == 3 && h.a != 0xFFFFFFFFu && img.lit_data_offset(h.a, off)) { DataValue v; if (img.decode_data(off, v)) sink += walk_value(v, 0); }
+            for (uint32_t g : h.globs) if (img.glob_data_offset(g, off)) { DataValue v; if (img.decode_data(off, v)) sink += walk_value(v, 0); }
+        }
+    }
     return sink;
 }
 

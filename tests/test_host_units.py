@@ -33,7 +33,7 @@ def test_mutated_database_files_under_sanitizers(tmp_path):
     exe = tmp_path / "fuzz_db_image"
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                     "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", str(csrc), str(ROOT / "tests/cpp/fuzz_db_image.cpp"),
-                    *(str(csrc / f) for f in ("db_image.cpp", "data_codec.cpp", "db_builder.cpp", "unicode_lower.cpp")), "-o", str(exe)], check=True)
+                    *(str(csrc / f) for f in ("db_image.cpp", "data_codec.cpp", "db_builder.cpp", "unicode_lower.cpp", "host_lookup.cpp")), "-o", str(exe)], check=True)
     seeds = sorted(str(p) for p in (ROOT / "tests" / "golden").glob("handmade_*.mxy"))
     assert seeds
     env = dict(os.environ, MATCHY_AMD_LOWERCASE=str(ROOT / "matchy_amd" / "data" / "lowercase.bin"))
