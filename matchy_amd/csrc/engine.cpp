@@ -897,6 +897,11 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         // — k_rare takes what they leave — then get a launch of their own in front of the rare anchors (IPv6 / e-mail: ten times as
         // many, 0.12 ms), so that k_rare runs beside those instead of behind them.
         const bool rare_own = L.split_misc && rare_possible && !L.ip_pass;
+        // Long lists (dense logs): these passes wait for memory most of their time, and beyond a few workgroups per CU more of them only
+        // queue up in front of it. Measured per pass on 1.85 GB batches (tools/sweep_misc_grid.sh, profiles/r05_log_shapes.txt): long tokens
+        // 8 -> 6 per CU: step 2.61 -> 2.41 ms (endpoint log with hashes); '@' / "::" anchors 8 -> 4: 2.37 -> 2.31 (JSON lines); domains
+        // k_validate_dom left undecided 8 -> 2: 2.36 -> 2.22 (proxy log with URLs). Short lists keep their default grids.
+        constexpr int TOK_WGS_PER_CU = 6, RARE_WGS_PER_CU = 4, RARE_DOM_WGS_PER_CU = 2;
         // Both lists long (the previous batch had hundreds of thousands of long tokens AND of IPv6 / e-mail anchors: application logs in
         // JSON lines): the long tokens do not run in front of the rare anchors on the third stream but beside them on the second, in front
         // of k_rare (which takes what they leave: stream order instead of an event), and list their hashes in k_rare's candidate list — the
@@ -910,18 +915,18 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
             TokParams tt = t1;
             tt.vmode = 4u;
             tt.cands = work_[0].cands_r.p; tt.cand_cap = (uint32_t)work_[0].cands_r.n; tt.n_cand = &counters_.p->n_cand_r;
-            launch_validate_misc(tt, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_tok, 1024, std::max(1, n_cu_ / 2), 8), aux_stream_);
+            launch_validate_misc(tt, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_tok, 1024, std::max(1, n_cu_ / 2), TOK_WGS_PER_CU), aux_stream_);
             t1.vmode = 1u;
         } else if (rare_own) {
             TokParams tt = t1;
             tt.vmode = 4u;
-            launch_validate_misc(tt, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_tok, 1024, std::max(1, n_cu_ / 2), 8), aux2_stream_);   // 6 KB of LDS, workgroups beyond the list leave at once
+            launch_validate_misc(tt, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_tok, 1024, std::max(1, n_cu_ / 2), TOK_WGS_PER_CU), aux2_stream_);   // 6 KB of LDS, workgroups beyond the list leave at once
             if (!ev_v1_) MXY_HIP(hipEventCreateWithFlags(&ev_v1_, hipEventDisableTiming));
             MXY_HIP(hipEventRecord(ev_v1_, aux2_stream_));
             t1.vmode = 1u;
         }
         // beside k_validate_dom: half the CUs, so that kernel keeps most of its resident waves (more when the previous batch's lists were long)
-        launch_validate_misc(t1, view, misc_wgs > 0 ? misc_wgs : grid_for(rare_own ? hint_.n_rare : std::max(hint_.n_rare, hint_.n_tok), 1024, std::max(1, n_cu_ / 2), 8), aux2_stream_);
+        launch_validate_misc(t1, view, misc_wgs > 0 ? misc_wgs : grid_for(rare_own ? hint_.n_rare : std::max(hint_.n_rare, hint_.n_tok), 1024, std::max(1, n_cu_ / 2), rare_own ? RARE_WGS_PER_CU : 8), aux2_stream_);
         // Split lists: the side chains do not join the scan's stream through events — the last kernel of each (a k_lookup launch) reports
         // its end in ScanCounters::chains_done, which k_finish polls (arrive_chain 1: third stream, 2: k_rare's, 3: the fourth stream)
         static const bool env_join = getenv("MATCHY_AMD_EVENT_JOIN") != nullptr;
@@ -978,7 +983,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
                 MXY_HIP(hipEventRecord(ev_join3_, dom_stream_));
             }
             t2.cands = work_[0].cands_d.p; t2.cand_cap = (uint32_t)work_[0].cands_d.n; t2.n_cand = &counters_.p->n_cand_d;
-            launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_rare_dom, 512, n_cu_, 8), stream);
+            launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_rare_dom, 512, n_cu_, RARE_DOM_WGS_PER_CU), stream);
             launch_lookup(L.ld, view, grid_for(hint_.n_cand_d, 512, std::max(1, n_cu_ / 8), 4), stream);
         } else {
             if (early_glob_) {
@@ -1019,7 +1024,7 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
                 }
                 expect_chains_ = chains;
             }
-            if (!(early_glob_ && glob_v2_aside_)) launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_rare_dom, 512, n_cu_, 8), stream);
+            if (!(early_glob_ && glob_v2_aside_)) launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_rare_dom, 512, n_cu_, RARE_DOM_WGS_PER_CU), stream);
             // no timing events inside the forked tail: every packet between two kernels of the chain is ~6-8 us of it, and with
             // kernels running side by side the intervals would not be kernel times anyway (ScanTiming: validate_ms = the whole tail)
             MXY_HIP(hipStreamWaitEvent(stream, ev_join2_, 0));

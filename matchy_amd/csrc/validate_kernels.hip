@@ -1344,7 +1344,12 @@ void launch_validate_dom(const TokParams& p, const DevDb& db, int grid, hipStrea
 }
 // k_validate (tokens, rare anchors, undecided domains: TokParams::vmode says which lists) has a fraction of the work and is
 // latency-bound: every workgroup stages the suffix tables first, so few workgroups (one per CU measured best for the whole job)
+static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
 void launch_validate_misc(const TokParams& p, const DevDb& db, int grid, hipStream_t stream) {
+    // experiments: MATCHY_AMD_MISC_GRID_V<vmode>=<workgroups> overrides the grid of one variant (tools/sweep_misc_grid.sh)
+    static const int ov[8] = {0, env_int("MATCHY_AMD_MISC_GRID_V1"), env_int("MATCHY_AMD_MISC_GRID_V2"), 0, env_int("MATCHY_AMD_MISC_GRID_V4"),
+                              env_int("MATCHY_AMD_MISC_GRID_V5"), 0, env_int("MATCHY_AMD_MISC_GRID_V7")};
+    if (ov[p.vmode & 7u] > 0) grid = ov[p.vmode & 7u];
     if (p.vmode == 5u) hipLaunchKernelGGL(k_validate<5u>, dim3(grid), dim3(256), 0, stream, p, db);
     else if (p.vmode == 4u) hipLaunchKernelGGL(k_validate<4u>, dim3(grid), dim3(256), 0, stream, p, db);
     else if (p.vmode == 1u) hipLaunchKernelGGL(k_validate<1u>, dim3(grid), dim3(256), 0, stream, p, db);
