@@ -935,7 +935,8 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         if (L.split_misc) {
             LookupParams lm = L.lm;
             if (arrive && (rare_own || !rare_possible)) { lm.arrive_chain = 1; lm.arrive = counters_.p; ++chains; }
-            launch_lookup(lm, view, grid_for(hint_.n_cand_m, 512, std::max(1, n_cu_ / 2), 4), aux2_stream_);
+            static const int lm_wgs = getenv("MATCHY_AMD_LMGRID") ? atoi(getenv("MATCHY_AMD_LMGRID")) : 0;   // experiments (tools/sweep_tail_knobs.sh)
+            launch_lookup(lm, view, lm_wgs > 0 ? lm_wgs : grid_for(hint_.n_cand_m, 512, std::max(1, n_cu_ / 2), 4), aux2_stream_);
         }
         if (rare_possible) {   // one wave per SIMD (297 VGPRs)
             TokParams tr = t1;
@@ -984,7 +985,8 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
             }
             t2.cands = work_[0].cands_d.p; t2.cand_cap = (uint32_t)work_[0].cands_d.n; t2.n_cand = &counters_.p->n_cand_d;
             launch_validate_misc(t2, view, misc_wgs > 0 ? misc_wgs : grid_for(hint_.n_rare_dom, 512, n_cu_, RARE_DOM_WGS_PER_CU), stream);
-            launch_lookup(L.ld, view, grid_for(hint_.n_cand_d, 512, std::max(1, n_cu_ / 8), 4), stream);
+            static const int ld_wgs = getenv("MATCHY_AMD_LDGRID") ? atoi(getenv("MATCHY_AMD_LDGRID")) : 0;
+            launch_lookup(L.ld, view, ld_wgs > 0 ? ld_wgs : grid_for(hint_.n_cand_d, 512, std::max(1, n_cu_ / 8), 4), stream);
         } else {
             if (early_glob_) {
                 // Databases with globs keep one candidate list, but the candidates k_validate_dom flags for the glob pass — most of that

@@ -989,6 +989,37 @@ __global__ __launch_bounds__(256) void k_validate_dom(TokParams p, DevDb db) {
     if (lane_id() == 0 && n_valid) atomicAdd(&p.counters->cand_true, n_valid);
 }
 
+// "Can a literal key be the text log[s, s + n)?" for the passes that list candidates one by one (DevDb::lit_bm: every key enters with its
+// first 32 bytes and its length — engine.cpp). false = no key can be it: the candidate is counted and not listed. The keys of a
+// case-insensitive database were lower-cased with the Unicode tables, which can change the LENGTH of a text that is not pure ASCII: such a
+// text is decided here only when all of it was looked at (n <= 32, no byte >= 0x80) or the caller knows it is ASCII (e-mail addresses).
+__device__ __forceinline__ bool lit_bm_may_hit(const DevDb& db, const LogView& lg, uint32_t s, uint32_t n, bool ascii) {
+    uint64_t l[4] = {0, 0, 0, 0};
+    if (s + 32 <= lg.len) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __builtin_memcpy(&l[k], lg.p + s + 8 * k, 8);
+    } else {
+        for (uint32_t k = 0; k < 32 && s + k < lg.len; ++k) l[k >> 3] |= (uint64_t)lg.p[s + k] << (8 * (k & 7));
+    }
+    if (db.ci) {
+        if (!ascii) {
+            if (n > 32) return true;
+            uint64_t high = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rem = (int)n - 8 * k;
+                const uint64_t m = rem >= 8 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << (8 * rem)) - 1ull));
+                high |= l[k] & m & 0x8080808080808080ull;
+            }
+            if (high) return true;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) l[k] = ascii_lower8(l[k]);
+    }
+    const uint32_t b = name_hash31(l[0], l[1], l[2], l[3], n) & db.lit_bm_mask;
+    return ((db.lit_bm[b >> 5] >> (b & 31)) & 1u) != 0;
+}
+
 // k_validate — stage A2b: one lane per long token (hex hashes; prefix tests for the address formats) and per rare
 // anchor: IPv6, e-mail, and the domain anchors k_validate_dom could not decide (general right-to-left walk).
 // VM = TokParams::vmode of the launch (bit 0: k_anchor's rare anchors, bit 1: the undecided domains, bit 2: the long tokens — a launch of
@@ -1273,6 +1304,14 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         if (dr == WALK_YES) {
             if (de - ds > 0xFFFFFFu) atomicOr(&p.counters->error, 4u);
             c.start = ds; c.len_type = (de - ds) | ((uint32_t)IT_DOMAIN << 24); emit = true;
+        }
+        // E-mail addresses and the names of the general walk, like the names k_validate_dom decides and the hashes above: in a database
+        // without globs only a literal key can match them, and the bitmap of the keys says which of them could (an application log with
+        // an address in every fourth line, a proxy log with 2 M long host names: the lookup pass behind this one read every one of them
+        // again, 0.1-0.2 ms at the end of the step)
+        if (tok_filter && emit) {
+            const uint32_t ty = c.len_type >> 24;
+            if ((ty == IT_EMAIL || ty == IT_DOMAIN) && !lit_bm_may_hit(db, lg, c.start, c.len_type & 0xFFFFFFu, ty == IT_EMAIL)) { emit = false; ++unlisted; }
         }
         cw.append(emit, c, p.cands, p.cand_cap, p.n_cand);
     }
