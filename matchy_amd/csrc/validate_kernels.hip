@@ -363,6 +363,77 @@ __device__ __forceinline__ int val_domain_pre(const uint2* tldtab, uint32_t min_
     return 2;
 }
 
+// val_domain_pre over NB context words instead of three, for the anchors k_validate_dom could not decide from its 24 context bytes (a proxy
+// log: 2 M host names of 25..48 bytes in front of their last label per batch, which otherwise all take the byte-and-word loops of the general
+// walk): w = log[j, j+8), b[k] = log[j-8(k+1), j-8k). The same rules on the same masks, written as loops over the words that unroll. A name
+// decided here has at most 8 NB + 7 <= 63 bytes, so the 63-byte label and 253-byte name limits of is_valid_domain (ext:637-689) cannot bite
+// (NB <= 7). Returns 0 (no domain), 1 (domain: start / end set) or 2 (undecided: the general walk).
+template <int NB>
+__device__ __forceinline__ int val_domain_ctx(const uint2* tldtab, uint32_t min_labels, uint32_t j, uint2 w, const uint64_t (&b)[NB],
+                                              uint32_t& start, uint32_t& end) {
+    static_assert(NB >= 1 && NB <= 7, "a label must not reach 64 bytes inside the context");
+    constexpr uint64_t H = 0x8080808080808080ull;
+    const uint64_t w64 = (uint64_t)w.x | ((uint64_t)w.y << 32);
+    const ByteMasks mw = domain_masks(w64);
+    const uint64_t ndc = ~mw.dc & H;
+    const uint32_t ll = ndc ? (uint32_t)(__ffsll((long long)ndc) - 1) >> 3 : 8u;
+    if (ll > 7 || ll < 1) return 2;
+    const uint64_t below = (1ull << (8 * ll)) - 1ull;
+    if (mw.dot & below) return 0;                                    // a later dot owns this run
+    const uint32_t stop_c = (uint32_t)(w64 >> (8 * ll)) & 0xFF;
+    if (!d_is_boundary(stop_c)) return 0;
+    const uint32_t lo = (uint32_t)(w64 & below), hi = (uint32_t)((w64 & below) >> 32);
+    uint32_t slot = tld_tab_slot(lo, hi);
+    bool alone = false;
+    for (;;) {
+        const uint2 t = tldtab[slot];
+        if ((t.y >> 24) == 0) return 0;
+        if (t.x == lo && (t.y & 0xFFFFFFu) == hi) { alone = (t.y >> 24) & 1; break; }
+        slot = (slot + 1) & ((1u << TLD_TAB_BITS) - 1);
+    }
+    if (!alone) return 2;
+    ByteMasks m[NB];
+    uint32_t consumed = 0;
+    bool open = true;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        m[k] = domain_masks(b[k]);
+        const uint64_t nm = ~m[k].dc & H;
+        const uint32_t ck = nm ? (uint32_t)__clzll((long long)nm) >> 3 : 8u;   // domain chars at the top of word k
+        if (open) { consumed += ck; open = ck == 8; }
+    }
+    if (consumed == 8 * NB && j != 8 * NB) return 2;                 // the name reaches further back than the context
+    uint64_t bad = 0, high = mw.high & below;
+    uint32_t ndots = 0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const uint32_t in_k = consumed > 8u * k ? min(consumed - 8u * k, 8u) : 0u;     // bytes of word k that belong to the run (its top ones)
+        const uint64_t r = in_k == 0 ? 0ull : (~0ull << (64 - 8 * in_k));
+        // the byte to the right (one position closer to the label) moved onto each byte; right of b[0]'s top byte stands the label's first byte
+        const uint64_t d = (m[k].dot >> 8) | (k ? (m[k ? k - 1 : 0].dot << 56) : 0ull);
+        const uint64_t sd = (m[k].dash >> 8) | (k ? (m[k ? k - 1 : 0].dash << 56) : 0ull);
+        bad |= ((m[k].dot & (d | sd)) | (m[k].dash & d)) & r;        // empty label, label starting with '-', label ending with '-'
+        ndots += (uint32_t)__popcll(m[k].dot & r);
+        high |= m[k].high & r;
+    }
+    // leftmost byte of the run and the byte in front of it, by their index in address order (word NB-1 holds the lowest addresses)
+    const uint32_t li = 8 * NB - consumed, fi = li - 1;
+    uint32_t left_c = 0, first_c = 0x100u;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const uint32_t wi = (uint32_t)(NB - 1 - k);                   // index in address order of word k
+        if ((li >> 3) == wi) left_c = (uint32_t)(b[k] >> (8 * (li & 7))) & 0xFF;
+        if (consumed < 8 * NB && (fi >> 3) == wi) first_c = (uint32_t)(b[k] >> (8 * (fi & 7))) & 0xFF;
+    }
+    const uint32_t lastc = (uint32_t)(w64 >> (8 * (ll - 1))) & 0xFF;
+    const bool any_bad = bad != 0 || lastc == '-' || consumed == 0 || left_c == '.' || left_c == '-';
+    if (any_bad || ndots == 0 || 1 + ndots < min_labels) return 0;
+    if (first_c != 0x100u && !d_is_boundary(first_c)) return 0;
+    if (high) return 2;                                              // needs the UTF-8 check of the general path
+    start = j - consumed; end = j + ll;
+    return 1;
+}
+
 __device__ bool all_hex(const LogView& lg, uint32_t s, uint32_t n) {
     for (uint32_t k = 0; k < n; ++k) if (!d_is_hex(lg.at(s + k))) return false;
     return true;
@@ -1262,6 +1333,20 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         uint32_t ds = 0, de = 0;
         if constexpr (DOM) {
             bool todo = kind == RARE_DOM;
+            // 48 context bytes in registers first (val_domain_ctx): most of what k_validate_dom leaves is a name that is merely longer than ITS context
+            const bool wide = todo && ra.pos >= 48 && ra.pos + 8 <= lg.len;
+            if (__ballot(wide)) {
+                if (wide) {
+                    uint64_t cb[6];
+                    uint2 cw8;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) __builtin_memcpy(&cb[k], lg.p + ra.pos - 8 * (k + 1), 8);
+                    __builtin_memcpy(&cw8, lg.p + ra.pos, 8);
+                    uint32_t s2 = 0, e2 = 0;
+                    const int rw = val_domain_ctx<6>(tldtab_p, p.min_labels, ra.pos, cw8, cb, s2, e2);
+                    if (rw != 2) { todo = false; dr = rw == 1 ? WALK_YES : WALK_NO; ds = s2; de = e2; }
+                }
+            }
             const bool inner = todo && ra.pos >= WIN_BACK && ra.pos + (WIN - WIN_BACK) <= lg.len;
             if (__ballot(inner)) {
                 if (inner) fill_window(ra.pos - WIN_BACK);
