@@ -1176,7 +1176,22 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
                     bool hex = true;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) hex = hex && hex4((uint32_t)w[k]) && hex4((uint32_t)(w[k] >> 32));
-                    if (hex && tl > 32) hex = all_hex_wide(s + 32, tl - 32);
+                    if (hex && tl > 32) {
+                        // bytes 32..63 in one round trip (the hash lengths are multiples of 8: whole words only); a SHA-384 / SHA-512 goes on from byte 64.
+                        // (all_hex_wide alone compiled to a chain: load 4 bytes, wait, test, branch — eight round trips for a SHA-256)
+                        if (ra.pos + 64 <= lg.len) {
+                            uint64_t v[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) __builtin_memcpy(&v[k], s + 32 + 8 * k, 8);
+                            bool h2 = true;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) h2 = h2 & (((int)tl - 32 - 8 * k < 8) | (hex4((uint32_t)v[k]) & hex4((uint32_t)(v[k] >> 32))));
+                            hex = h2;
+                            if (hex && tl > 64) hex = all_hex_wide(s + 64, tl - 64);
+                        } else {
+                            hex = all_hex_wide(s + 32, tl - 32);
+                        }
+                    }
                     if (hex) {
                         c.start = ra.pos; c.len_type = tl | ((uint32_t)ht << 24); emit = true;
                         if (tok_filter) {
