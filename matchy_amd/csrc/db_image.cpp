@@ -346,8 +346,9 @@ void DbImage::build_lit2pat(std::vector<uint32_t>& off, std::vector<uint32_t>& i
 }
 
 bool DbImage::build_ac_dfa(std::vector<uint32_t>& next, std::vector<uint8_t>& cls, uint32_t& k, std::vector<uint32_t>& node_off,
-                           size_t max_bytes) const {
+                           size_t max_bytes, bool* alnum_literal) const {
     next.clear(); cls.assign(256, 0); node_off.clear(); k = 0;
+    if (alnum_literal) *alnum_literal = true;   // until the whole trie has been seen
     if (!has_glob) return false;
     const uint8_t* pg = bytes.data() + pg_off;
     const uint32_t ac_start = rd32(pg + 20), ac_size = rd32(pg + 24);
@@ -378,6 +379,7 @@ bool DbImage::build_ac_dfa(std::vector<uint32_t>& next, std::vector<uint8_t>& cl
     };
     // breadth-first numbering of the reachable nodes
     std::vector<uint32_t> state_of(ac_size / 4 + 1, 0xFFFFFFFFu), depth;
+    std::vector<uint8_t> alnum_path(1, 1);   // the bytes on the way from the root to this state are ASCII letters and digits
     std::vector<Edge> flat, tmp;        // goto edges of all states, CSR by state
     std::vector<size_t> edge_begin;
     bool used[256] = {false};
@@ -393,6 +395,8 @@ bool DbImage::build_ac_dfa(std::vector<uint32_t>& next, std::vector<uint8_t>& cl
                 state_of[e.target / 4] = (uint32_t)node_off.size();
                 node_off.push_back(e.target);
                 depth.push_back(depth[s] + 1);
+                const uint8_t c = e.ch;
+                alnum_path.push_back(alnum_path[s] && ((c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z')));
             }
         }
         edge_begin.push_back(flat.size());
@@ -415,6 +419,13 @@ bool DbImage::build_ac_dfa(std::vector<uint32_t>& next, std::vector<uint8_t>& cl
     next.assign(n * (size_t)k, 0);
     std::vector<uint8_t> has_out(n);
     for (size_t s = 0; s < n; ++s) has_out[s] = ac[node_off[s] + 3] != 0;
+    if (alnum_literal) {
+        // The state after a text of letters and digits is a node whose path consists of them (the longest suffix of the text that is a prefix of a
+        // literal), and what such a node puts out are suffixes of its path: if none of these nodes has output, no such text contains a literal.
+        bool any = false;
+        for (size_t s = 1; s < n && !any; ++s) any = alnum_path[s] && has_out[s];
+        *alnum_literal = any;
+    }
     // states are in breadth-first order, so a valid failure link (strictly shallower) is always resolved already
     for (size_t s = 0; s < n; ++s) {
         uint32_t* row = &next[s * k];

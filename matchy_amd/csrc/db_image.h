@@ -64,8 +64,9 @@ struct DbImage {
     // next[state * k + cls[byte]] = next state | 0x80000000 when that state has output literals; node_off[state] is the
     // node's offset in the AC section. Returns false (nothing built) when the section is empty, malformed in a way the
     // flattening does not handle, or the table would exceed `max_bytes`; the kernels then walk the stored nodes.
+    // *alnum_literal (optional): some literal consists of ASCII letters and digits only (a node with output whose path from the root does).
     bool build_ac_dfa(std::vector<uint32_t>& next, std::vector<uint8_t>& cls, uint32_t& k, std::vector<uint32_t>& node_off,
-                      size_t max_bytes) const;
+                      size_t max_bytes, bool* alnum_literal = nullptr) const;
 };
 
 }  // namespace mxy

@@ -361,7 +361,10 @@ void DeviceDb::upload(const DbImage& img, int dev) {
             uint32_t k = 0;
             size_t limit = (size_t)8 << 30;
             if (const char* env = getenv("MATCHY_AMD_DFA_MAX_MB")) limit = (size_t)atoll(env) << 20;
-            if (img.build_ac_dfa(nx, cls, k, noff, limit)) {
+            bool alnum_literal = true;
+            view.ac_alnum = 1;
+            if (img.build_ac_dfa(nx, cls, k, noff, limit, &alnum_literal)) {
+                view.ac_alnum = alnum_literal ? 1u : 0u;
                 // case-insensitive: the automaton holds lower-cased literals and the text is ASCII-lower-cased while it is
                 // walked (paraglob_offset.rs:1198-1206) — here by giving 'A'..'Z' the classes of 'a'..'z'
                 if (img.match_mode == 1) for (int c = 'A'; c <= 'Z'; ++c) cls[c] = cls[c + 32];

@@ -736,6 +736,10 @@ __global__ __launch_bounds__(256) void k_lookup(LookupParams p, DevDb db) {
                 if (db.has_ip && d_parse_ipv6(text, tl, seg) && trie_v6(db, seg, off, pfx)) { h.kind = 2; h.a = off; h.prefix_len = (uint8_t)pfx; emit = true; }
             } else {
                 // producers that know already (k_validate_dom's suffix filter) say so in the candidate: no automaton walk then
+                // a token of letters and digits in a database whose automaton has no literal made of them: the literal table alone can hold it
+                const bool alnum_tok = type == IT_MD5 || type == IT_SHA1 || type == IT_SHA256 || type == IT_SHA384 || type == IT_SHA512 ||
+                                       type == IT_BITCOIN || type == IT_ETHEREUM || type == IT_MONERO;
+                if (!db.ac_alnum && alnum_tok) c.pad = CAND_NO_GLOB;
                 if (!GLOB && p.ac_filter && p.early_glob && c.pad == CAND_GLOB) {
                     // queued for the glob pass by its producer (TokParams::glob_work_d): that pass runs beside this one
                 } else if (!GLOB && p.ac_filter && (c.pad == CAND_GLOB || (c.pad != CAND_NO_GLOB && (defer_unwalked || ac_touches_output(db, dv, text, tl))))) defer = true;

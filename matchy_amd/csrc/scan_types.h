@@ -104,6 +104,8 @@ struct DevDb {
     const uint32_t* lit2pat_off;  // [n_ac_lits + 1]
     const uint32_t* lit2pat;
     uint32_t n_ac_lits;
+    uint32_t ac_alnum;            // 0: every literal of the automaton holds a byte that is no ASCII letter or digit, so a text of letters and digits only
+                                  // (hex hashes, Base58 / Bech32 / 0x addresses: the long tokens) cannot contain one — no walk, no glob pass for it
     // public-suffix table
     const PslSlot* psl_slots;
     uint32_t psl_mask;

@@ -1144,7 +1144,11 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
     // a hash can only hit through the literal table when the database has no glob section (with one, a substring literal or a glob may
     // match it: every valid hash is listed); DevDb::lit_bm then also holds the keys of 32 bytes and more, hashed from their first 32
     // bytes and their length
-    const bool tok_filter = p.filter_lit && !db.has_glob && db.lit_bm != nullptr;
+    // ... or when no literal of its automaton consists of letters and digits only (DevDb::ac_alnum: a million domain names as substring patterns,
+    // globs over host names): neither a substring literal nor a glob can match a token then, and the walk of a 64-byte hash through the automaton —
+    // 64 dependent row loads, in the last pass of the step — is not needed to know it
+    const bool lit_only = p.filter_lit && !db.has_glob && db.lit_bm != nullptr;
+    const bool tok_filter = p.filter_lit && db.lit_bm != nullptr && (!db.has_glob || !db.ac_alnum);
     for (uint32_t base = blockIdx.x * blockDim.x; base < nt; base += stride) {
         const uint32_t i = base + threadIdx.x;
         RareAnchor ra{0, 0xFF};
@@ -1409,7 +1413,7 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         // without globs only a literal key can match them, and the bitmap of the keys says which of them could (an application log with
         // an address in every fourth line, a proxy log with 2 M long host names: the lookup pass behind this one read every one of them
         // again, 0.1-0.2 ms at the end of the step)
-        if (tok_filter && emit) {
+        if (lit_only && emit) {
             const uint32_t ty = c.len_type >> 24;
             if ((ty == IT_EMAIL || ty == IT_DOMAIN) && !lit_bm_may_hit(db, lg, c.start, c.len_type & 0xFFFFFFu, ty == IT_EMAIL)) { emit = false; ++unlisted; }
         }

@@ -1773,3 +1773,45 @@ def test_literal_hash_vectors_through_matchy_query(M):
         if ref.endswith(":53"):
             assert [d["source"] for d in db.query_json("evil.com")[1]] == ["literal", "glob"]
         db.close()
+
+
+@pytest.mark.parametrize("alnum_literal", [False, True])
+def test_long_tokens_in_databases_with_globs(M, oracle, alnum_literal):
+    """DevDb::ac_alnum: when no literal of the glob automaton consists of letters and digits only, a long token (hex hash, Base58 / 0x address)
+    cannot contain one — the scan then decides tokens through the literal table alone (bitmap in k_validate<4>, no automaton walk, no glob
+    pass). With one such literal in the database (`glob:deadbeef`, `*cafe12*`) the tokens take the glob pass as before. Both ways: GPU == oracle,
+    through every device entry, over tokens that are literal keys, that contain the substring literal, and that are neither."""
+    import hashlib
+    rng = random.Random(77)
+    keys = [hashlib.md5(b"k%d" % i).hexdigest() for i in range(40)] + [hashlib.sha256(b"k%d" % i).hexdigest() for i in range(40)] + \
+           [hashlib.sha1(b"k%d" % i).hexdigest() for i in range(20)]
+    b = M.DatabaseBuilder(build_epoch=3)
+    for i, k in enumerate(keys):
+        b.add_entry(k, {"h": i})
+    for k, v in [("*.evil-domain.com", {"g": 1}), ("glob:phish.example", {"g": 2}), ("bad-??.example.[a-c]om", {"g": 3}), ("203.0.113.0/24", {"n": 1}),
+                 ("mail.corp.example", {"l": 1})]:
+        b.add_entry(k, v)
+    if alnum_literal:
+        b.add_entry("glob:deadbeef", {"g": "substring"})
+        b.add_entry("*cafe12*", {"g": "star"})
+    blob = b.build()
+    lines = []
+    for i in range(6000):
+        r = rng.random()
+        if r < 0.2:
+            tok = rng.choice(keys)
+        elif r < 0.4:
+            h = hashlib.sha256(b"x%d" % i).hexdigest()
+            tok = h[:20] + rng.choice(["deadbeef", "cafe1234"]) + h[28:]
+        elif r < 0.5:
+            tok = "0x" + hashlib.sha1(b"e%d" % i).hexdigest()                # Ethereum-shaped (all lower case: accepted)
+        elif r < 0.6:
+            tok = "1A1zP1eP5QGefi2DMPTfTL5SLmv7DivfNa"                       # a valid Base58Check address
+        else:
+            tok = hashlib.new(rng.choice(["md5", "sha1", "sha256", "sha512"]), b"r%d" % i).hexdigest()
+        host = rng.choice(["www.evil-domain.com", "phish.example.net", "mail.corp.example", "bad-ab.example.com", "ok.example.org"])
+        lines.append(f"203.0.113.{i % 250} {host} id={tok} user=a{i}@{host}".encode())
+    text = b"\n".join(lines) + b"\n"
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, text)
+    assert gs == ws and gh == wh and gl == wl
+    assert len(gh) > 3000, len(gh)

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Per-kernel instruction and wave-cycle counters of one bench step on a log shape: tools/pmc_kernel.sh <shape> [tag]   (GPU box, repo root)
+# Per-kernel instruction and wave-cycle counters of one bench step: tools/pmc_kernel.sh <shape> [tag] [more bench args, e.g. --config c3b]   (GPU box, repo root)
 # One rocprofv3 --pmc pass (no trace domains beside it). Millions per launch, averaged over the launches of the run.
 export TMPDIR=/tmp
-SH=$1; TAG=${2:-$1}
+SH=$1; TAG=${2:-$1}; shift; shift
 OUT=$PWD/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_FLAT SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $OUT -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --no-scatter-gather --pipelined 0 --log-shape $SH > $OUT.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_FLAT SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $OUT -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --no-scatter-gather --pipelined 0 --log-shape $SH "$@" > $OUT.log 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
