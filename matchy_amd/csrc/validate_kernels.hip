@@ -622,6 +622,83 @@ __device__ bool val_email_finish(const LogView& lg, const DevDb& db, uint32_t at
     return true;
 }
 
+// extract_email_at (ext:891-950) on context words in registers instead of the byte and word loops above, for an '@' in the middle of a line (an
+// application log has one in every fourth line: 1.9 M per batch, each a chain of a dozen dependent loads through the loops): Lw[k] =
+// log[at-8(k+1), at-8k) — the local part grows leftwards from the top byte of Lw[0] —, Rw[k] = log[at+1+8k, at+9+8k) — the domain part
+// grows rightwards from the low byte of Rw[0]. The rules are conjunctive, so their order does not matter: local part not empty, a boundary in
+// front of it, no two dots in a row, a letter; domain part (ASCII domain characters) not empty, a boundary behind it, a dot in it, a public
+// suffix at its end. The suffix test takes the shortcut of val_domain: a last label of <= 7 bytes is looked up in the exact table of last labels
+// (absent: no suffix can end the name; alone a suffix: done); everything else asks psl_suffix_exists as before.
+// Returns 0 (no address), 1 (address: start / end set) or 2 (a part is longer than its context: the loops decide).
+template <int NL, int NR>
+__device__ __forceinline__ int val_email_ctx(const uint2* tldtab, const DevDb& db, const LogView& lg, uint32_t at, const uint64_t (&Lw)[NL],
+                                             const uint64_t (&Rw)[NR], uint32_t& start, uint32_t& end) {
+    constexpr uint64_t H = 0x8080808080808080ull;
+    uint32_t nl = 0, nr = 0;
+    bool open = true;
+    LocalMasks lm[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        lm[k] = email_local_masks(Lw[k]);
+        const uint64_t nm = ~lm[k].loc & H;
+        const uint32_t ck = nm ? (uint32_t)__clzll((long long)nm) >> 3 : 8u;   // local-part characters at the top of word k
+        if (open) { nl += ck; open = ck == 8; }
+    }
+    if (nl == 8 * NL) return 2;
+    ByteMasks rm[NR];
+    open = true;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        rm[k] = domain_masks(Rw[k]);
+        const uint64_t nm = ~(rm[k].dc & ~rm[k].high) & H;                     // is_domain_char (ext:1639): ASCII only
+        const uint32_t ck = nm ? (uint32_t)(__ffsll((long long)nm) - 1) >> 3 : 8u;   // domain characters at the bottom of word k
+        if (open) { nr += ck; open = ck == 8; }
+    }
+    if (nr == 8 * NR) return 2;
+    if (nl == 0 || nr == 0) return 0;
+    bool dotdot = false, has_letter = false, has_dot = false;
+    uint32_t first_c = 0, stop_c = 0, last_dot = 0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const uint32_t in_k = nl > 8u * k ? min(nl - 8u * k, 8u) : 0u;          // bytes of word k that belong to the local part (its top ones)
+        const uint64_t r = in_k == 0 ? 0ull : (~0ull << (64 - 8 * in_k));
+        const uint64_t d = (lm[k].dot >> 8) | (k ? (lm[k ? k - 1 : 0].dot << 56) : 0ull);   // the byte to the right is a dot (right of Lw[0]'s top byte stands the '@')
+        dotdot |= (lm[k].dot & d & r) != 0;
+        has_letter |= (lm[k].alp & r) != 0;
+        const uint32_t fi = 8 * NL - 1 - nl;                                      // byte in front of the local part, index in address order
+        if ((fi >> 3) == (uint32_t)(NL - 1 - k)) first_c = (uint32_t)(Lw[k] >> (8 * (fi & 7))) & 0xFF;
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const uint32_t in_k = nr > 8u * k ? min(nr - 8u * k, 8u) : 0u;          // bytes of word k that belong to the domain part (its low ones)
+        const uint64_t r = in_k == 8 ? ~0ull : ((1ull << (8 * in_k)) - 1ull);
+        const uint64_t dots = rm[k].dot & r;
+        if (dots) { has_dot = true; last_dot = 8u * k + ((63u - (uint32_t)__clzll((long long)dots)) >> 3); }
+        if ((nr >> 3) == (uint32_t)k) stop_c = (uint32_t)(Rw[k] >> (8 * (nr & 7))) & 0xFF;
+    }
+    if (!d_is_boundary(first_c) || !d_is_boundary(stop_c)) return 0;
+    if (dotdot || !has_letter || !has_dot) return 0;
+    const uint32_t e = at + 1 + nr, ll = nr - 1 - last_dot;
+    bool suffix = false, decided = false;
+    if (ll >= 1 && ll <= 7) {
+        uint2 w;
+        __builtin_memcpy(&w, lg.p + at + 2 + last_dot, 8);                        // the last label (the caller keeps 8 bytes behind the context readable)
+        const uint32_t lo = ll >= 4 ? w.x : (w.x & ((1u << (8 * ll)) - 1u));
+        const uint32_t hi = ll > 4 ? (w.y & ((1u << (8 * (ll - 4))) - 1u)) : 0u;
+        uint32_t slot = tld_tab_slot(lo, hi);
+        for (;;) {
+            const uint2 t = tldtab[slot];
+            if ((t.y >> 24) == 0) { decided = true; break; }                      // no suffix ends with this label
+            if (t.x == lo && (t.y & 0xFFFFFFu) == hi) { if ((t.y >> 24) & 1) { decided = true; suffix = true; } break; }
+            slot = (slot + 1) & ((1u << TLD_TAB_BITS) - 1);
+        }
+    }
+    if (!decided) suffix = psl_suffix_exists(db, lg.p, at + 1, e);
+    if (!suffix) return 0;
+    start = at - nl; end = e;
+    return 1;
+}
+
 // ---- SHA-256, Keccak-f[1600], base58, bech32 for the checksum validators of k_rare. All state lives in registers
 // (fully unrolled rounds, static indices); byte strings (the token and the decoded address) live in a per-lane LDS
 // scratch, so nothing goes to scratch memory.
@@ -1309,6 +1386,25 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
         // e-mail anchors: the local part leftwards (a lane that meets a long run gets the wave's help), then the rest
         {
             bool is_at = MISC && kind == RARE_AT;
+            if constexpr (MISC) {
+                // 48 bytes in front of the '@' and 32 behind it in registers first (val_email_ctx)
+                const bool wide = is_at && ra.pos >= 48 && ra.pos + 1 + 32 + 8 <= lg.len;
+                if (__ballot(wide)) {
+                    if (wide) {
+                        uint64_t lw[6], rw[4];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) __builtin_memcpy(&lw[k], lg.p + ra.pos - 8 * (k + 1), 8);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) __builtin_memcpy(&rw[k], lg.p + ra.pos + 1 + 8 * k, 8);
+                        uint32_t s2 = 0, e2 = 0;
+                        const int rw_ = val_email_ctx<6, 4>(db.tld_tab, db, lg, ra.pos, lw, rw, s2, e2);
+                        if (rw_ != 2) {
+                            is_at = false;
+                            if (rw_ == 1) { c.start = s2; c.len_type = (e2 - s2) | ((uint32_t)IT_EMAIL << 24); emit = true; }
+                        }
+                    }
+                }
+            }
             if constexpr (MISC) {
                 // the window first: most addresses are short and stand in the middle of a line
                 const bool inner = is_at && ra.pos >= WIN_BACK && ra.pos + (WIN - WIN_BACK) <= lg.len;
