@@ -677,14 +677,15 @@ def test_domain_rules_structured_fuzz(M, oracle, seed):
     # lookup path: database with a sample of the valid names (+ one IP so that the trie exists)
     valid = sorted({v for t, s, e, v in want if t == "Domain"})
     assert len(valid) > 300
-    b = M.DatabaseBuilder(build_epoch=3)
-    for v in valid[::5]:
-        b.add_entry("literal:" + v, {"n": len(v)})
-    b.add_entry("192.0.2.1", {"ip": True})
-    blob = b.build()
-    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, buf)
-    assert gs == ws and gh == wh and gl == wl
-    assert len(gh) >= len(valid[::5])
+    for ci in (False, True):   # case-insensitive: the bitmap test of the general-walk names folds ASCII and leaves non-ASCII / long names listed
+        b = M.DatabaseBuilder(build_epoch=3, case_insensitive=ci)
+        for v in valid[::5]:
+            b.add_entry("literal:" + v, {"n": len(v)})
+        b.add_entry("192.0.2.1", {"ip": True})
+        blob = b.build()
+        gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, buf)
+        assert gs == ws and gh == wh and gl == wl
+        assert len(gh) >= len(valid[::5])
 
 
 @pytest.mark.parametrize("seed", [1, 2])
@@ -1815,3 +1816,27 @@ def test_long_tokens_in_databases_with_globs(M, oracle, alnum_literal):
     gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, text)
     assert gs == ws and gh == wh and gl == wl
     assert len(gh) > 3000, len(gh)
+
+
+@pytest.mark.parametrize("ci", [False, True])
+def test_email_addresses_as_database_keys(M, oracle, ci):
+    """E-mail candidates go through the literal-key bitmap before they are listed (lit_bm_may_hit: first 32 bytes + length, ASCII-folded for a
+    case-insensitive database): a database keyed with a sample of the addresses of a generated log — short ones, ones longer than 32 bytes,
+    upper-case variants of the keys in the log — must give the oracle's match set through every device entry."""
+    buf = _long_emails(5, count=2500)
+    found = sorted({v for t, s, e, v in oracle.extract(buf) if t == "Email"})
+    assert len(found) > 300 and any(len(v) > 32 for v in found) and any(len(v) <= 32 for v in found)
+    keys = found[::3]
+    b = M.DatabaseBuilder(build_epoch=4, case_insensitive=ci)
+    for v in keys:
+        b.add_entry("literal:" + v, {"n": len(v)})
+    b.add_entry("192.0.2.1", {"ip": True})
+    blob = b.build()
+    # the same addresses again in upper case (hits only in the case-insensitive database) and with one byte changed (never hits)
+    extra = bytearray()
+    for v in keys[:200]:
+        extra += b" " + v.upper().encode() + b" " + (v[:-1] + ("x" if v[-1] != "x" else "y")).encode() + b"\n"
+    text = buf + b"\n" + bytes(extra)
+    gh, gl, gs, wh, wl, ws = _scan_both(M, oracle, blob, text)
+    assert gs == ws and gh == wh and gl == wl
+    assert len(gh) >= len(keys)
