@@ -211,6 +211,34 @@ struct SparseWriter {
     }
 };
 
+// One entry per lane held in REGISTERS in front of a SparseWriter (the long tokens): the LDS stage has seven slots — this kernel's 40 KiB per
+// workgroup are spoken for — and an endpoint or application log carries eight long tokens per 2 KiB block, so the stage was flushed in nearly
+// every block: kernel-argument loads, the chunk state through LDS, a store, three wave barriers, with the wave waiting at each step (hash-dense:
+// 392 M vector instructions but 1.24 ms, where 328 M take 0.65). A lane now keeps its token until it finds another one; then every lane's
+// entry leaves in ONE reservation (the direct path of SparseWriter::append). A web-server log flushes once, at the end of the wave's work.
+template <int WHICH>
+struct LaneHeldWriter {
+    SparseWriter<WHICH> sw;
+    uint2 held = make_uint2(0u, 0xFFu);
+    bool has = false;
+    __device__ __forceinline__ explicit LaneHeldWriter(uint2* lds) : sw(lds) {}
+    __device__ __forceinline__ void flush_held() {
+        const uint64_t m = __ballot(has);
+        if (m == 0) return;
+        const typename SparseWriter<WHICH>::Dest d = SparseWriter<WHICH>::dest();
+        const uint32_t b = sw.reserve(d, (uint32_t)__popcll(m));
+        const uint32_t rank = mbcnt64(m);
+        if (has && b + rank < d.cap) d.out[b + rank] = held;
+        has = false;
+    }
+    // all lanes of the (converged) wave call this
+    __device__ __forceinline__ void append(bool emit, const uint2& v) {
+        if (__ballot(emit && has)) flush_held();
+        if (emit) { held = v; has = true; }
+    }
+    __device__ __forceinline__ void finish() { flush_held(); sw.finish(); }
+};
+
 constexpr uint32_t V4_STAGE = CAND_STAGE * sizeof(Candidate) / sizeof(uint2);
 struct V4Lookup {
     uint2* stage;        // V4_STAGE entries of LDS owned by this wave (the CandWriter's buffer)
@@ -545,7 +573,7 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     V4Lookup vl{reinterpret_cast<uint2*>(wb_cand[wave]), 0u};   // TokParams::inline_v4: the same LDS holds {start, address} pairs
     DomWriter cw_dom;
     SparseWriter<0> cw_misc(wb_misc[wave]);   // rare anchors and long tokens are sparse: dense lists
-    SparseWriter<1> cw_tok(wb_tok[wave]);
+    LaneHeldWriter<1> cw_tok(wb_tok[wave]);
     WaveCtx cx{&p, raw32, ctab, bloom, db.ip_bm24, 0u, 0u};
     PendingV4 pend;
     const uint32_t lane_off = lane << 2;
