@@ -635,6 +635,17 @@ void Scanner::slice_params(int sl, const uint8_t* dptr, uint32_t len, uint32_t l
     }
     L.grid_anchor = (int)std::min<uint32_t>((tp.n_segs + 3) / 4, (uint32_t)n_cu_ * L.gm[0]);
     if (L.grid_anchor < 1) L.grid_anchor = 1;
+    {
+        // starting chunk of k_anchor's sparse lists when the previous batch filled them (SparseWriter in k_anchor.hip): a quarter of what a
+        // wave wrote then, in whole 64-slot steps, at most 4032 (the chunk state holds 12 bits)
+        const uint32_t waves = (uint32_t)L.grid_anchor * 4u;
+        auto chunk_for = [&](uint32_t n_prev) -> uint32_t {
+            if (n_prev < 262144u) return 0u;
+            return std::min<uint32_t>(4032u, std::max<uint32_t>(64u, (n_prev / waves / 4u) & ~63u));
+        };
+        tp.tok_chunk = chunk_for(hint_.n_tok);
+        tp.rare_chunk = chunk_for(hint_.n_rare);
+    }
     LookupParams& lp = L.lp;
     lp = LookupParams{};
     if (lookup) {

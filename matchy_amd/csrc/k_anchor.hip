@@ -162,7 +162,13 @@ struct SparseWriter {
         if (base == 0xFFFFFFFFu || used + n > cap) {
             // the rest of the old chunk stays unused: sentinels
             if (base != 0xFFFFFFFFu) for (uint32_t k = used + lane_id(); k < cap; k += 64) if (base + k < d.cap) d.out[base + k] = make_uint2(0xFFFFFFFFu, 0xFFu);
-            const uint32_t chunk = flushes < 4 ? n : (flushes < 32 ? 64u : 512u);
+            // Dense lists (round 5): the steps above are a BURST on a log that has these anchors in every line — every wave starts with nine small
+            // reservations in its first blocks, all 4096 waves at once: 37 K returning atomics on one line, each wave waiting its turn nine times
+            // (hash-dense: 0.49 of k_anchor's 1.24 ms, measured by handing out the slots without the atomic). The host knows the density from the
+            // previous batch (TokParams::tok_chunk / rare_chunk = a quarter of a wave's share of that list): two to five reservations per wave,
+            // spread over its life.
+            const uint32_t hinted = WHICH ? cold_tok()->tok_chunk : cold_tok()->rare_chunk;
+            const uint32_t chunk = hinted ? hinted : (flushes < 4 ? n : (flushes < 32 ? 64u : 512u));
             cap = chunk < n ? n : chunk;
             uint32_t b = 0;
             if (lane_id() == 0) b = atomicAdd(d.counter, cap);

@@ -242,6 +242,7 @@ struct TokParams {
     uint32_t cand_chunk;      // slots k_anchor reserves per atomic for its IPv4 candidates (64: sparse list, 1024: one per line)
     RareAnchor* rare;         // IPv6 / e-mail anchors
     uint32_t rare_cap;
+    uint32_t rare_chunk;      // 0, or slots per reservation in k_anchor when the previous batch's list was long (SparseWriter; tok_chunk below alike)
     RareAnchor* rare_dom;     // undecided domain anchors (written by k_validate_dom)
     uint32_t rare_dom_cap;
     // databases with globs, forked scans: k_validate_dom queues the candidates it flags CAND_GLOB on a work list of its own (indices into
@@ -251,6 +252,7 @@ struct TokParams {
     uint32_t vmode;           // k_validate: bit 0 = the rare list (IPv6 / e-mail anchors), bit 1 = the rare_dom list, bit 2 = the long tokens
     RareAnchor* tok;          // long-token anchors
     uint32_t tok_cap;
+    uint32_t tok_chunk;
     RareAnchor* heavy;        // tokens that passed the cheap prefilters of k_validate and need k_rare
     uint32_t heavy_cap;
     // Domain anchors that survive k_anchor's prefilter, with 32 bytes of context copied from its LDS window so that
