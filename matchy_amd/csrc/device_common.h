@@ -267,17 +267,26 @@ struct DomWriter {
     // all lanes of the converged wave call this; returns the lane's slot, or 0xFFFFFFFF (not emitting / list full).
     // counter_fn() yields the list counter: it is called only when a new chunk is needed (once per ANCHOR_CHUNK entries), so the
     // caller can fetch the pointer there instead of holding it in registers
-    template <class F>
-    __device__ __forceinline__ uint32_t reserve(bool emit, uint32_t* out, uint32_t cap, F counter_fn) {
+    // static_fn() yields the first slot of the chunk this wave owns WITHOUT a reservation, or 0xFFFFFFFF: every wave of k_anchor needs its first
+    // chunk in its first blocks, all of them at once — 4096 returning atomics on one counter line, served one after the other while every wave
+    // waits for its own (6 % of k_anchor on a web-server log, measured by handing the first chunks out without the atomic). When the previous
+    // batch was dense the host presets the counter to waves x ANCHOR_CHUNK (TokParams::dom_static) and wave w starts in chunk w.
+    template <class F, class G>
+    __device__ __forceinline__ uint32_t reserve(bool emit, uint32_t* out, uint32_t cap, F counter_fn, G static_fn) {
         const uint64_t m = __ballot(emit);
         if (m == 0) return 0xFFFFFFFFu;
         const uint32_t n = (uint32_t)__popcll(m);
         if (base == 0xFFFFFFFFu || used + n > ANCHOR_CHUNK) {
+            const uint32_t own = base == 0xFFFFFFFFu ? static_fn() : 0xFFFFFFFFu;
             pad_rest(out, cap);
-            uint32_t b = 0;
-            uint32_t* const counter = counter_fn();
-            if (lane_id() == 0) b = atomicAdd(counter, ANCHOR_CHUNK);
-            base = __builtin_amdgcn_readfirstlane(b);
+            if (own != 0xFFFFFFFFu) {
+                base = own;
+            } else {
+                uint32_t b = 0;
+                uint32_t* const counter = counter_fn();
+                if (lane_id() == 0) b = atomicAdd(counter, ANCHOR_CHUNK);
+                base = __builtin_amdgcn_readfirstlane(b);
+            }
             used = 0;
         }
         uint32_t slot = 0xFFFFFFFFu;

@@ -814,8 +814,21 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
     for (int k = 0; k < ns; ++k) slice_params(k, dptr, len, cuts[k], cuts[k + 1], lookup, host_mirror, launch_[k]);
     early_glob_ = early_glob_ && launch_[0].lp.early_glob != 0;
     // the counter blocks are zero already when the last scan ended with fetch() (k_finish copies them out and clears them)
-    if (!counters_clean_) MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters) * MAX_SLICES, stream));
+    if (!counters_clean_) { MXY_HIP(hipMemsetAsync(counters_.p, 0, sizeof(ScanCounters) * MAX_SLICES, stream)); dom_preset_ = 0; }
     counters_clean_ = false;
+    {
+        // First chunks of the domain list without a reservation (DomWriter::reserve): when the previous batch needed more than one chunk per
+        // wave on average, wave w of k_anchor owns chunk w and the counter starts behind those chunks — k_finish of the previous scan has
+        // written that value already when the batches are alike; otherwise it is set here.
+        static const bool env_no_static = getenv("MATCHY_AMD_NO_DOM_STATIC") != nullptr;
+        const uint64_t total = (uint64_t)launch_[0].grid_anchor * 4u * ANCHOR_CHUNK;
+        uint32_t want = 0;
+        if (ns == 1 && !env_no_static && total <= launch_[0].tp.dom_cap && (uint64_t)hint_.n_dom * 2 >= total * 3) want = (uint32_t)total;
+        if (want != dom_preset_) MXY_HIP(hipMemsetD32Async((hipDeviceptr_t)&counters_.p->n_dom, (int)want, 1, stream));
+        dom_preset_ = want;
+        dom_want_ = want;
+        launch_[0].tp.dom_static = want ? ANCHOR_CHUNK : 0u;
+    }
     const bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
     static const int misc_wgs = getenv("MATCHY_AMD_MISC_GRID") ? atoi(getenv("MATCHY_AMD_MISC_GRID")) : 0;
     const DevDb& view = ddb_->view;
@@ -1101,7 +1114,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
     const int ns = n_slices_;
     for (int attempt = 0;; ++attempt) {
         // k_finish: the counter blocks go to pinned host memory and are cleared on the device for the next scan
-        launch_finish(counters_.p, host_slices_, ns, expect_chains_, stream);
+        launch_finish(counters_.p, host_slices_, ns, expect_chains_, dom_want_, stream);
         // side chains that report to k_finish end behind the last event scan_device recorded: the interval ends behind k_finish then
         if (profile_ && expect_chains_) MXY_HIP(hipEventRecord(ev_[4], stream));
         expect_chains_ = 0;   // a rescan sets it again; the spill pass below runs on this stream
@@ -1114,7 +1127,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
             if (aux_stream_) MXY_HIP(hipStreamSynchronize(aux_stream_));
             if (aux2_stream_) MXY_HIP(hipStreamSynchronize(aux2_stream_));
             if (dom_stream_) MXY_HIP(hipStreamSynchronize(dom_stream_));
-            launch_finish(counters_.p, host_slices_, ns, 0u, stream);
+            launch_finish(counters_.p, host_slices_, ns, 0u, dom_want_, stream);
             wait_stream(stream, false);
         }
         counters_clean_ = true;
@@ -1200,6 +1213,7 @@ void Scanner::fetch(ScanOutput& out, bool want_cands, hipStream_t stream, HitMod
             hh.n_tok = std::max(hh.n_tok, q.n_tok); hh.n_rare = std::max(hh.n_rare, q.n_rare); hh.n_rare_dom = std::max(hh.n_rare_dom, q.n_rare_dom);
             hh.n_heavy = std::max(hh.n_heavy, q.n_heavy); hh.n_cand = std::max(hh.n_cand, q.n_cand); hh.n_cand_m = std::max(hh.n_cand_m, q.n_cand_m);
             hh.n_cand_r = std::max(hh.n_cand_r, q.n_cand_r); hh.n_cand_d = std::max(hh.n_cand_d, q.n_cand_d);
+            hh.n_dom = std::max(hh.n_dom, q.n_dom);
         }
         hint_ = hh;
     }

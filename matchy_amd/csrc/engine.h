@@ -217,7 +217,9 @@ private:
     // sparse lists of a web-server log — half a workgroup per CU for the long tokens, an eighth for some lookups — and a log of another
     // shape (two file hashes per line: 18 M tokens) walked such a list with 500 iterations per lane. Batches of one input look alike,
     // so the next scan's grids follow the last scan's counts (grid_for); the first scan of a scanner runs with the defaults.
-    struct ListHint { uint32_t n_tok = 0, n_rare = 0, n_rare_dom = 0, n_heavy = 0, n_cand = 0, n_cand_m = 0, n_cand_r = 0, n_cand_d = 0; } hint_;
+    struct ListHint { uint32_t n_tok = 0, n_rare = 0, n_rare_dom = 0, n_heavy = 0, n_cand = 0, n_cand_m = 0, n_cand_r = 0, n_cand_d = 0, n_dom = 0; } hint_;
+    uint32_t dom_preset_ = 0;   // what ScanCounters::n_dom of slice 0 holds on the device while the counters are clean (k_finish presets it: TokParams::dom_static)
+    uint32_t dom_want_ = 0;     // ... and what the scan in flight asked for
     int grid_for(uint32_t n_hint, uint32_t per_wg, int dflt, int max_per_cu) const;
     bool counters_clean_ = false;   // the device counter blocks are zero (k_finish of the last fetch left them so)
     int last_slices_ = 0;

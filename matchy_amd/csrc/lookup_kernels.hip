@@ -913,7 +913,8 @@ void launch_lookup_early_glob(const LookupParams& p_in, const DevDb& db, int gri
     check_launch("launch_lookup_early_glob");
 }
 // see launch_finish (scan_types.h)
-__global__ __launch_bounds__(256) void k_finish(ScanCounters* dev, ScanCounters* host, uint32_t n_words, uint32_t expect_chains, unsigned long long poll_ticks) {
+__global__ __launch_bounds__(256) void k_finish(ScanCounters* dev, ScanCounters* host, uint32_t n_words, uint32_t expect_chains, unsigned long long poll_ticks,
+                                                uint32_t next_n_dom) {
     uint32_t* d = reinterpret_cast<uint32_t*>(dev);
     uint32_t* h = reinterpret_cast<uint32_t*>(host);
     __shared__ uint32_t gave_up;
@@ -944,13 +945,15 @@ __global__ __launch_bounds__(256) void k_finish(ScanCounters* dev, ScanCounters*
         if (!keep) d[i] = 0;
     }
     __syncthreads();
+    // the next scan's k_anchor starts with one chunk of the domain list per wave already handed out (TokParams::dom_static)
+    if (!keep && threadIdx.x == 0 && next_n_dom) dev->n_dom = next_n_dom;
     if (keep && threadIdx.x == 0) host->error |= 8u;
     __threadfence_system();
 }
-void launch_finish(ScanCounters* dev, ScanCounters* host_pinned, int n_blocks, uint32_t expect_chains, hipStream_t stream) {
+void launch_finish(ScanCounters* dev, ScanCounters* host_pinned, int n_blocks, uint32_t expect_chains, uint32_t next_n_dom, hipStream_t stream) {
     // how long k_finish polls for the side chains before it hands the join back to the host (100 MHz ticks; MATCHY_AMD_FINISH_POLL_US for tests)
     static const unsigned long long poll_ticks = getenv("MATCHY_AMD_FINISH_POLL_US") ? strtoull(getenv("MATCHY_AMD_FINISH_POLL_US"), nullptr, 10) * 100ull : 200000000ull;
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, stream, dev, host_pinned, (uint32_t)(n_blocks * sizeof(ScanCounters) / 4), expect_chains, poll_ticks);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, stream, dev, host_pinned, (uint32_t)(n_blocks * sizeof(ScanCounters) / 4), expect_chains, poll_ticks, next_n_dom);
     check_launch("launch_finish");
 }
 void launch_lookup_spill(const LookupParams& p, const DevDb& db, hipStream_t stream) {

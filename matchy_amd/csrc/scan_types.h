@@ -261,6 +261,8 @@ struct TokParams {
     // planes 1..8 = log[j-24, j+8). dom_cap counts slots.
     uint32_t* dom_list;
     uint32_t dom_cap;
+    uint32_t dom_static;      // 0, or ANCHOR_CHUNK: wave w of k_anchor owns chunk w of the list without a reservation; ScanCounters::n_dom was preset to
+                              // waves x ANCHOR_CHUNK before the launch (Scanner::scan_device / k_finish)
     ScanCounters* counters;
     // inline_v4 = 1 (lookup scans of a database whose /24 bitmap thins the IPv4 candidates): k_anchor looks its IPv4 candidates up
     // itself — a few dozen at a time, whenever a wave has collected them — and writes the hit records through `pk`; no candidate
@@ -274,7 +276,7 @@ struct TokParams {
 // in front of the next one.
 // expect_chains > 0: the kernel first waits (polling ScanCounters::chains_done of block 0, with a time-out that sets error bit 8) until that
 // many side-stream chains have reported their end.
-void launch_finish(ScanCounters* dev, ScanCounters* host_pinned, int n_blocks, uint32_t expect_chains, hipStream_t stream);
+void launch_finish(ScanCounters* dev, ScanCounters* host_pinned, int n_blocks, uint32_t expect_chains, uint32_t next_n_dom, hipStream_t stream);
 
 // Called by every launch wrapper right after its hipLaunchKernelGGL: a launch the runtime rejects (LDS or register budget of
 // another target, bad grid) would otherwise show up as a scan without hits. Throws mxy::HipError (engine.cpp).
