@@ -157,6 +157,29 @@ def test_headline_batch_as_one_launch(M, oracle, size):
     r2.close()
     assert (c1[0] + c2[0], c1[1] + c2[1]) == (st.lines, st.candidates)
     assert h1 + _rebased(h2, cut) == want
+    # The whole batch again, twice, through the same scanner: from its second launch on k_anchor starts with what the scanner learnt from the
+    # previous one — every wave owns its first chunk of the domain list without a reservation (TokParams::dom_static, the counter preset by
+    # k_finish or by the scan), the sparse lists start with chunks sized from the previous batch. Then a batch without a single domain (the
+    # waves mark their own chunks unused; the scanner drops the preset), then the log once more: the same counters and records every time.
+    if size == "headline":
+        for rnd in range(2):
+            r = sc.scan_device(dptr.value, len(log), fetch_mode=3)
+            assert (r.lines, r.candidates, r.n_hits) == (st.lines, st.candidates, len(want)), rnd
+            if rnd == 1:
+                assert r.hits() == want
+            r.close()
+        plain = (b"the quick brown fox jumps over the lazy dog " * 4 + b"\n") * 1_000_000
+        d3 = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(d3), ctypes.c_size_t(len(plain) + 64)) == 0
+        assert hip.hipMemcpy(d3, plain, ctypes.c_size_t(len(plain)), 1) == 0
+        for _ in range(2):
+            r = sc.scan_device(d3.value, len(plain), fetch_mode=3)
+            assert (r.lines, r.n_hits) == (1_000_000, 0)
+            r.close()
+        hip.hipFree(d3)
+        r = sc.scan_device(dptr.value, len(log), fetch_mode=3)
+        assert (r.lines, r.candidates, r.n_hits) == (st.lines, st.candidates, len(want)) and r.hits() == want
+        r.close()
     sc.close(); db.close()
     hip.hipFree(dptr); hip.hipFree(d2)
 
