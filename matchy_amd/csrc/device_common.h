@@ -257,44 +257,50 @@ struct StagedChunkWriter {
 // Chunked writer for the plane-organised domain anchor list (TokParams::dom_list): slots are reserved like in
 // ChunkWriter (one atomic per ANCHOR_CHUNK slots), the caller stores the planes of its slot.
 struct DomWriter {
-    uint32_t base = 0xFFFFFFFFu, used = 0;
+    uint32_t next = 0xFFFFFFFFu, left = 0;   // the wave's current chunk: next free slot, slots left in it (0xFFFFFFFF: no chunk yet)
     __device__ __forceinline__ void pad_rest(uint32_t* out, uint32_t cap) {
-        if (base == 0xFFFFFFFFu) return;
-        for (uint32_t k = used + lane_id(); k < ANCHOR_CHUNK; k += 64)
-            if (base + k < cap) out[dom_plane_index(base + k, 0)] = 0xFFFFFFFFu;
-        used = ANCHOR_CHUNK;
+        if (next == 0xFFFFFFFFu) return;
+        for (uint32_t k = lane_id(); k < left; k += 64)
+            if (next + k < cap) out[dom_plane_index(next + k, 0)] = 0xFFFFFFFFu;
+        next += left;
+        left = 0;
     }
     // all lanes of the converged wave call this; returns the lane's slot, or 0xFFFFFFFF (not emitting / list full).
-    // counter_fn() yields the list counter: it is called only when a new chunk is needed (once per ANCHOR_CHUNK entries), so the
-    // caller can fetch the pointer there instead of holding it in registers
-    // static_fn() yields the first slot of the chunk this wave owns WITHOUT a reservation, or 0xFFFFFFFF: every wave of k_anchor needs its first
-    // chunk in its first blocks, all of them at once — 4096 returning atomics on one counter line, served one after the other while every wave
-    // waits for its own (6 % of k_anchor on a web-server log, measured by handing the first chunks out without the atomic). When the previous
-    // batch was dense the host presets the counter to waves x ANCHOR_CHUNK (TokParams::dom_static) and wave w starts in chunk w.
-    template <class F, class G>
-    __device__ __forceinline__ uint32_t reserve(bool emit, uint32_t* out, uint32_t cap, F counter_fn, G static_fn) {
+    // counter_fn() yields the list counter: it is called only when a new chunk is needed, so the caller can fetch the pointer there instead
+    // of holding it in registers; chunk_fn() the size of such a chunk (a multiple of DOM_TILE, at most ANCHOR_CHUNK).
+    // static_fn() yields the first slot of the ANCHOR_CHUNK slots this wave owns WITHOUT a reservation, or 0xFFFFFFFF: every wave of k_anchor needs
+    // its first chunk in its first blocks, all of them at once — 4096 returning atomics on one counter line, served one after the other while every
+    // wave waits for its own (6 % of k_anchor on a web-server log, measured by handing the first chunks out without the atomic). When the previous
+    // batch was dense the host presets the counter to waves x ANCHOR_CHUNK (TokParams::dom_static) and wave w starts in chunk w. The later
+    // reservations of a wave are spread over the kernel and cost nothing measurable, so they can be small (TokParams::dom_chunk: an eighth of a
+    // wave's share of the previous batch): what a wave leaves unused of its last chunk are slots k_validate_dom reads for nothing.
+    template <class F, class G, class H>
+    __device__ __forceinline__ uint32_t reserve(bool emit, uint32_t* out, uint32_t cap, F counter_fn, G static_fn, H chunk_fn) {
         const uint64_t m = __ballot(emit);
         if (m == 0) return 0xFFFFFFFFu;
         const uint32_t n = (uint32_t)__popcll(m);
-        if (base == 0xFFFFFFFFu || used + n > ANCHOR_CHUNK) {
-            const uint32_t own = base == 0xFFFFFFFFu ? static_fn() : 0xFFFFFFFFu;
+        if (left < n) {
+            const uint32_t own = next == 0xFFFFFFFFu ? static_fn() : 0xFFFFFFFFu;
             pad_rest(out, cap);
             if (own != 0xFFFFFFFFu) {
-                base = own;
+                next = own;
+                left = ANCHOR_CHUNK;
             } else {
+                const uint32_t c = chunk_fn();
                 uint32_t b = 0;
                 uint32_t* const counter = counter_fn();
-                if (lane_id() == 0) b = atomicAdd(counter, ANCHOR_CHUNK);
-                base = __builtin_amdgcn_readfirstlane(b);
+                if (lane_id() == 0) b = atomicAdd(counter, c);
+                next = __builtin_amdgcn_readfirstlane(b);
+                left = c;
             }
-            used = 0;
         }
         uint32_t slot = 0xFFFFFFFFu;
         if (emit) {
-            slot = base + used + (uint32_t)__popcll(m & lanemask_lt());
+            slot = next + (uint32_t)__popcll(m & lanemask_lt());
             if (slot >= cap) slot = 0xFFFFFFFFu;
         }
-        used += n;
+        next += n;
+        left -= n;
         return slot;
     }
 };

@@ -828,6 +828,14 @@ void Scanner::scan_device(const uint8_t* dptr, uint32_t len, bool lookup, hipStr
         dom_preset_ = want;
         dom_want_ = want;
         launch_[0].tp.dom_static = want ? ANCHOR_CHUNK : 0u;
+        // behind the first chunk: an eighth of what a wave wrote last time, in whole tiles, 256..ANCHOR_CHUNK slots (less padding for k_validate_dom
+        // to read; these reservations are spread over the kernel)
+        static const int env_chunk = getenv("MATCHY_AMD_DOM_CHUNK") ? atoi(getenv("MATCHY_AMD_DOM_CHUNK")) : 0;
+        for (int k = 0; k < ns; ++k) launch_[k].tp.dom_chunk = ANCHOR_CHUNK;
+        if (want) {
+            const uint32_t share = hint_.n_dom / ((uint32_t)launch_[0].grid_anchor * 4u) / 8u;
+            launch_[0].tp.dom_chunk = env_chunk > 0 ? (uint32_t)env_chunk : std::min<uint32_t>(ANCHOR_CHUNK, std::max<uint32_t>(256u, share & ~63u));
+        }
     }
     const bool rare_possible = (flags_ & (EX_HASHES | EX_BITCOIN | EX_ETHEREUM | EX_MONERO)) != 0;
     static const int misc_wgs = getenv("MATCHY_AMD_MISC_GRID") ? atoi(getenv("MATCHY_AMD_MISC_GRID")) : 0;

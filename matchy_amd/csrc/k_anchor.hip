@@ -488,7 +488,8 @@ __device__ __forceinline__ void drain_dom(uint32_t* ring, uint32_t& head, uint32
         }
     }
     const uint32_t slot = dw.reserve(keep, p.dom_list, p.dom_cap, [] { return &cold_tok()->counters->n_dom; },
-                                     [] { const uint32_t st = cold_tok()->dom_static; return st ? (blockIdx.x * 4u + (threadIdx.x >> 6)) * st : 0xFFFFFFFFu; });
+                                     [] { const uint32_t st = cold_tok()->dom_static; return st ? (blockIdx.x * 4u + (threadIdx.x >> 6)) * st : 0xFFFFFFFFu; },
+                                     [] { return cold_tok()->dom_chunk; });
     if (slot != 0xFFFFFFFFu) {
         uint32_t* rec = p.dom_list + dom_plane_index(slot, 0);   // the planes of a 64-slot tile are 256 bytes apart
         rec[0] = have_ctx ? j : (j | 0x80000000u);
@@ -892,9 +893,9 @@ __global__ __launch_bounds__(AW * 64) void k_anchor(TokParams p, DevDb db) {
     cw_misc.finish();
     cw_tok.finish();
     // mark the unused tail of every open chunk
-    if (cw_dom.base == 0xFFFFFFFFu && cold_tok()->dom_static) {   // a wave that met no domain anchor: its own chunk (TokParams::dom_static) is all sentinels
-        cw_dom.base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * cold_tok()->dom_static;
-        cw_dom.used = 0;
+    if (cw_dom.next == 0xFFFFFFFFu && cold_tok()->dom_static) {   // a wave that met no domain anchor: its own chunk (TokParams::dom_static) is all sentinels
+        cw_dom.next = (blockIdx.x * 4u + (threadIdx.x >> 6)) * cold_tok()->dom_static;
+        cw_dom.left = cold_tok()->dom_static;
     }
     cw_dom.pad_rest(p.dom_list, p.dom_cap);
     cw_cand.finish(p.cands_a, p.cand_a_cap, &p.counters->n_cand_a, Candidate{0u, 0xFFFFFFFFu, 0u, 0u});

@@ -245,6 +245,7 @@ struct TokParams {
     uint32_t rare_chunk;      // 0, or slots per reservation in k_anchor when the previous batch's list was long (SparseWriter; tok_chunk below alike)
     RareAnchor* rare_dom;     // undecided domain anchors (written by k_validate_dom)
     uint32_t rare_dom_cap;
+    uint32_t dom_chunk;       // slots k_anchor reserves per atomic for the domain list (ANCHOR_CHUNK, or less behind the preset first chunks: dom_static)
     // databases with globs, forked scans: k_validate_dom queues the candidates it flags CAND_GLOB on a work list of its own (indices into
     // `cands`, counter ScanCounters::n_glob_work_d), and the glob pass over them runs beside the lean pass over the rest. nullptr: off
     uint32_t* glob_work_d;
