@@ -1250,6 +1250,14 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
                 for (uint32_t k = 0; k < 32 && ra.pos + k < lg.len; ++k) w[k >> 3] |= (uint64_t)s[k] << (8 * (k & 7));
             }
         }
+        // ... and bytes 32..63 of a longer token in the SAME round trip (a SHA-1 / SHA-256 is looked at to its end in most cases: the second load
+        // behind the test of the first half was another trip to memory for six tokens in ten of an endpoint log)
+        uint64_t v2[4] = {0, 0, 0, 0};
+        const bool wide2 = live && tl > 32 && ra.pos + 64 <= lg.len;
+        if (wide2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) __builtin_memcpy(&v2[k], s + 32 + 8 * k, 8);
+        }
         const uint32_t c0 = (uint32_t)w[0] & 0xFF, c1 = (uint32_t)(w[0] >> 8) & 0xFF, c2 = (uint32_t)(w[0] >> 16) & 0xFF;
         // hashes: token length 32/40/64/96/128 and all hex (ext:1212-1250)
         {
@@ -1264,13 +1272,10 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
                     if (hex && tl > 32) {
                         // bytes 32..63 in one round trip (the hash lengths are multiples of 8: whole words only); a SHA-384 / SHA-512 goes on from byte 64.
                         // (all_hex_wide alone compiled to a chain: load 4 bytes, wait, test, branch — eight round trips for a SHA-256)
-                        if (ra.pos + 64 <= lg.len) {
-                            uint64_t v[4];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) __builtin_memcpy(&v[k], s + 32 + 8 * k, 8);
+                        if (wide2) {
                             bool h2 = true;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) h2 = h2 & (((int)tl - 32 - 8 * k < 8) | (hex4((uint32_t)v[k]) & hex4((uint32_t)(v[k] >> 32))));
+                            for (int k = 0; k < 4; ++k) h2 = h2 & (((int)tl - 32 - 8 * k < 8) | (hex4((uint32_t)v2[k]) & hex4((uint32_t)(v2[k] >> 32))));
                             hex = h2;
                             if (hex && tl > 64) hex = all_hex_wide(s + 64, tl - 64);
                         } else {
@@ -1314,10 +1319,8 @@ __global__ __launch_bounds__(256) void k_validate(TokParams p, DevDb db) {
                     // ... and the bytes behind them, for the one token in sixty that is longer and got this far (a 64-character hash without a
                     // '0' in its first half: 13 % of those that start with 1 or 3; without one anywhere: 2 %): one more round trip for those lanes
                     // instead of a Base58 decode and two SHA-256 in k_rare for eight times as many entries
-                    if (!bad && tl > 32 && ra.pos + 64 <= lg.len) {
-                        uint64_t w2[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) __builtin_memcpy(&w2[k], s + 32 + 8 * k, 8);
+                    if (!bad && wide2) {
+                        const uint64_t (&w2)[4] = v2;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int rem = (int)tl - 32 - 8 * k;
